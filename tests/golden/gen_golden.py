@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own kernels.  Runs only in the build container
+(needs /root/reference and `make -C oracle ref`); the fixtures it writes are plain data (inputs and
+expected outputs) and are what travels -- no reference source or binary is stored under tests/.
+
+What runs:
+  * the reference's compiled C extensions (oracle/_ref, built from the read-only tree by
+    oracle/Makefile with the reference's own flags) on duck-typed field / particle bags;
+  * the reference's Python FDTD (core/maxwell/cpu.py), executed as plain Python: the file is loaded
+    by path with `numba.njit` bound to the identity decorator (what NUMBA_DISABLE_JIT does) because
+    numba is not installed here.
+
+Usage:  python tests/golden/gen_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference/src/lambdapic")
+OUT = Path(__file__).resolve().parent
+
+import oracle  # noqa: E402
+from oracle import driver  # noqa: E402
+from lambdapic_amd.fields import Fields2D, Fields3D  # noqa: E402
+from lambdapic_amd.particles import ParticlesBase  # noqa: E402
+from lambdapic_amd.patch import make_patches_2d  # noqa: E402
+
+C = 299792458.0
+QE = -1.602176634e-19
+ME = 9.1093837139e-31
+SEED = 20260722
+
+PATTRS = ["x", "y", "z", "w", "ux", "uy", "uz", "inv_gamma"]
+PEB = ["ex_part", "ey_part", "ez_part", "bx_part", "by_part", "bz_part"]
+
+
+def load_ref_maxwell():
+    """core/maxwell/cpu.py as plain Python (decorators -> identity, prange -> range)."""
+    nb = types.ModuleType("numba")
+    nb.njit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+    nb.prange = range
+    sys.modules.setdefault("numba", nb)
+    for name in ("lambdapic", "lambdapic.core", "lambdapic.core.utils", "lambdapic.core.maxwell"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    js = types.ModuleType("lambdapic.core.utils.jit_spinner")
+    js.jit_spinner = lambda f: f
+    sys.modules["lambdapic.core.utils.jit_spinner"] = js
+    spec = importlib.util.spec_from_file_location("lambdapic.core.maxwell.cpu",
+                                                  REF / "core/maxwell/cpu.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def rand_fields(f, rng, e_amp=1e12, b_amp=1e4):
+    for a in ("ex", "ey", "ez"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * e_amp
+    for a in ("bx", "by", "bz"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * b_amp
+
+
+def rand_particles_2d(f, n, rng, u_scale=1.0, ipatch=0):
+    p = ParticlesBase(ipatch, 0)
+    p.initialize(n)
+    p.x[:] = f.x0 + rng.uniform(-0.5, f.nx - 0.5, n) * f.dx
+    p.y[:] = f.y0 + rng.uniform(-0.5, f.ny - 0.5, n) * f.dy
+    for a in ("ux", "uy", "uz"):
+        getattr(p, a)[:] = rng.normal(size=n) * u_scale
+    p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+    p.w[:] = rng.uniform(0.5, 1.5, n) * 1e27 * f.dx * f.dy / 10
+    # edge cases: dead slots, NaN position, particles sitting on the patch edge (deposit through
+    # the wrap), fast movers crossing a cell boundary
+    p.is_dead[::17] = True
+    p.x[5] = np.nan
+    p.y[11] = np.nan
+    p.x[20:24] = f.x0 + np.array([-0.49, -0.2, f.nx - 0.51, f.nx - 0.8]) * f.dx
+    p.y[24:28] = f.y0 + np.array([-0.49, -0.2, f.ny - 0.51, f.ny - 0.8]) * f.dy
+    return p
+
+
+def rand_particles_3d(f, n, rng, u_scale=1.0):
+    p = rand_particles_2d(f, n, rng, u_scale)
+    p.z[:] = f.z0 + rng.uniform(-0.5, f.nz - 0.5, n) * f.dz
+    p.w[:] = rng.uniform(0.5, 1.5, n) * 1e27 * f.dx * f.dy * f.dz / 10
+    p.z[13] = np.nan
+    p.z[28:32] = f.z0 + np.array([-0.49, -0.2, f.nz - 0.51, f.nz - 0.8]) * f.dz
+    return p
+
+
+def snap(obj, names, prefix):
+    return {prefix + n: np.array(getattr(obj, n), copy=True) for n in names}
+
+
+def g1_fused_2d(rng):
+    mod = oracle.ref_module("pusher", "unified_pusher_2d")
+    nx, ny, ng, dx, dy = 16, 12, 3, 4e-8, 5e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    fl = [Fields2D(nx, ny, dx, dy, 3 * dx, -2 * dy, ng), Fields2D(nx, ny, dx, dy, 19 * dx, -2 * dy, ng)]
+    pl = []
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, dt=dt, q=QE, m=ME, npatches=2)
+    for k, f in enumerate(fl):
+        rand_fields(f, rng)
+        p = rand_particles_2d(f, 1500, rng, u_scale=1.0 if k == 0 else 0.05, ipatch=k)
+        pl.append(p)
+        out.update({f"x0_{k}": f.x0, f"y0_{k}": f.y0})
+        out.update(snap(f, f.attrs[:6], f"in{k}_"))
+        out.update(snap(p, PATTRS + ["is_dead"], f"in{k}_"))
+    mod.unified_boris_pusher_cpu_2d(pl, fl, 2, dt, QE, ME)
+    for k, (f, p) in enumerate(zip(fl, pl)):
+        out.update(snap(f, ["rho", "jx", "jy", "jz"], f"out{k}_"))
+        out.update(snap(p, PATTRS + PEB, f"out{k}_"))
+    np.savez_compressed(OUT / "g1_fused_2d.npz", **out)
+
+
+def g2_fused_3d(rng):
+    mod = oracle.ref_module("pusher", "unified_pusher_3d")
+    nx, ny, nz, ng, dx, dy, dz = 8, 6, 7, 3, 4e-8, 5e-8, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 3 * dx, -2 * dy, 5 * dz, ng)
+    rand_fields(f, rng)
+    p = rand_particles_3d(f, 1200, rng)
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng, dx=dx, dy=dy, dz=dz, dt=dt, q=QE, m=ME,
+               x0=f.x0, y0=f.y0, z0=f.z0)
+    out.update(snap(f, f.attrs[:6], "in_"))
+    out.update(snap(p, PATTRS + ["is_dead"], "in_"))
+    mod.unified_boris_pusher_cpu_3d([p], [f], 1, dt, QE, ME)
+    out.update(snap(f, ["rho", "jx", "jy", "jz"], "out_"))
+    out.update(snap(p, PATTRS + PEB, "out_"))
+    np.savez_compressed(OUT / "g2_fused_3d.npz", **out)
+
+
+def g3_deposit(rng):
+    nx, ny, ng, dx, dy = 16, 12, 3, 4e-8, 5e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    f = Fields2D(nx, ny, dx, dy, 3 * dx, -2 * dy, ng)
+    p = rand_particles_2d(f, 1500, rng)
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, dt=dt, q=QE, x0=f.x0, y0=f.y0)
+    out.update(snap(p, PATTRS + ["is_dead"], "in_"))
+    oracle.ref_module("current", "cpu2d").current_deposition_cpu_2d([f], [p], 1, dt, QE)
+    out.update(snap(f, ["rho", "jx", "jy", "jz"], "out_"))
+    np.savez_compressed(OUT / "g3_deposit_2d.npz", **out)
+
+    nx, ny, nz, dz = 8, 6, 7, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 3 * dx, -2 * dy, 5 * dz, ng)
+    p = rand_particles_3d(f, 1200, rng, u_scale=0.5)
+    # the standalone 3-D depositor only wraps negative indices (current/cpu3d.c:56-116 with
+    # INDEX3): keep particles one cell inside the upper edges so no index reaches NX
+    for a, n_, d_, o_ in (("x", nx, dx, f.x0), ("y", ny, dy, f.y0), ("z", nz, dz, f.z0)):
+        v = getattr(p, a)
+        np.clip(v, o_ - 0.49 * d_, o_ + (n_ - 0.5) * d_, out=v, where=~np.isnan(v))
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng, dx=dx, dy=dy, dz=dz, dt=dt, q=QE,
+               x0=f.x0, y0=f.y0, z0=f.z0)
+    out.update(snap(p, PATTRS + ["is_dead"], "in_"))
+    oracle.ref_module("current", "cpu3d").current_deposition_cpu_3d([f], [p], 1, dt, QE)
+    out.update(snap(f, ["rho", "jx", "jy", "jz"], "out_"))
+    np.savez_compressed(OUT / "g3_deposit_3d.npz", **out)
+
+
+def g4_interp(rng):
+    nx, ny, ng, dx, dy = 16, 12, 3, 4e-8, 5e-8
+    f = Fields2D(nx, ny, dx, dy, 3 * dx, -2 * dy, ng)
+    rand_fields(f, rng)
+    p = rand_particles_2d(f, 1000, rng)
+    p.x[5] = f.x0
+    p.y[11] = f.y0   # standalone interpolator does not skip NaN positions: keep them finite
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, x0=f.x0, y0=f.y0)
+    out.update(snap(f, f.attrs[:6], "in_"))
+    out.update(snap(p, ["x", "y", "is_dead"], "in_"))
+    oracle.ref_module("interpolation", "cpu2d").interpolation_patches_2d([p], [f], 1)
+    out.update(snap(p, PEB, "out_"))
+    np.savez_compressed(OUT / "g4_interp_2d.npz", **out)
+
+    nx, ny, nz, dz = 8, 6, 7, 6e-8
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 3 * dx, -2 * dy, 5 * dz, ng)
+    rand_fields(f, rng)
+    p = rand_particles_3d(f, 800, rng)
+    p.x[5] = f.x0
+    p.y[11] = f.y0
+    p.z[13] = f.z0
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng, dx=dx, dy=dy, dz=dz, x0=f.x0, y0=f.y0, z0=f.z0)
+    out.update(snap(f, f.attrs[:6], "in_"))
+    out.update(snap(p, ["x", "y", "z", "is_dead"], "in_"))
+    oracle.ref_module("interpolation", "cpu3d").interpolation_patches_3d([p], [f], 1)
+    out.update(snap(p, PEB, "out_"))
+    np.savez_compressed(OUT / "g4_interp_3d.npz", **out)
+
+
+def g5_fdtd(rng, mx):
+    nx, ny, ng, dx, dy = 24, 20, 3, 4e-8, 5e-8
+    dt = 0.5 * 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    f = Fields2D(nx, ny, dx, dy, 0.0, 0.0, ng)
+    rand_fields(f, rng)
+    for a in ("jx", "jy", "jz"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e15
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, dt=dt)
+    out.update(snap(f, f.attrs[:9], "in_"))
+    mx.update_efield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, dx, dy, dt, nx, ny, ng)
+    out.update(snap(f, ["ex", "ey", "ez"], "outE_"))
+    mx.update_bfield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, dx, dy, dt, nx, ny, ng)
+    out.update(snap(f, ["bx", "by", "bz"], "outB_"))
+    np.savez_compressed(OUT / "g5_fdtd_2d.npz", **out)
+
+    nx, ny, nz, dz = 10, 8, 6, 6e-8
+    dt = 0.5 * 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, ng)
+    rand_fields(f, rng)
+    for a in ("jx", "jy", "jz"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e15
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng, dx=dx, dy=dy, dz=dz, dt=dt)
+    out.update(snap(f, f.attrs[:9], "in_"))
+    mx.update_efield_3d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, dx, dy, dz, dt,
+                        nx, ny, nz, ng)
+    out.update(snap(f, ["ex", "ey", "ez"], "outE_"))
+    mx.update_bfield_3d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, dx, dy, dz, dt, nx, ny, nz, ng)
+    out.update(snap(f, ["bx", "by", "bz"], "outB_"))
+    np.savez_compressed(OUT / "g5_fdtd_3d.npz", **out)
+
+
+class RefSorter:
+    """drives the reference's sort_particles_patches_2d like ParticleSort2D.__call__
+    (core/sort/particle_sort.py:196-211) with the default 1-D x buckets."""
+
+    def __init__(self, patches, ispec):
+        self.mod = oracle.ref_module("sort", "cpu2d")
+        self.patches, self.ispec = patches, ispec
+        self.nxb, self.nyb = patches.nx, 1
+        n = patches.npatches
+        mk = lambda: [np.zeros((self.nxb, self.nyb), dtype=np.int64) for _ in range(n)]
+        self.count, self.bmin, self.bmax, self.cnot, self.start = mk(), mk(), mk(), mk(), mk()
+        self.nbuf_last = 0
+
+    def __call__(self):
+        P, s = self.patches, self.ispec
+        parts = [p.particles[s] for p in P]
+        attrs = parts[0].attrs
+        attrs_list = [getattr(q, a) for q in parts for a in attrs]
+        scratch = lambda dt: [np.zeros(q.npart, dtype=dt) for q in parts]
+        self.nbuf_last = self.mod.sort_particles_patches_2d(
+            [q.x for q in parts], [q.y for q in parts], [q.is_dead for q in parts], attrs_list,
+            [p.x0 - p.dx / 2 for p in P], [p.y0 - p.dy / 2 for p in P],
+            self.nxb, self.nyb, P.dx, P.ny * P.dy, P.npatches,
+            self.count, self.bmin, self.bmax, self.cnot, self.start,
+            scratch(np.int64), scratch(np.int64), scratch(np.int64), scratch(np.float64), 0)
+        return self.nbuf_last
+
+
+def ref_sync_particles(patches, ispec, dx, dy):
+    """Patches.sync_particles for one species (core/patch/patch.py:705-742) on the ref extension"""
+    mod = oracle.ref_module("patch", "sync_particles_2d")
+    parts = [p.particles[ispec] for p in patches]
+    ext, inc, outg, alive = mod.get_npart_to_extend_2d(parts, list(patches), patches.npatches, dx, dy)
+    for q, n in zip(parts, ext):
+        if n > 0:
+            q.extend(int(n))
+    mod.fill_particles_from_boundary_2d(parts, list(patches), inc, outg, patches.npatches, dx, dy,
+                                        patches.xmin_global, patches.xmax_global,
+                                        patches.ymin_global, patches.ymax_global, parts[0].attrs)
+    return alive
+
+
+def ref_kernels(mx, sorters):
+    sf = oracle.ref_module("patch", "sync_fields2d")
+    up = oracle.ref_module("pusher", "unified_pusher_2d")
+
+    def upd_e(f, dt):
+        mx.update_efield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, f.dx, f.dy, dt,
+                            f.nx, f.ny, f.n_guard)
+
+    def upd_b(f, dt):
+        mx.update_bfield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.dx, f.dy, dt, f.nx, f.ny, f.n_guard)
+
+    return driver.KernelSet(
+        unified=up.unified_boris_pusher_cpu_2d, update_e=upd_e, update_b=upd_b,
+        sync_guard=sf.sync_guard_fields_2d, sync_currents=sf.sync_currents_2d,
+        sync_particles=ref_sync_particles, sort=lambda P, s: sorters[s](),
+        reset=oracle.ref_module("current", "cpu2d").reset_current_cpu_2d)
+
+
+def g6_sort(rng):
+    P = make_patches_2d(16, 8, 4e-8, 4e-8, 1, 1)
+    p = P[0]
+    q = p.particles[0]
+    n = 3000
+    q.initialize(n)
+    q.x[:] = rng.uniform(-0.5, p.nx - 0.5, n) * p.dx
+    q.y[:] = rng.uniform(-0.5, p.ny - 0.5, n) * p.dy
+    for a in ("ux", "uy", "uz", "w"):
+        getattr(q, a)[:] = rng.normal(size=n)
+    q.is_dead[rng.random(n) < 0.1] = True
+    q.is_dead[0] = True   # leading dead particle inherits bucket 0 (sort/cpu2d.c:18,44-52)
+    out = dict(nx=p.nx, ny=p.ny, dx=p.dx, dy=p.dy, x0=p.x0, y0=p.y0)
+    out.update(snap(q, ["x", "y", "ux", "uy", "uz", "w", "_id", "is_dead"], "in_"))
+    s = RefSorter(P, 0)
+    out["nbuf"] = s()
+    out["bucket_count"] = s.count[0].copy()
+    out["bucket_bound_min"] = s.bmin[0].copy()
+    out["bucket_bound_max"] = s.bmax[0].copy()
+    out.update(snap(q, ["x", "y", "ux", "uy", "uz", "w", "_id", "is_dead"], "out_"))
+    out["nbuf_again"] = s()   # already sorted -> nothing moves (tests/test_sort.py:140-148)
+    np.savez_compressed(OUT / "g6_sort_2d.npz", **out)
+
+
+def g7_sync(rng):
+    nx = ny = 16
+    dx = dy = 4e-8
+    P = make_patches_2d(nx, ny, dx, dy, 2, 2)
+    sf = oracle.ref_module("patch", "sync_fields2d")
+    out = dict(nx=nx, ny=ny, dx=dx, dy=dy, npx=2, npy=2, ng=3)
+    for k, p in enumerate(P):
+        for a in p.fields.attrs:
+            getattr(p.fields, a)[...] = rng.normal(size=p.fields.shape)
+        out.update(snap(p.fields, p.fields.attrs, f"in{k}_"))
+    fl = [p.fields for p in P]
+    sf.sync_guard_fields_2d(fl, list(P), ["ex", "ey", "ez", "bx", "by", "bz"], 4, P.nx, P.ny, 3)
+    sf.sync_currents_2d(fl, list(P), 4, P.nx, P.ny, 3)
+    for k, p in enumerate(P):
+        out.update(snap(p.fields, p.fields.attrs, f"out{k}_"))
+    # particle migration: everything shifted by +0.8 cell in x and -0.6 cell in y
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        n = 400
+        q.initialize(n)
+        q.x[:] = p.x0 + rng.uniform(-0.5, p.nx - 0.5, n) * dx + 0.8 * dx
+        q.y[:] = p.y0 + rng.uniform(-0.5, p.ny - 0.5, n) * dy - 0.6 * dy
+        q.ux[:] = rng.normal(size=n)
+        q.w[:] = rng.uniform(1, 2, n)
+        q.is_dead[::9] = True
+        out.update(snap(q, ["x", "y", "ux", "w", "_id", "is_dead"], f"pin{k}_"))
+    alive = ref_sync_particles(P, 0, dx, dy)
+    out["npart_alive"] = np.asarray(alive)
+    for k, p in enumerate(P):
+        out.update(snap(p.particles[0], ["x", "y", "ux", "w", "_id", "is_dead"], f"pout{k}_"))
+    np.savez_compressed(OUT / "g7_sync_2d.npz", **out)
+
+
+def g8_trace(mx):
+    """C1-like multi-step trace with the reference kernels: 32x32 periodic,
+    2x2 patches, e- 8 ppc, thermal u ~ N(0, 0.05), n = n_c(0.8 um), dx = lambda/20."""
+    lam = 0.8e-6
+    nx = ny = 32
+    dx = dy = lam / 20
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    omega = 2 * np.pi * C / lam
+    nc = driver.EPSILON_0 * ME * omega ** 2 / QE ** 2
+    nsteps, ppc, uth = 40, 8, 0.05
+    P = make_patches_2d(nx, ny, dx, dy, 2, 2)
+    rng = np.random.default_rng(SEED + 8)
+    driver.load_uniform_plasma(P, 0, ppc, nc, uth, rng)
+    out = dict(nx=nx, ny=ny, dx=dx, dy=dy, dt=dt, npx=2, npy=2, ng=3, q=QE, m=ME, nsteps=nsteps,
+               ppc=ppc, density=nc, uth=uth, seed=SEED + 8)
+    for k, p in enumerate(P):
+        out.update(snap(p.particles[0], ["x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id"],
+                        f"in{k}_"))
+    ks = ref_kernels(mx, [RefSorter(P, 0)])
+    tr = {k: [] for k in ("field_energy", "kinetic_energy", "charge", "jx", "jy", "jz", "nalive")}
+    for _ in range(nsteps):
+        driver.step(P, ks, dt, [(QE, ME)])
+        tr["field_energy"].append(driver.field_energy(P))
+        tr["kinetic_energy"].append(driver.kinetic_energy(P, 0, ME))
+        tr["charge"].append(driver.total_charge(P))
+        jx, jy, jz = driver.current_sums(P)
+        tr["jx"].append(jx), tr["jy"].append(jy), tr["jz"].append(jz)
+        tr["nalive"].append(sum(int((~p.particles[0].is_dead).sum()) for p in P))
+    for k, v in tr.items():
+        out["trace_" + k] = np.array(v)
+    for k, p in enumerate(P):
+        out.update(snap(p.fields, ["ex", "ey", "ez", "bx", "by", "bz", "rho"], f"final{k}_"))
+    np.savez_compressed(OUT / "g8_trace_2d.npz", **out)
+
+
+def main():
+    assert oracle.ref_available(), "run `make -C oracle ref` first"
+    mx = load_ref_maxwell()
+    rng = np.random.default_rng(SEED)
+    g1_fused_2d(rng)
+    g2_fused_3d(rng)
+    g3_deposit(rng)
+    g4_interp(rng)
+    g5_fdtd(rng, mx)
+    g6_sort(rng)
+    g7_sync(rng)
+    g8_trace(mx)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,212 @@
+"""Pins the oracle (oracle/picoracle.c, oracle/sync.py, oracle/driver.py) to the golden vectors
+recorded from the reference's own kernels (tests/golden/gen_golden.py).  CPU only.
+
+Tolerances (FP64): the reference build contracts a*b+c into FMAs (gcc -O3 -march=native), the
+oracle is built -ffp-contract=off, so agreement is to a few ulp of the dominant term:
+  per-particle pushed quantities 1e-12 relative to the array's max; gathered fields 1e-11
+  (27-term sums of O(1e12) random fields cancel); grid rho/J 1e-12 of the max entry;
+  40-step energy / charge traces 1e-9 relative.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import driver, sync
+from helpers import (PATTRS, PEB, assert_close, fields2d_from, fields3d_from, particles_from)
+from lambdapic_amd.patch import make_patches_2d
+
+
+def test_g1_fused_2d(golden):
+    g = golden("g1_fused_2d")
+    for k in range(int(g["npatches"])):
+        f = fields2d_from(g, f"in{k}_", g[f"x0_{k}"], g[f"y0_{k}"])
+        p = particles_from(g, f"in{k}_")
+        oracle.unified_boris_pusher_cpu_2d([p], [f], 1, float(g["dt"]), float(g["q"]), float(g["m"]))
+        for a in ["x", "y", "ux", "uy", "uz", "inv_gamma"]:
+            assert_close(getattr(p, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
+        alive = ~(p.is_dead | np.isnan(g[f"in{k}_x"]) | np.isnan(g[f"in{k}_y"]))
+        for a in PEB:
+            assert_close(getattr(p, a)[alive], g[f"out{k}_{a}"][alive], 1e-11, what=f"patch{k} {a}")
+        for a in ["rho", "jx", "jy", "jz"]:
+            assert_close(getattr(f, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
+
+
+def test_g2_fused_3d(golden):
+    g = golden("g2_fused_3d")
+    f = fields3d_from(g, "in_")
+    p = particles_from(g, "in_")
+    oracle.unified_boris_pusher_cpu_3d([p], [f], 1, float(g["dt"]), float(g["q"]), float(g["m"]))
+    for a in ["x", "y", "z", "ux", "uy", "uz", "inv_gamma"]:
+        assert_close(getattr(p, a), g[f"out_{a}"], 1e-12, what=a)
+    alive = ~(p.is_dead | np.isnan(g["in_x"]) | np.isnan(g["in_y"]) | np.isnan(g["in_z"]))
+    for a in PEB:
+        assert_close(getattr(p, a)[alive], g[f"out_{a}"][alive], 1e-11, what=a)
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+
+
+def test_g3_standalone_deposit(golden):
+    g = golden("g3_deposit_2d")
+    f = fields2d_from(g, "none_", g["x0"], g["y0"])
+    p = particles_from(g, "in_")
+    oracle.current_deposition_cpu_2d([f], [p], 1, float(g["dt"]), float(g["q"]))
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+    g = golden("g3_deposit_3d")
+    f = fields3d_from(g, "none_")
+    p = particles_from(g, "in_")
+    oracle.current_deposition_cpu_3d([f], [p], 1, float(g["dt"]), float(g["q"]))
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+
+
+def test_g4_interpolation(golden):
+    g = golden("g4_interp_2d")
+    f = fields2d_from(g, "in_", g["x0"], g["y0"])
+    p = particles_from(g, "in_", ["x", "y"])
+    oracle.interpolation_patches_2d([p], [f], 1)
+    for a in PEB:
+        assert_close(getattr(p, a)[~p.is_dead], g[f"out_{a}"][~p.is_dead], 1e-11, what=a)
+    g = golden("g4_interp_3d")
+    f = fields3d_from(g, "in_")
+    p = particles_from(g, "in_", ["x", "y", "z"])
+    oracle.interpolation_patches_3d([p], [f], 1)
+    for a in PEB:
+        assert_close(getattr(p, a)[~p.is_dead], g[f"out_{a}"][~p.is_dead], 1e-11, what=a)
+
+
+def test_g5_fdtd(golden):
+    g = golden("g5_fdtd_2d")
+    f = fields2d_from(g, "in_", 0.0, 0.0)
+    oracle.update_efield_2d(f, float(g["dt"]))
+    for a in ["ex", "ey", "ez"]:
+        assert_close(getattr(f, a), g[f"outE_{a}"], 1e-14, what=a)
+    oracle.update_bfield_2d(f, float(g["dt"]))
+    for a in ["bx", "by", "bz"]:
+        assert_close(getattr(f, a), g[f"outB_{a}"], 1e-14, what=a)
+    g = golden("g5_fdtd_3d")
+    f = fields3d_from({**{k: g[k] for k in g.files}, "x0": 0.0, "y0": 0.0, "z0": 0.0}, "in_")
+    oracle.update_efield_3d(f, float(g["dt"]))
+    for a in ["ex", "ey", "ez"]:
+        assert_close(getattr(f, a), g[f"outE_{a}"], 1e-14, what=a)
+    oracle.update_bfield_3d(f, float(g["dt"]))
+    for a in ["bx", "by", "bz"]:
+        assert_close(getattr(f, a), g[f"outB_{a}"], 1e-14, what=a)
+
+
+def test_g6_sort_buckets(golden):
+    """bucket counts / bounds are exact; the permutation inside a bucket is implementation
+    defined, so compare the per-bucket multiset of particle ids (reference tests/test_sort.py:38-74)"""
+    g = golden("g6_sort_2d")
+    nx, ny, dx, dy = int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"])
+    Ly = ny * dy
+    idx, cnt = oracle.bucket_index_2d(g["in_x"].copy(), g["in_y"].copy(), g["in_is_dead"].copy(),
+                                      nx, 1, dx, Ly, float(g["x0"]) - dx / 2, float(g["y0"]) - dy / 2)
+    assert np.array_equal(cnt.reshape(nx, 1), g["bucket_count"])
+    bmin = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    assert np.array_equal(bmin.reshape(nx, 1), g["bucket_bound_min"])
+    assert np.array_equal((bmin + cnt).reshape(nx, 1), g["bucket_bound_max"])
+    order = np.argsort(idx, kind="stable")
+    ids_mine, ids_ref = g["in__id"].view(np.uint64)[order], g["out__id"].view(np.uint64)
+    for b in range(nx):
+        lo, hi = bmin[b], bmin[b] + cnt[b]
+        assert np.array_equal(np.sort(ids_mine[lo:hi]), np.sort(ids_ref[lo:hi]))
+    assert int(g["nbuf_again"]) == 0
+
+
+def _patches_from_g7(g):
+    P = make_patches_2d(int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"]),
+                        int(g["npx"]), int(g["npy"]))
+    for k, p in enumerate(P):
+        for a in p.fields.attrs:
+            getattr(p.fields, a)[...] = g[f"in{k}_{a}"]
+    return P
+
+
+def test_g7_sync_fields(golden):
+    g = golden("g7_sync_2d")
+    P = _patches_from_g7(g)
+    fl = [p.fields for p in P]
+    sync.sync_guard_fields_2d(fl, list(P), ["ex", "ey", "ez", "bx", "by", "bz"], 4, P.nx, P.ny, 3)
+    sync.sync_currents_2d(fl, list(P), 4, P.nx, P.ny, 3)
+    for k, p in enumerate(P):
+        for a in ["ex", "ey", "ez", "bx", "by", "bz"]:
+            assert np.array_equal(getattr(p.fields, a), g[f"out{k}_{a}"]), (k, a)
+        for a in ["jx", "jy", "jz", "rho"]:
+            # fold order differs from the reference's (face vs corner first): few-ulp sums
+            assert_close(getattr(p.fields, a), g[f"out{k}_{a}"], 1e-15, what=f"{k} {a}")
+
+
+def test_g7_sync_particles(golden):
+    g = golden("g7_sync_2d")
+    P = _patches_from_g7(g)
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        q.initialize(g[f"pin{k}_x"].size)
+        for a in ["x", "y", "ux", "w", "_id"]:
+            getattr(q, a)[:] = g[f"pin{k}_{a}"]
+        q.is_dead[:] = g[f"pin{k}_is_dead"]
+    alive = sync.sync_particles_2d(P, 0, float(g["dx"]), float(g["dy"]))
+    assert np.array_equal(alive, g["npart_alive"])
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        assert q.npart == g[f"pout{k}_x"].size
+        assert np.array_equal(q.is_dead, g[f"pout{k}_is_dead"])
+        live = ~q.is_dead
+        for a in ["x", "y", "ux", "w"]:
+            assert np.array_equal(getattr(q, a)[live], g[f"pout{k}_{a}"][live]), (k, a)
+        assert np.array_equal(q.id[live], g[f"pout{k}__id"].view(np.uint64)[live])
+
+
+def test_g8_step_trace(golden):
+    """the a0 stage order + all kernels in combination: 40-step traces of field energy, kinetic
+    energy, total charge and current sums against the reference-kernel run."""
+    g = golden("g8_trace_2d")
+    P = make_patches_2d(int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"]),
+                        int(g["npx"]), int(g["npy"]))
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        q.initialize(g[f"in{k}_x"].size)
+        for a in ["x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id"]:
+            getattr(q, a)[:] = g[f"in{k}_{a}"]
+    ks = driver.oracle_kernels()
+    q_, m_, dt = float(g["q"]), float(g["m"]), float(g["dt"])
+    tr = {k: [] for k in ("field_energy", "kinetic_energy", "charge", "nalive")}
+    for _ in range(int(g["nsteps"])):
+        driver.step(P, ks, dt, [(q_, m_)])
+        tr["field_energy"].append(driver.field_energy(P))
+        tr["kinetic_energy"].append(driver.kinetic_energy(P, 0, m_))
+        tr["charge"].append(driver.total_charge(P))
+        tr["nalive"].append(sum(int((~p.particles[0].is_dead).sum()) for p in P))
+    assert np.array_equal(tr["nalive"], g["trace_nalive"])
+    np.testing.assert_allclose(tr["field_energy"], g["trace_field_energy"], rtol=1e-9)
+    np.testing.assert_allclose(tr["kinetic_energy"], g["trace_kinetic_energy"], rtol=1e-12)
+    np.testing.assert_allclose(tr["charge"], g["trace_charge"], rtol=1e-12)
+    for k, p in enumerate(P):
+        for a in ["ex", "ey", "ez", "bx", "by", "bz", "rho"]:
+            assert_close(getattr(p.fields, a), g[f"final{k}_{a}"], 1e-9, what=f"{k} {a}")
+
+
+def test_known_answers_charge_and_current():
+    """reference tests/core/current/test_current_deposition.py:328-369: for one particle,
+    sum(rho) = q w/(dx dy) and sum(jx) = q w vx/(dx dy)."""
+    from lambdapic_amd.fields import Fields2D
+    from lambdapic_amd.particles import ParticlesBase
+    dx = dy = 1e-8
+    f = Fields2D(16, 16, dx, dy, 0.0, 0.0, 3)
+    p = ParticlesBase(0, 0)
+    p.initialize(1)
+    rng = np.random.default_rng(3)
+    p.x[:] = rng.uniform(3, 12) * dx
+    p.y[:] = rng.uniform(3, 12) * dy
+    p.ux[:], p.uy[:], p.uz[:] = 0.3, -0.2, 0.1
+    p.inv_gamma[:] = 1 / np.sqrt(1 + 0.09 + 0.04 + 0.01)
+    p.w[:] = 1e27 * dx * dy / 10
+    q, dt = -1.602176634e-19, 1e-17
+    oracle.current_deposition_cpu_2d([f], [p], 1, dt, q)
+    n = p.w[0] / (dx * dy)
+    v = np.array([p.ux[0], p.uy[0], p.uz[0]]) * p.inv_gamma[0] * 299792458.0
+    assert f.rho.sum() == pytest.approx(q * n, rel=1e-10)
+    assert f.jx.sum() == pytest.approx(q * n * v[0], rel=1e-10)
+    assert f.jy.sum() == pytest.approx(q * n * v[1], rel=1e-10)
+    assert f.jz.sum() == pytest.approx(q * n * v[2], rel=1e-10)
