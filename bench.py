@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/s of the MI355X PIC inner loop on BASELINE.json's config C2
+(2-D uniform thermal plasma, 1024x1024 cells, 64 ppc, 1 species, periodic; push + deposit + FDTD +
+guard handling + the periodic tile sort), synthetic inputs generated in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...`` (one rank per GPU, RCCL): WEAK scaling -- every rank owns a 1024x1024 slab of a
+(1024*N)x1024 periodic box, x faces exchanged with the ring neighbours.
+
+Rank 0 prints ONE JSON line: metric/value (whole-job particle-updates/s), a ``roofline`` object
+for the dominant kernel (the tiled push+deposit kernel, timed live with HIP events on its stream)
+and, at N = 1, a ``cpu_baseline`` object (the oracle port timed on the host cores on a bounded
+sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C_LIGHT = 299792458.0
+LAMBDA0 = 0.8e-6
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_PARTICLE = 105.0     # 7 f64 + is_dead read, 6 f64 written
+GATHER_SCATTER_BYTES_PER_CELL = 112.0  # 6 arrays read + 4 arrays RMW
+
+
+def build_engine(args, comm, device):
+    from lambdapic_amd import constants
+    from lambdapic_amd.engine import PicEngine2D
+
+    nx, ny, ppc = args.nx, args.ny, args.ppc
+    dx = dy = LAMBDA0 / 20                                  # example/ring.py:34-40
+    dt = 0.95 / (C_LIGHT * np.sqrt(dx ** -2 + dy ** -2))    # simulation.py:219
+    q, m = -constants.E_CHARGE, constants.M_E
+    omega = 2 * np.pi * C_LIGHT / LAMBDA0
+    n_c = constants.EPSILON_0 * m * omega ** 2 / q ** 2     # tests/test_numerical_heating.py:16,86
+    u_th = 0.0442                                           # 1 keV electrons
+    n = nx * ny * ppc
+    eng = PicEngine2D(nx, ny, dx, dy, n_guard=3, device=device, comm=comm,
+                      sort_interval=args.sort_interval, block_particles=args.block_particles)
+    area = 2 * eng.migrate_capacity * max(args.sort_interval, 1) if comm.size > 1 else 0
+    eng.add_species(q, m, capacity=n + area + 4096)
+    s = eng.species[0].cset
+    gen = torch.Generator(device=device).manual_seed(20260722 + comm.rank)
+    chunk = 1 << 24
+    for lo in range(0, n, chunk):                           # cell by cell, ppc per cell (patch/cpu.py:36-44)
+        hi = min(lo + chunk, n)
+        cell = torch.arange(lo, hi, device=device) // ppc
+        r = lambda: torch.rand(hi - lo, device=device, dtype=torch.float64, generator=gen)
+        g = lambda: torch.randn(hi - lo, device=device, dtype=torch.float64, generator=gen)
+        s.arr("x")[lo:hi] = eng.x0 + ((cell // ny).double() + r() - 0.5) * dx
+        s.arr("y")[lo:hi] = ((cell % ny).double() + r() - 0.5) * dy
+        ux, uy, uz = g() * u_th, g() * u_th, g() * u_th
+        s.arr("ux")[lo:hi], s.arr("uy")[lo:hi], s.arr("uz")[lo:hi] = ux, uy, uz
+        s.arr("inv_gamma")[lo:hi] = 1.0 / torch.sqrt(1 + ux * ux + uy * uy + uz * uz)
+        s.arr("w")[lo:hi] = n_c * dx * dy / ppc
+        s.id[lo:hi] = torch.arange(lo, hi, device=device) + (comm.rank << 40)
+        del cell, ux, uy, uz
+    eng.species[0].n = n
+    return eng, dt, n
+
+
+def cpu_baseline(args):
+    """oracle port (oracle/picoracle.c, rebuilt -O3 -march=native on this host) on a bounded sample:
+    same physics and cell size, smaller box; fused push+deposit (OpenMP over patches) + the four
+    FDTD half steps + guard copies / current fold; no sort, no particle migration."""
+    import oracle
+    from oracle import driver, sync
+    from lambdapic_amd.patch import make_patches_2d
+
+    L = oracle.lib(native=True)
+    threads = int(L.orc_num_threads())
+    nx = ny = args.cpu_cells
+    ppc, npx = args.ppc, max(1, args.cpu_cells // 32)
+    dx = dy = LAMBDA0 / 20
+    dt = 0.95 / (C_LIGHT * np.sqrt(dx ** -2 + dy ** -2))
+    q, m = -oracle.E_CHARGE, oracle.M_E
+    n_c = oracle.EPSILON_0 * m * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / q ** 2
+    P = make_patches_2d(nx, ny, dx, dy, npx, npx)
+    driver.load_uniform_plasma(P, 0, ppc, n_c, 0.0442, np.random.default_rng(1))
+    fl, pl = [p.fields for p in P], list(P)
+    parts = [p.particles[0] for p in P]
+    npat, ng = P.npatches, 3
+    import ctypes as C
+    ftab = oracle._tab([getattr(f, a) for f in fl for a in oracle.FIELD_ORDER])
+
+    def fdtd_e(h):
+        L.orc_fdtd_e_2d_patches(C.c_long(npat), ftab, C.c_long(P.nx), C.c_long(P.ny), C.c_long(ng),
+                                C.c_double(dx), C.c_double(dy), C.c_double(h), C.c_double(oracle.EPSILON_0))
+
+    def fdtd_b(h):
+        L.orc_fdtd_b_2d_patches(C.c_long(npat), ftab, C.c_long(P.nx), C.c_long(P.ny), C.c_long(ng),
+                                C.c_double(dx), C.c_double(dy), C.c_double(h))
+
+    def one_step():
+        E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+        fdtd_e(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, E, npat, P.nx, P.ny, ng)
+        fdtd_b(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, B, npat, P.nx, P.ny, ng)
+        oracle.reset_current(fl, npat)
+        oracle.unified_boris_pusher_cpu_2d(parts, fl, npat, dt, q, m, native=True)
+        sync.sync_currents_2d(fl, pl, npat, P.nx, P.ny, ng)
+        fdtd_b(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, B, npat, P.nx, P.ny, ng)
+        fdtd_e(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, E, npat, P.nx, P.ny, ng)
+
+    one_step()                      # warm-up (page faults, thread pool)
+    n = nx * ny * ppc
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < args.cpu_seconds and steps < 50):
+        one_step()
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
+                      f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
+                      f"-O3 -march=native, {threads} OpenMP threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--nx", type=int, default=1024)
+    ap.add_argument("--ny", type=int, default=1024)
+    ap.add_argument("--ppc", type=int, default=64)
+    ap.add_argument("--sort-interval", type=int, default=8)
+    ap.add_argument("--block-particles", type=int, default=8192)
+    ap.add_argument("--cpu-cells", type=int, default=512)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from lambdapic_amd.dist import SlabComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: lambdapic_amd has no CPU path")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    comm = SlabComm(None)
+    assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    eng, dt, n_local = build_engine(args, comm, device)
+    for _ in range(args.warmup):
+        eng.step(dt)
+    # timed region: EXACTLY --steps steps between barrier + synchronize on both sides
+    eng.kernel_events = []
+    torch.cuda.synchronize(device)
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(dt)
+    torch.cuda.synchronize(device)
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: tiled push+deposit, HIP events recorded on its stream inside the timed region
+    ev = eng.kernel_events
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    d = eng.diagnostics()
+    alive = d["nalive"][0]
+    alg_bytes = BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * args.nx * args.ny
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if ev else float("nan")
+    n_total = n_local * comm.size
+    out = {
+        "metric": "particle-updates/sec", "value": n_total * args.steps / elapsed,
+        "unit": "particle-updates/s", "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C2: 2-D uniform thermal plasma {args.nx}x{args.ny} cells per GPU, "
+                               f"{args.ppc} ppc, 1 species (e-), periodic, dt_cfl 0.95, push+deposit+FDTD"
+                               f"+guards, tile sort every {args.sort_interval} steps",
+                   "particles_per_gpu": n_local, "alive_rank0": alive,
+                   "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
+                   "part_eb_writeback": False},
+        "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": None},
+    }
+    if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args)
+        except Exception as e:  # the GPU number stands on its own
+            out["cpu_baseline"] = {"value": None, "unit": "particle-updates/s", "cores": 0, "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    if comm.rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

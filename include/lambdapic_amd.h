@@ -1,0 +1,198 @@
+/*
+ * lambdapic_amd.h -- C ABI of the MI355X (gfx950) PIC inner loop.
+ *
+ * Drop-in boundary for lambdaPIC's per-step hot path: every entry point is
+ * what a lambdaPIC facade would bind in place of one of its compiled CPU kernels; the reference
+ * interface each one replaces is cited as file:line relative to /root/reference/src/lambdapic.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  All array pointers are DEVICE
+ *    pointers (hipMalloc / torch CUDA tensors); the library never allocates or frees memory and
+ *    never synchronises: every call enqueues work on `stream` (a hipStream_t passed as void*,
+ *    NULL = the default stream) and returns.  Scratch comes from caller-provided workspaces.
+ *  - every function returns 0 on success, a negative lpa_status on error; lpa_last_error()
+ *    returns a message for the calling thread.  Nothing throws across the ABI.
+ *  - FP64 throughout (the reference computes in float64 everywhere).
+ *  - Field arrays: row-major double[NX][NY]([NZ]), NX = nx + 2*ng, in the CONVENTIONAL guard
+ *    layout [ng | interior | ng]: interior node i lives at index i + ng.  This is lambdaPIC's
+ *    wrapped layout (core/fields.py:24-27) rolled by +ng along every axis; all kernels treat the
+ *    padded array as a torus exactly like the reference's INDEX2/INDEX3 macros and
+ *    PRECOMPUTE_WRAP_INDICES (core/utils/cutils.h:19-26, core/current/current_deposit.h:41-49).
+ *  - Particle arrays: SoA double[n]; a particle is skipped when is_dead[i] != 0 (if is_dead is
+ *    given) or when x (or y, z) is NaN -- the reference's rule
+ *    (core/pusher/unified/unified_pusher_2d.c:265-268,316-317).
+ */
+#ifndef LAMBDAPIC_AMD_H
+#define LAMBDAPIC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LPA_OK = 0,
+    LPA_ERR_ARG = -1,      /* bad argument (null pointer, non-positive size, unsupported shape) */
+    LPA_ERR_HIP = -2,      /* a HIP runtime call / launch failed; see lpa_last_error()            */
+    LPA_ERR_WORKSPACE = -3 /* workspace too small                                                 */
+} lpa_status;
+
+/* One rank's field slab.  Mirrors the attribute bag Fields2D/Fields3D (core/fields.py:56,78-170):
+ * ex ey ez bx by bz jx jy jz rho, nx ny nz, n_guard, dx dy dz, x0 y0 z0.  nz = 1, dz = 0 in 2-D. */
+typedef struct {
+    int32_t nx, ny, nz; /* interior cells */
+    int32_t ng;         /* guard cells per side (reference default 3, simulation.py:156) */
+    double dx, dy, dz;
+    double x0, y0, z0;  /* position of interior node 0 */
+    double *ex, *ey, *ez, *bx, *by, *bz, *jx, *jy, *jz, *rho;
+} lpa_grid;
+
+/* One species' particle store.  Mirrors ParticlesBase (core/particles.py:63-67): x y z w ux uy uz
+ * inv_gamma, ex_part..bz_part, _id, is_dead.  Optional pointers may be NULL:
+ *   z (2-D), part_eb[0..5] (per-particle E/B write-back for callbacks), id, is_dead. */
+typedef struct {
+    int64_t n; /* slots in use (alive + dead) */
+    double *x, *y, *z, *ux, *uy, *uz, *inv_gamma, *w;
+    double *part_eb[6]; /* ex_part ey_part ez_part bx_part by_part bz_part, or all NULL */
+    uint64_t *id;       /* bit pattern of ParticlesBase._id */
+    uint8_t *is_dead;
+} lpa_particles;
+
+/* Tile binning of a particle store (product of lpa_sort_tiles_2d, consumed by
+ * lpa_push_deposit_tiled_2d).  All pointers are device memory inside the sort workspace. */
+typedef struct {
+    int32_t tiles_x, tiles_y;  /* tile grid; tile = LPA_TILE x LPA_TILE cells                    */
+    int64_t n_sorted;          /* particles [0, n_sorted) are tile ordered; the rest are "loose" */
+    int32_t max_blocks;        /* launch bound for the tiled kernel                              */
+    const int32_t *tile_off;   /* [ntiles+1] first particle of each tile                         */
+    const int32_t *blk_tile;   /* [max_blocks] tile of each work block                           */
+    const int32_t *blk_begin;  /* [max_blocks] first particle of each work block                 */
+    const int32_t *blk_end;    /* [max_blocks] one past the last particle                        */
+    const int32_t *n_blocks;   /* [1] number of valid work blocks                                */
+} lpa_tiling;
+
+#define LPA_TILE 16        /* cells per tile edge                                               */
+#define LPA_TILE_MARGIN 1  /* cells a particle may sit outside its tile and stay on the LDS path */
+
+const char *lpa_last_error(void);
+int lpa_version(void);
+
+/* ---- Yee FDTD (replaces update_efield_patches_2d / update_bfield_patches_2d,
+ *      core/maxwell/cpu.py:38-79, called through MaxwellSolver2D.update_efield/bfield,
+ *      core/maxwell/solver/solver.py:143-190).  Interior cells only; dt is the caller's (half)
+ *      step; eps0 is scipy.constants.epsilon_0 of the host environment. */
+int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *stream);
+int lpa_fdtd_b_2d(const lpa_grid *g, double dt, void *stream);
+/* 3-D twins (core/maxwell/cpu.py:115-158) */
+int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream);
+int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream);
+
+/* ---- zero jx jy jz rho including guards (replaces reset_current_cpu_2d/3d,
+ *      core/current/cpu2d.c:19-72, cpu3d.c:185-240) */
+int lpa_reset_current(const lpa_grid *g, void *stream);
+
+/* ---- periodic guard handling inside one slab (replaces sync_guard_fields_2d and
+ *      sync_currents_2d with a self-neighbour table, core/patch/sync_fields2d.c:150-255,43-148).
+ *      `which`: bit 0 = ex ey ez, bit 1 = bx by bz.  `axes`: bit 0 = x, bit 1 = y (, bit 2 = z):
+ *      the axes that are periodic INSIDE this slab (x is excluded when x is split over ranks). */
+int lpa_guard_wrap(const lpa_grid *g, int which, int axes, void *stream);
+int lpa_current_fold(const lpa_grid *g, int axes, void *stream);
+
+/* ---- x-face halo buffers for the slab decomposition (replaces the MPI subarray / packed-buffer
+ *      exchange of core/mpi/sync_fields2d.c:365-640).  Buffers are [ncomp][ng][NY(*NZ)] doubles.
+ *      side: 0 = low-x face, 1 = high-x face.
+ *      pack_guard_src  : interior edge planes that become the neighbour's guard (E/B, `which` as
+ *                        above)
+ *      unpack_guard    : write received planes into my guard on `side`
+ *      pack_current    : my guard planes of jx jy jz rho on `side`, zeroing them
+ *                        (fill_currents_buf, core/mpi/sync_fields2d.c:44-74)
+ *      unpack_current  : add received planes into my interior edge on `side` (:76-102) */
+int lpa_halo_pack_guard_src(const lpa_grid *g, int which, int side, double *buf, void *stream);
+int lpa_halo_unpack_guard(const lpa_grid *g, int which, int side, const double *buf, void *stream);
+int lpa_halo_pack_current(const lpa_grid *g, int side, double *buf, void *stream);
+int lpa_halo_unpack_current(const lpa_grid *g, int side, const double *buf, void *stream);
+
+/* ---- fused particle kernel (replaces unified_boris_pusher_cpu_2d(particles_list, fields_list,
+ *      npatches, dt, q, m), core/pusher/unified/unified_pusher_2d.c:157-365): half push, TSC
+ *      gather, Boris, half push, Esirkepov deposit of rho jx jy jz.
+ *      lpa_push_deposit_2d      : any particle order, global-memory gather + FP64 atomics;
+ *                                 processes particles [first, first+count).
+ *      lpa_push_deposit_tiled_2d: tile-binned particles, E/B and J staged in LDS per tile;
+ *                                 particles outside their tile's margin are appended to
+ *                                 `overflow` (uint32 indices, count in overflow_count[0]) and must
+ *                                 then be finished with lpa_push_deposit_list_2d.
+ *      wrap flags: bit 0/1 = after the deposit, fold x/y back into the periodic box
+ *      [lo, hi] of size L (Patches.sync_particles with a self neighbour,
+ *      core/patch/sync_particles_2d.c:168-182) -- the fused form of the periodic migration. */
+typedef struct {
+    double dt, q, m;
+    int32_t wrap;              /* bit 0: x, bit 1: y (bit 2: z) */
+    double lo[3], hi[3];       /* global particle box: lo = -d/2, hi = L - d/2 */
+} lpa_push_params;
+
+int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                        int64_t first, int64_t count, void *stream);
+int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles *p,
+                              const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
+                              uint32_t *overflow_count, void *stream);
+int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                             const uint32_t *list, const uint32_t *list_count, int64_t max_count,
+                             void *stream);
+int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                        int64_t first, int64_t count, void *stream);
+
+/* ---- split kernels of the callback-in-pusher-stage path
+ *      interpolation_patches_2d (core/interpolation/cpu2d.c:71-136), boris_push_patches
+ *      (core/pusher/cpu.py:11-35), push_position_patches_2d (core/pusher/cpu.py:73-91),
+ *      current_deposition_cpu_2d (core/current/cpu2d.c:74-184) */
+int lpa_interpolate_2d(const lpa_grid *g, const lpa_particles *p, void *stream);
+int lpa_boris(const lpa_particles *p, double dt, double q, double m, void *stream);
+int lpa_push_position_2d(const lpa_particles *p, double dt, void *stream);
+int lpa_deposit_2d(const lpa_grid *g, const lpa_particles *p, double dt, double q, void *stream);
+
+/* ---- cell-index sort (replaces sort_particles_patches_2d, core/sort/cpu2d.c:220-303, as driven
+ *      by ParticleSort2D.__call__, core/sort/particle_sort.py:196-211).  Out of place: `src` is
+ *      binned by LPA_TILE x LPA_TILE cell tiles into `dst` (same capacity), dead / NaN particles
+ *      are dropped (they sort behind every live particle in the reference and are recycled by
+ *      sync_particles); within a tile the order is deliberately cell-interleaved.  The number
+ *      of live particles is written to the workspace header and returned through lpa_tiling. */
+int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
+int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                      void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                      lpa_tiling *out, void *stream);
+/* number of live particles after the last sort (device pointer inside the workspace) */
+const int32_t *lpa_sort_live_count(void *workspace);
+
+/* ---- particle ownership along x for the slab decomposition (replaces get_npart_to_extend_2d +
+ *      fill_particles_from_boundary_2d, core/patch/sync_particles_2d.c:204-518 and the MPI twins
+ *      core/mpi/sync_particles_2d.c:274-770: count message + AoS payload message per boundary).
+ *      One fixed-size message per face carries its own count, so no host round trip is needed:
+ *      buffer = 1 + LPA_MIG_NATTR*capacity doubles; [0] = count (int64 bit pattern), then SoA
+ *      [attr][capacity].
+ *      pack  : live particles with x < xlo / x > xhi are copied to buf_lo / buf_hi and killed
+ *              (x = y = NaN, sync_particles_2d.c:185-202).  A particle that does not fit stays
+ *              where it is and leaves one step later (count > capacity records the event).
+ *      unpack: append the received particles to the arrival area [first_slot, first_slot +
+ *              area_capacity) at the device-side cursor, adding shift_x to x (periodic wrap at
+ *              the global edge, sync_particles_2d.c:168-182).  cursor > area_capacity = overflow. */
+#define LPA_MIG_NATTR 9 /* x y z ux uy uz inv_gamma w id */
+int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
+                       double *buf_hi, int64_t capacity, void *stream);
+int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_capacity,
+                       int32_t *cursor, const double *buf, int64_t capacity, double shift_x,
+                       void *stream);
+
+/* ---- diagnostics the parity contract is stated on (field energy, kinetic energy, total
+ *      charge; reference tests/test_numerical_heating.py:19-50).  out[] is device memory and is
+ *      accumulated into (zero it first).
+ *      field: out[0] += sum_interior eps0/2 E^2 dV, out[1] += sum_interior B^2/(2 mu0) dV,
+ *             out[2] += sum_interior rho dV, out[3..5] += sum_interior jx jy jz
+ *      particles: out[0] += sum w (1/inv_gamma - 1) m c^2, out[1] += number alive */
+int lpa_diag_fields(const lpa_grid *g, double eps0, double mu0, double *out, void *stream);
+int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMBDAPIC_AMD_H */

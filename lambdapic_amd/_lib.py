@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI declared in include/lambdapic_amd.h.
+
+The HIP library is the product: there is no CPU fallback.  ``lib()`` raises if
+``liblambdapic_amd.so`` is missing or a symbol the header declares is not exported.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "liblambdapic_amd.so"
+
+LPA_TILE = 16
+LPA_TILE_MARGIN = 1
+LPA_MIG_NATTR = 9
+
+
+class LpaError(RuntimeError):
+    pass
+
+
+class lpa_grid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ng", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("x0", C.c_double), ("y0", C.c_double), ("z0", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho")]
+
+
+class lpa_particles(C.Structure):
+    _fields_ = [("n", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")] + \
+               [("part_eb", C.c_void_p * 6), ("id", C.c_void_p), ("is_dead", C.c_void_p)]
+
+
+class lpa_tiling(C.Structure):
+    _fields_ = [("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("n_sorted", C.c_int64),
+                ("max_blocks", C.c_int32),
+                ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
+                ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p)]
+
+
+class lpa_push_params(C.Structure):
+    _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32),
+                ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+_G, _P, _T, _PP = C.POINTER(lpa_grid), C.POINTER(lpa_particles), C.POINTER(lpa_tiling), C.POINTER(lpa_push_params)
+_vp, _d, _i, _i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
+
+# name -> (restype, argtypes); every symbol include/lambdapic_amd.h declares
+SIGNATURES = {
+    "lpa_last_error": (C.c_char_p, []),
+    "lpa_version": (_i, []),
+    "lpa_fdtd_e_2d": (_i, [_G, _d, _d, _vp]),
+    "lpa_fdtd_b_2d": (_i, [_G, _d, _vp]),
+    "lpa_fdtd_e_3d": (_i, [_G, _d, _d, _vp]),
+    "lpa_fdtd_b_3d": (_i, [_G, _d, _vp]),
+    "lpa_reset_current": (_i, [_G, _vp]),
+    "lpa_guard_wrap": (_i, [_G, _i, _i, _vp]),
+    "lpa_current_fold": (_i, [_G, _i, _vp]),
+    "lpa_halo_pack_guard_src": (_i, [_G, _i, _i, _vp, _vp]),
+    "lpa_halo_unpack_guard": (_i, [_G, _i, _i, _vp, _vp]),
+    "lpa_halo_pack_current": (_i, [_G, _i, _vp, _vp]),
+    "lpa_halo_unpack_current": (_i, [_G, _i, _vp, _vp]),
+    "lpa_push_deposit_2d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
+    "lpa_push_deposit_tiled_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
+    "lpa_push_deposit_list_2d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
+    "lpa_push_deposit_3d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
+    "lpa_interpolate_2d": (_i, [_G, _P, _vp]),
+    "lpa_boris": (_i, [_P, _d, _d, _d, _vp]),
+    "lpa_push_position_2d": (_i, [_P, _d, _vp]),
+    "lpa_deposit_2d": (_i, [_G, _P, _d, _d, _vp]),
+    "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),
+    "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, _T, _vp]),
+    "lpa_sort_live_count": (_vp, [_vp]),
+    "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp]),
+    "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
+    "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
+    "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load liblambdapic_amd.so and bind every declared symbol; fail loudly otherwise."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise LpaError(f"{LIB_PATH} not built: run `python -m lambdapic_amd.build` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise LpaError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib().lpa_last_error()
+        raise LpaError(f"{what} failed ({status}): {msg.decode() if msg else ''}")

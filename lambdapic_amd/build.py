@@ -1,0 +1,57 @@
+"""Build the HIP library in-tree: lambdapic_amd/liblambdapic_amd.so (gfx950 only).
+
+    python -m lambdapic_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU.  Objects are rebuilt when their source (or a header) is newer.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "liblambdapic_amd.so"
+SOURCES = ["lpa_fields.hip", "lpa_particles.hip", "lpa_particles3d.hip", "lpa_sort.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (Path(c).exists() or c == "hipcc"):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    headers = list(CSRC.glob("*.hpp")) + [HERE.parent / "include" / "lambdapic_amd.h"]
+    newest_hdr = max(h.stat().st_mtime for h in headers)
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    objs, rebuilt = [], False
+    procs = []
+    for s in SOURCES:
+        src, obj = CSRC / s, objdir / (s + ".o")
+        objs.append(obj)
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, newest_hdr):
+            cmd = [_hipcc(), *FLAGS, *extra_flags, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd)))
+            rebuilt = True
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if rebuilt or not LIB.exists():
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

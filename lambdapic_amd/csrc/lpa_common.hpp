@@ -1,0 +1,217 @@
+// lpa_common.hpp -- shared device helpers of the MI355X PIC kernels (gfx950, wave64, FP64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lambdapic_amd.h"
+
+#define LPA_C 299792458.0 /* core/utils/cutils.h:17 */
+
+// ---- host side error plumbing -------------------------------------------------------------------
+void lpa_set_error(const char *fmt, ...);
+#define LPA_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            lpa_set_error(__VA_ARGS__);        \
+            return LPA_ERR_ARG;                \
+        }                                      \
+    } while (0)
+#define LPA_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            lpa_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return LPA_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
+    if (!g || g->nx <= 0 || g->ny <= 0 || g->ng < 1 || !(g->dx > 0) || !(g->dy > 0)) return 0;
+    if (dim == 3 && (g->nz <= 0 || !(g->dz > 0))) return 0;
+    if (!g->ex || !g->ey || !g->ez || !g->bx || !g->by || !g->bz) return 0;
+    if (need_j && (!g->jx || !g->jy || !g->jz || !g->rho)) return 0;
+    return 1;
+}
+
+// ---- kernel-side views (passed by value) ---------------------------------------------------------
+struct GridV {
+    int nx, ny, nz, ng, NX, NY, NZ;
+    double dx, dy, dz, x0, y0, z0;
+    double *ex, *ey, *ez, *bx, *by, *bz, *jx, *jy, *jz, *rho;
+};
+
+static inline GridV make_gridv(const lpa_grid *g, int dim) {
+    GridV v;
+    v.nx = g->nx; v.ny = g->ny; v.nz = dim == 3 ? g->nz : 1; v.ng = g->ng;
+    v.NX = g->nx + 2 * g->ng; v.NY = g->ny + 2 * g->ng; v.NZ = dim == 3 ? g->nz + 2 * g->ng : 1;
+    v.dx = g->dx; v.dy = g->dy; v.dz = g->dz; v.x0 = g->x0; v.y0 = g->y0; v.z0 = g->z0;
+    v.ex = g->ex; v.ey = g->ey; v.ez = g->ez; v.bx = g->bx; v.by = g->by; v.bz = g->bz;
+    v.jx = g->jx; v.jy = g->jy; v.jz = g->jz; v.rho = g->rho;
+    return v;
+}
+
+struct PartV {
+    long n;
+    double *x, *y, *z, *ux, *uy, *uz, *ig, *w;
+    double *eb[6];
+    unsigned long long *id;
+    unsigned char *dead;
+};
+
+static inline PartV make_partv(const lpa_particles *p) {
+    PartV v;
+    v.n = p->n; v.x = p->x; v.y = p->y; v.z = p->z; v.ux = p->ux; v.uy = p->uy; v.uz = p->uz;
+    v.ig = p->inv_gamma; v.w = p->w;
+    for (int c = 0; c < 6; c++) v.eb[c] = p->part_eb[c];
+    v.id = (unsigned long long *)p->id; v.dead = p->is_dead;
+    return v;
+}
+
+static inline int lpa_part_ok(const lpa_particles *p, int dim) {
+    if (!p || p->n < 0) return 0;
+    if (p->n == 0) return 1;
+    if (!p->x || !p->y || !p->ux || !p->uy || !p->uz || !p->inv_gamma || !p->w) return 0;
+    if (dim == 3 && !p->z) return 0;
+    int have = 0;
+    for (int c = 0; c < 6; c++) have += p->part_eb[c] != nullptr;
+    return have == 0 || have == 6;
+}
+
+// ---- device math ---------------------------------------------------------------------------------
+// torus index into a padded axis of length N (conventional layout: node i -> i + ng).
+__device__ __forceinline__ int torus(int c, int N) {
+    if ((unsigned)c >= (unsigned)N) {
+        c %= N;
+        if (c < 0) c += N;
+    }
+    return c;
+}
+
+// floor to int that never traps on NaN / huge values (garbage in, bounded garbage out)
+__device__ __forceinline__ int ifloor(double v) {
+    v = floor(v);
+    v = fmin(fmax(v, -1.0e9), 1.0e9);  // NaN -> -1e9 (fmax/fmin return the non-NaN operand)
+    return (int)v;
+}
+
+// TSC gather weights, core/pusher/unified/unified_pusher_2d.c:64-69
+__device__ __forceinline__ void tsc3(double d, double g[3]) {
+    double d2 = d * d;
+    g[0] = 0.5 * (0.25 + d2 + d);
+    g[1] = 0.75 - d2;
+    g[2] = 0.5 * (0.25 + d2 - d);
+}
+
+// relativistic Boris rotation, core/pusher/unified/unified_pusher_2d.c:15-51
+__device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double &ig, double Ex,
+                                      double Ey, double Ez, double Bx, double By, double Bz,
+                                      double efactor, double bfactor) {
+    double umx = ux + efactor * Ex, umy = uy + efactor * Ey, umz = uz + efactor * Ez;
+    double g = 1.0 / sqrt(1 + umx * umx + umy * umy + umz * umz);
+    double Tx = bfactor * Bx * g, Ty = bfactor * By * g, Tz = bfactor * Bz * g;
+    double upx = umx + umy * Tz - umz * Ty;
+    double upy = umy + umz * Tx - umx * Tz;
+    double upz = umz + umx * Ty - umy * Tx;
+    double Tf = 2.0 / (1 + Tx * Tx + Ty * Ty + Tz * Tz);
+    double Sx = Tf * Tx, Sy = Tf * Ty, Sz = Tf * Tz;
+    double px = umx + upy * Sz - upz * Sy;
+    double py = umy + upz * Sx - upx * Sz;
+    double pz = umz + upx * Sy - upy * Sx;
+    ux = px + efactor * Ex;
+    uy = py + efactor * Ey;
+    uz = pz + efactor * Ez;
+    ig = 1.0 / sqrt(1 + ux * ux + uy * uy + uz * uz);
+}
+
+// One axis of the Esirkepov deposit on a 4-cell window (current/current_deposit.h:7-35,206-249).
+// The reference works on the 5-cell window i0-2..i0+2 and loops [lo,hi) = [dc<0?0:1, dc>0?5:4);
+// that range is always contained in the 4 cells starting at i0-2+shift with shift = (dc<0 ? 0 : 1),
+// so the window is re-based there and all 4 cells are visited unconditionally (no divergence).
+// Cells the reference does not visit carry exactly-zero shape values here; the two running sums
+// whose residual would land on such a cell are masked by the caller through `tail_zero`.
+struct AxisW {
+    double S0[4], S1[4], DS[4];
+    int base;       // node index of window cell 0
+    bool tail_zero; // dc == 0: the 4th window cell is outside the reference's loop
+};
+
+__device__ __forceinline__ void axis_window(AxisW &a, double r_old, double r_adv, double d) {
+    double o0 = r_old / d, o1 = r_adv / d;
+    int i0 = ifloor(o0 + 0.5), i1 = ifloor(o1 + 0.5);
+    int dc = i1 - i0;
+    double d0 = i0 - o0, d1 = i1 - o1;
+    double q0 = d0 * d0, q1 = d1 * d1;
+    double lo0 = 0.5 * (q0 + d0 + 0.25), mi0 = 0.75 - q0, hi0 = 0.5 * (q0 - d0 + 0.25);
+    double lo1 = 0.5 * (q1 + d1 + 0.25), mi1 = 0.75 - q1, hi1 = 0.5 * (q1 - d1 + 0.25);
+    bool sh = dc >= 0;            // shift = 1
+    bool up = dc > 0;
+    bool valid = dc >= -1 && dc <= 1;  // |dc| > 1: the reference's calculate_S gives S1 == 0
+    if (!valid) { lo1 = 0.0; mi1 = 0.0; hi1 = 0.0; }
+    a.S0[0] = sh ? lo0 : 0.0; a.S0[1] = sh ? mi0 : lo0; a.S0[2] = sh ? hi0 : mi0; a.S0[3] = sh ? 0.0 : hi0;
+    a.S1[0] = up ? 0.0 : lo1; a.S1[1] = up ? lo1 : mi1; a.S1[2] = up ? mi1 : hi1; a.S1[3] = up ? hi1 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.DS[k] = a.S1[k] - a.S0[k];
+    a.base = i0 - 2 + (sh ? 1 : 0);
+    a.tail_zero = dc == 0;
+}
+
+// 2-D Esirkepov deposit of one particle on the 4x4 window; `sink(k, l, djx, djy, djz, drho)` adds the
+// contributions of window cell (k, l).  Factor grouping of the fused CPU kernel
+// (current/current_deposit.h:238-241) when FAST, of the standalone one (:104-108) otherwise.
+template <bool FAST, class Sink>
+__device__ __forceinline__ void esirkepov_2d(const AxisW &ax, const AxisW &ay, double vz, double w,
+                                             double q, double dx, double dy, double dt, Sink &&sink) {
+    double cd, fdx_, fdy_, fvz;
+    if (FAST) {
+        cd = (q / (dx * dy)) * w;
+        fdx_ = (q / (dy * dt)) * w;
+        fdy_ = (q / (dx * dt)) * w;
+        fvz = cd * vz;
+    } else {
+        cd = q * w / (dx * dy);
+        double f = cd / dt;
+        fdx_ = f * dx;
+        fdy_ = f * dy;
+        fvz = f * dt * vz;
+    }
+    const double one_twelfth = 1.0 / 12.0;
+    double jx_run[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double a = ax.S0[k] + 0.5 * ax.DS[k];
+        double fdx = fdx_ * ax.DS[k];
+        double t12 = one_twelfth * ax.DS[k];
+        double jy_run = 0.0;
+        bool xz = ax.tail_zero && k == 3;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            double b = ay.S0[l] + 0.5 * ay.DS[l];
+            double wy = ay.DS[l] * a;
+            double wz = a * b + t12 * ay.DS[l];
+            jx_run[l] -= fdx * b;
+            jy_run -= fdy_ * wy;
+            bool yz = ay.tail_zero && l == 3;
+            sink(k, l, xz ? 0.0 : jx_run[l], yz ? 0.0 : jy_run, fvz * wz, cd * ax.S1[k] * ay.S1[l]);
+        }
+    }
+}
+
+// block-wide sum of `v` into *out with one atomic per block (blockDim.x multiple of 64, <= 1024)
+__device__ __forceinline__ void block_atomic_sum(double v, double *out) {
+    __shared__ double red[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against a previous use
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    if (wv == 0) {
+        int nw = (blockDim.x + 63) >> 6;
+        double s = lane < nw ? red[lane] : 0.0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) atomicAdd(out, s);
+    }
+}

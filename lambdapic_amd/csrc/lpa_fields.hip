@@ -1,0 +1,374 @@
+// lpa_fields.hip -- grid-side kernels: Yee FDTD half steps, current reset, periodic guard wrap,
+// current fold, x-face halo pack/unpack, field diagnostics.  All are HBM-bound streaming kernels:
+// one thread per cell, threads consecutive along the fastest (last) axis so every wave reads and
+// writes whole 512-B rows.
+#include <stdarg.h>
+
+#include "lpa_common.hpp"
+
+// ---- error string ----------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void lpa_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *lpa_last_error(void) { return g_err; }
+extern "C" int lpa_version(void) { return 100; }
+
+// =====================================================================================================
+// FDTD.  Restates update_efield_2d / update_bfield_2d (core/maxwell/cpu.py:9-35) on the conventional
+// layout: interior node (i,j) is at [i+ng][j+ng]; i-1 at i=0 is the low guard, i+1 at nx-1 the high one.
+// AI: E sweep 13 loads + 3 stores per cell (104+24 B, 17 flop) -> HBM bound.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double jfac) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xm = c - g.NY, ym = c - 1;
+    double bzc = g.bz[c];
+    g.ex[c] += bfac * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c];
+    g.ey[c] += bfac * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    g.ez[c] += bfac * ((g.by[c] - g.by[xm]) / g.dx - (g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xp = c + g.NY, yp = c + 1;
+    double ezc = g.ez[c];
+    g.bx[c] -= dt * ((g.ez[yp] - ezc) / g.dy);
+    g.by[c] -= dt * (-(g.ez[xp] - ezc) / g.dx);
+    g.bz[c] -= dt * ((g.ey[xp] - g.ey[c]) / g.dx - (g.ex[yp] - g.ex[c]) / g.dy);
+}
+
+// 3-D (core/maxwell/cpu.py:83-112): grid (ceil(nz/256), ny, nx)
+__global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double jfac) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    long xm = c - sx, ym = c - sy, zm = c - 1;
+    double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
+    g.ex[c] += bfac * ((bzc - g.bz[ym]) / g.dy - (byc - g.by[zm]) / g.dz) - jfac * g.jx[c];
+    g.ey[c] += bfac * ((bxc - g.bx[zm]) / g.dz - (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    g.ez[c] += bfac * ((byc - g.by[xm]) / g.dx - (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    long xp = c + sx, yp = c + sy, zp = c + 1;
+    double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
+    g.bx[c] -= dt * ((g.ez[yp] - ezc) / g.dy - (g.ey[zp] - eyc) / g.dz);
+    g.by[c] -= dt * ((g.ex[zp] - exc) / g.dz - (g.ez[xp] - ezc) / g.dx);
+    g.bz[c] -= dt * ((g.ey[xp] - eyc) / g.dx - (g.ex[yp] - exc) / g.dy);
+}
+
+extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1), "lpa_fdtd_e_2d: bad grid");
+    LPA_REQUIRE(eps0 > 0, "lpa_fdtd_e_2d: eps0 must be > 0");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_2d, grid, dim3(256), 0, (hipStream_t)stream, v,
+                       dt * (LPA_C * LPA_C), dt / eps0);
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_2d(const lpa_grid *g, double dt, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 0), "lpa_fdtd_b_2d: bad grid");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt);
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "lpa_fdtd_e_3d: bad grid");
+    LPA_REQUIRE(eps0 > 0, "lpa_fdtd_e_3d: eps0 must be > 0");
+    LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_e_3d: nx, ny must be <= 65535");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_3d, grid, dim3(256), 0, (hipStream_t)stream, v,
+                       dt * (LPA_C * LPA_C), dt / eps0);
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 0), "lpa_fdtd_b_3d: bad grid");
+    LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_3d: nx, ny must be <= 65535");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt);
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_3d");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// current reset (core/current/cpu2d.c:19-72): memset of the four arrays including guards
+// =====================================================================================================
+extern "C" int lpa_reset_current(const lpa_grid *g, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho, "lpa_reset_current: bad grid");
+    size_t n = (size_t)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) *
+               (g->nz > 1 ? (size_t)(g->nz + 2 * g->ng) : 1) * sizeof(double);
+    double *a[4] = {g->jx, g->jy, g->jz, g->rho};
+    for (int c = 0; c < 4; c++)
+        if (hipMemsetAsync(a[c], 0, n, (hipStream_t)stream) != hipSuccess) {
+            lpa_set_error("lpa_reset_current: hipMemsetAsync failed");
+            return LPA_ERR_HIP;
+        }
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// periodic guard wrap (sync_guard_fields_2d with the patch as its own neighbour,
+// core/patch/sync_fields2d.c:150-255): every guard cell takes the value of the interior cell it is
+// the periodic image of along the axes in `axes`; one thread per padded cell, interior cells exit.
+// =====================================================================================================
+struct Ptr6 { double *p[6]; int n; };
+
+__device__ __forceinline__ int image_of(int c, int n, int ng, bool periodic, bool &guard) {
+    // padded index c -> padded index of the interior cell it mirrors (or itself)
+    int i = c - ng;
+    if (i < 0) { guard = true; return periodic ? c + n : -1; }
+    if (i >= n) { guard = true; return periodic ? c - n : -1; }
+    return c;
+}
+
+__global__ void __launch_bounds__(256) k_guard_wrap(GridV g, Ptr6 f, int axes) {
+    int z = blockIdx.x * blockDim.x + threadIdx.x;  // fastest axis
+    int NF = g.NZ > 1 ? g.NZ : g.NY;
+    if (z >= NF) return;
+    int cx = g.NZ > 1 ? blockIdx.z : blockIdx.y;
+    int cy = g.NZ > 1 ? blockIdx.y : z;
+    int cz = g.NZ > 1 ? z : 0;
+    bool guard = false;
+    int sx = image_of(cx, g.nx, g.ng, axes & 1, guard);
+    int sy = image_of(cy, g.ny, g.ng, axes & 2, guard);
+    int sz = g.NZ > 1 ? image_of(cz, g.nz, g.ng, axes & 4, guard) : 0;
+    if (!guard || sx < 0 || sy < 0 || sz < 0) return;
+    long dst = ((long)cx * g.NY + cy) * g.NZ + cz;
+    long src = ((long)sx * g.NY + sy) * g.NZ + sz;
+    for (int c = 0; c < f.n; c++) f.p[c][dst] = f.p[c][src];
+}
+
+extern "C" int lpa_guard_wrap(const lpa_grid *g, int which, int axes, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, g && g->nz > 1 ? 3 : 2, 0), "lpa_guard_wrap: bad grid");
+    LPA_REQUIRE(g->nx >= g->ng && g->ny >= g->ng, "lpa_guard_wrap: slab thinner than the guard");
+    int dim = g->nz > 1 ? 3 : 2;
+    GridV v = make_gridv(g, dim);
+    Ptr6 f;
+    f.n = 0;
+    if (which & 1) { f.p[f.n++] = g->ex; f.p[f.n++] = g->ey; f.p[f.n++] = g->ez; }
+    if (which & 2) { f.p[f.n++] = g->bx; f.p[f.n++] = g->by; f.p[f.n++] = g->bz; }
+    if (f.n == 0 || axes == 0) return LPA_OK;
+    dim3 grid = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
+    hipLaunchKernelGGL(k_guard_wrap, grid, dim3(256), 0, (hipStream_t)stream, v, f, axes);
+    LPA_CHECK_LAUNCH("lpa_guard_wrap");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// current fold (sync_currents_2d with a self neighbour, core/patch/sync_fields2d.c:43-148): an
+// interior cell within ng of a periodic face accumulates its images in the guards (x face first,
+// then y, then the corner -- the reference's order), then the guards that were consumed are zeroed.
+// Two launches: the fold only reads guards and writes interior cells, the second pass zeroes.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_current_fold(GridV g, int axes) {
+    int z = blockIdx.x * blockDim.x + threadIdx.x;
+    bool d3 = g.NZ > 1;
+    int nf = d3 ? g.nz : g.ny;
+    if (z >= nf) return;
+    int i = d3 ? blockIdx.z : blockIdx.y, j = d3 ? blockIdx.y : z, k = d3 ? z : 0;
+    int ng = g.ng;
+    // image offsets along each axis: 0 = none, else +-n
+    int ox = (axes & 1) ? (i < ng ? g.nx : (i >= g.nx - ng ? -g.nx : 0)) : 0;
+    int oy = (axes & 2) ? (j < ng ? g.ny : (j >= g.ny - ng ? -g.ny : 0)) : 0;
+    int oz = (d3 && (axes & 4)) ? (k < ng ? g.nz : (k >= g.nz - ng ? -g.nz : 0)) : 0;
+    // thin slabs (n < 2 ng) would need both images of an axis; rejected on the host
+    if (!(ox | oy | oz)) return;
+    long sY = g.NZ, sX = (long)g.NY * g.NZ;
+    long c = (long)(i + ng) * sX + (long)(j + ng) * sY + (d3 ? k + ng : 0);
+    double *arr[4] = {g.jx, g.jy, g.jz, g.rho};
+    for (int a = 0; a < 4; a++) {
+        double *f = arr[a];
+        double v = f[c];
+        // faces, edges, vertex in the reference's order (x, y, (z), then mixed)
+        if (ox) v += f[c + ox * sX];
+        if (oy) v += f[c + oy * sY];
+        if (oz) v += f[c + oz];
+        if (ox && oy) v += f[c + ox * sX + oy * sY];
+        if (ox && oz) v += f[c + ox * sX + oz];
+        if (oy && oz) v += f[c + oy * sY + oz];
+        if (ox && oy && oz) v += f[c + ox * sX + oy * sY + oz];
+        f[c] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_current_zero_guard(GridV g, int axes) {
+    int z = blockIdx.x * blockDim.x + threadIdx.x;
+    bool d3 = g.NZ > 1;
+    int NF = d3 ? g.NZ : g.NY;
+    if (z >= NF) return;
+    int cx = d3 ? blockIdx.z : blockIdx.y, cy = d3 ? blockIdx.y : z, cz = d3 ? z : 0;
+    bool gx = cx < g.ng || cx >= g.nx + g.ng, gy = cy < g.ng || cy >= g.ny + g.ng;
+    bool gz = d3 && (cz < g.ng || cz >= g.nz + g.ng);
+    // a guard cell was consumed iff every axis on which it is a guard is periodic here
+    if (!(gx || gy || gz)) return;
+    if ((gx && !(axes & 1)) || (gy && !(axes & 2)) || (gz && !(axes & 4))) return;
+    long c = ((long)cx * g.NY + cy) * g.NZ + cz;
+    g.jx[c] = 0.0; g.jy[c] = 0.0; g.jz[c] = 0.0; g.rho[c] = 0.0;
+}
+
+extern "C" int lpa_current_fold(const lpa_grid *g, int axes, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx > 0 && g->ny > 0 && g->ng > 0,
+                "lpa_current_fold: bad grid");
+    int dim = g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(g->nx >= 2 * g->ng && g->ny >= 2 * g->ng && (dim == 2 || g->nz >= 2 * g->ng),
+                "lpa_current_fold: slab thinner than 2*ng");
+    if (axes == 0) return LPA_OK;
+    GridV v;
+    memset(&v, 0, sizeof v);
+    v.nx = g->nx; v.ny = g->ny; v.nz = dim == 3 ? g->nz : 1; v.ng = g->ng;
+    v.NX = g->nx + 2 * g->ng; v.NY = g->ny + 2 * g->ng; v.NZ = dim == 3 ? g->nz + 2 * g->ng : 1;
+    v.jx = g->jx; v.jy = g->jy; v.jz = g->jz; v.rho = g->rho;
+    dim3 gi = dim == 3 ? dim3((v.nz + 255) / 256, v.ny, v.nx) : dim3((v.ny + 255) / 256, v.nx);
+    hipLaunchKernelGGL(k_current_fold, gi, dim3(256), 0, (hipStream_t)stream, v, axes);
+    LPA_CHECK_LAUNCH("lpa_current_fold");
+    dim3 gp = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
+    hipLaunchKernelGGL(k_current_zero_guard, gp, dim3(256), 0, (hipStream_t)stream, v, axes);
+    LPA_CHECK_LAUNCH("lpa_current_zero_guard");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// x-face halo buffers of the slab decomposition.  Planes along x are contiguous (x is the slowest
+// index), so a face is ng * NY(*NZ) consecutive doubles per component: these kernels are plain
+// copies; buffers are [ncomp][ng * plane].
+// =====================================================================================================
+enum { HALO_PACK_SRC = 0, HALO_UNPACK_GUARD = 1, HALO_PACK_CUR = 2, HALO_UNPACK_CUR = 3 };
+
+__global__ void __launch_bounds__(256) k_halo(Ptr6 f, double *buf, long plane, long first_row, int ng,
+                                              int mode) {
+    long n = (long)ng * plane;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int c = blockIdx.y;
+    double *a = f.p[c] + first_row * plane + t;
+    double *b = buf + (long)c * n + t;
+    if (mode == HALO_PACK_SRC) *b = *a;
+    else if (mode == HALO_UNPACK_GUARD) *a = *b;
+    else if (mode == HALO_PACK_CUR) { *b = *a; *a = 0.0; }
+    else *a += *b;
+}
+
+static int halo_launch(const lpa_grid *g, Ptr6 f, long first_row, double *buf, int mode, void *stream,
+                       const char *name) {
+    long plane = (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1);
+    long n = (long)g->ng * plane;
+    dim3 grid((unsigned)((n + 255) / 256), f.n);
+    hipLaunchKernelGGL(k_halo, grid, dim3(256), 0, (hipStream_t)stream, f, buf, plane, first_row,
+                       g->ng, mode);
+    LPA_CHECK_LAUNCH(name);
+    return LPA_OK;
+}
+
+static Ptr6 eb_ptrs(const lpa_grid *g, int which) {
+    Ptr6 f;
+    f.n = 0;
+    if (which & 1) { f.p[f.n++] = g->ex; f.p[f.n++] = g->ey; f.p[f.n++] = g->ez; }
+    if (which & 2) { f.p[f.n++] = g->bx; f.p[f.n++] = g->by; f.p[f.n++] = g->bz; }
+    return f;
+}
+
+extern "C" int lpa_halo_pack_guard_src(const lpa_grid *g, int which, int side, double *buf,
+                                       void *stream) {
+    LPA_REQUIRE(g && buf && (side == 0 || side == 1) && g->nx >= g->ng, "lpa_halo_pack_guard_src: bad args");
+    Ptr6 f = eb_ptrs(g, which);
+    if (!f.n) return LPA_OK;
+    // low face: interior rows [0, ng) -> padded rows [ng, 2ng); high face: [nx-ng, nx) -> [nx, nx+ng)
+    long first = side == 0 ? g->ng : g->nx;
+    return halo_launch(g, f, first, buf, HALO_PACK_SRC, stream, "lpa_halo_pack_guard_src");
+}
+
+extern "C" int lpa_halo_unpack_guard(const lpa_grid *g, int which, int side, const double *buf,
+                                     void *stream) {
+    LPA_REQUIRE(g && buf && (side == 0 || side == 1), "lpa_halo_unpack_guard: bad args");
+    Ptr6 f = eb_ptrs(g, which);
+    if (!f.n) return LPA_OK;
+    long first = side == 0 ? 0 : g->nx + g->ng;  // my low guard / my high guard
+    return halo_launch(g, f, first, (double *)buf, HALO_UNPACK_GUARD, stream, "lpa_halo_unpack_guard");
+}
+
+static Ptr6 cur_ptrs(const lpa_grid *g) {
+    Ptr6 f;
+    f.n = 4;
+    f.p[0] = g->jx; f.p[1] = g->jy; f.p[2] = g->jz; f.p[3] = g->rho;
+    return f;
+}
+
+extern "C" int lpa_halo_pack_current(const lpa_grid *g, int side, double *buf, void *stream) {
+    LPA_REQUIRE(g && buf && g->jx && g->jy && g->jz && g->rho && (side == 0 || side == 1),
+                "lpa_halo_pack_current: bad args");
+    long first = side == 0 ? 0 : g->nx + g->ng;  // guard planes
+    return halo_launch(g, cur_ptrs(g), first, buf, HALO_PACK_CUR, stream, "lpa_halo_pack_current");
+}
+
+extern "C" int lpa_halo_unpack_current(const lpa_grid *g, int side, const double *buf, void *stream) {
+    LPA_REQUIRE(g && buf && g->jx && g->jy && g->jz && g->rho && (side == 0 || side == 1) &&
+                    g->nx >= g->ng,
+                "lpa_halo_unpack_current: bad args");
+    long first = side == 0 ? g->ng : g->nx;  // interior edge planes
+    return halo_launch(g, cur_ptrs(g), first, (double *)buf, HALO_UNPACK_CUR, stream,
+                       "lpa_halo_unpack_current");
+}
+
+// =====================================================================================================
+// field diagnostics over the interior (reference tests/test_numerical_heating.py:19-37)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_diag_fields(GridV g, double ce, double cb, double dv,
+                                                     double *out) {
+    long ncell = (long)g.nx * g.ny * g.nz;
+    double e = 0, b = 0, r = 0, sx = 0, sy = 0, sz = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell;
+         t += (long)gridDim.x * blockDim.x) {
+        int k = (int)(t % g.nz);
+        long r2 = t / g.nz;
+        int j = (int)(r2 % g.ny), i = (int)(r2 / g.ny);
+        long c = ((long)(i + g.ng) * g.NY + (j + g.ng)) * g.NZ + (g.NZ > 1 ? k + g.ng : 0);
+        double a0 = g.ex[c], a1 = g.ey[c], a2 = g.ez[c];
+        double b0 = g.bx[c], b1 = g.by[c], b2 = g.bz[c];
+        e += a0 * a0 + a1 * a1 + a2 * a2;
+        b += b0 * b0 + b1 * b1 + b2 * b2;
+        if (g.rho) { r += g.rho[c]; sx += g.jx[c]; sy += g.jy[c]; sz += g.jz[c]; }
+    }
+    block_atomic_sum(e * ce * dv, out + 0);
+    block_atomic_sum(b * cb * dv, out + 1);
+    block_atomic_sum(r * dv, out + 2);
+    block_atomic_sum(sx, out + 3);
+    block_atomic_sum(sy, out + 4);
+    block_atomic_sum(sz, out + 5);
+}
+
+extern "C" int lpa_diag_fields(const lpa_grid *g, double eps0, double mu0, double *out, void *stream) {
+    int dim = g && g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(lpa_grid_ok(g, dim, 0) && out && mu0 > 0, "lpa_diag_fields: bad args");
+    GridV v = make_gridv(g, dim);
+    if (!g->jx || !g->jy || !g->jz) v.rho = nullptr;
+    double dv = g->dx * g->dy * (dim == 3 ? g->dz : 1.0);
+    hipLaunchKernelGGL(k_diag_fields, dim3(512), dim3(256), 0, (hipStream_t)stream, v, 0.5 * eps0,
+                       0.5 / mu0, dv, out);
+    LPA_CHECK_LAUNCH("lpa_diag_fields");
+    return LPA_OK;
+}

@@ -1,0 +1,449 @@
+// lpa_particles.hip -- the fused particle kernel (half push, TSC gather, Boris, half push, Esirkepov
+// deposit) in two forms, plus the split kernels and the particle diagnostics.
+//
+//  K1-global  any particle order; gathers E/B from global memory (L1/L2) and deposits with FP64
+//             global atomics on the torus.  Correct for every input; used for loose particles, for
+//             the overflow list of the tiled kernel and as the drop-in for unsorted patch arrays.
+//  K1-tiled   particles binned by 16x16-cell tiles (lpa_sort.hip).  One workgroup per work block of
+//             a tile: the tile's E/B (+4-cell halo) are staged once in LDS, particles stream through
+//             in SoA order (fully coalesced 512-B wave loads), J/rho accumulate in an LDS tile with
+//             ds_add_f64 and are flushed with one global atomic per touched cell.  Lanes of a wave
+//             hold particles of different cells (cell-interleaved tile order), so the LDS atomics of
+//             one wave instruction hit different addresses.
+//
+// Restates unified_boris_pusher_cpu_2d (core/pusher/unified/unified_pusher_2d.c:157-365).
+#include "lpa_common.hpp"
+
+struct PushK {
+    double dt, q, m;
+    double efactor, bfactor, cdt_half;
+    int wrap;
+    double lo[3], hi[3];
+};
+
+static PushK make_pushk(const lpa_push_params *pp) {
+    PushK k;
+    k.dt = pp->dt; k.q = pp->q; k.m = pp->m;
+    k.efactor = pp->q * pp->dt / (2 * pp->m * LPA_C);  // unified_pusher_2d.c:246-248
+    k.bfactor = pp->q * pp->dt / (2 * pp->m);
+    k.cdt_half = LPA_C * 0.5 * pp->dt;
+    k.wrap = pp->wrap;
+    for (int a = 0; a < 3; a++) { k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a]; }
+    return k;
+}
+
+// periodic fold of a coordinate into [lo, hi] (sync_particles_2d.c:168-182 with a self neighbour)
+__device__ __forceinline__ double fold_coord(double v, double lo, double hi) {
+    double L = hi - lo;
+    if (v > hi) v -= L;
+    if (v < lo) v += L;
+    return v;
+}
+
+// ---- global-memory gather (torus indices) -----------------------------------------------------------
+struct GIdx2 { int r[3]; int c[3]; };  // 3 wrapped row offsets (already * NY) and 3 wrapped columns
+
+__device__ __forceinline__ void gidx(GIdx2 &o, int ix, int iy, const GridV &g) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o.r[a] = torus(ix - 1 + a + g.ng, g.NX) * g.NY;
+        o.c[a] = torus(iy - 1 + a + g.ng, g.NY);
+    }
+}
+
+__device__ __forceinline__ double gather9_g(const double *__restrict__ f, const GIdx2 &o,
+                                            const double fx[3], const double fy[3]) {
+    return fy[0] * (fx[0] * f[o.r[0] + o.c[0]] + fx[1] * f[o.r[1] + o.c[0]] + fx[2] * f[o.r[2] + o.c[0]]) +
+           fy[1] * (fx[0] * f[o.r[0] + o.c[1]] + fx[1] * f[o.r[1] + o.c[1]] + fx[2] * f[o.r[2] + o.c[1]]) +
+           fy[2] * (fx[0] * f[o.r[0] + o.c[2]] + fx[1] * f[o.r[1] + o.c[2]] + fx[2] * f[o.r[2] + o.c[2]]);
+}
+
+__device__ __forceinline__ void gather_global_2d(const GridV &g, double xo, double yo, double eb[6]) {
+    // xo, yo: position in cells relative to node 0 (unified_pusher_2d.c:112-135)
+    int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo), iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
+    double gx[3], hx[3], gy[3], hy[3];
+    tsc3(ix1 - xo, gx);
+    tsc3(ix2 - xo + 0.5, hx);
+    tsc3(iy1 - yo, gy);
+    tsc3(iy2 - yo + 0.5, hy);
+    GIdx2 a;
+    gidx(a, ix2, iy1, g);
+    eb[0] = gather9_g(g.ex, a, hx, gy);
+    eb[4] = gather9_g(g.by, a, hx, gy);
+    gidx(a, ix1, iy2, g);
+    eb[1] = gather9_g(g.ey, a, gx, hy);
+    eb[3] = gather9_g(g.bx, a, gx, hy);
+    gidx(a, ix1, iy1, g);
+    eb[2] = gather9_g(g.ez, a, gx, gy);
+    gidx(a, ix2, iy2, g);
+    eb[5] = gather9_g(g.bz, a, hx, hy);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, double y, double ux,
+                                                  double uy, double uz, double ig, double w, double q,
+                                                  double dt) {
+    double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+    AxisW ax, ay;
+    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, g.dx);
+    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, g.dy);
+    int rows[4], cols[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        rows[k] = torus(ax.base + k + g.ng, g.NX) * g.NY;
+        cols[k] = torus(ay.base + k + g.ng, g.NY);
+    }
+    esirkepov_2d<FAST>(ax, ay, vz, w, q, g.dx, g.dy, dt,
+                       [&](int k, int l, double djx, double djy, double djz, double drho) {
+                           int idx = rows[k] + cols[l];
+                           if (djx != 0.0) atomicAdd(&g.jx[idx], djx);
+                           if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
+                           if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
+                           if (drho != 0.0) atomicAdd(&g.rho[idx], drho);
+                       });
+}
+
+// the whole per-particle update on global memory
+__device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p, const PushK &k, long ip) {
+    double x = p.x[ip], y = p.y[ip];
+    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return;
+    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig = p.ig[ip], w = p.w[ip];
+    x += k.cdt_half * ig * ux;
+    y += k.cdt_half * ig * uy;
+    double eb[6];
+    gather_global_2d(g, (x - g.x0) * (1.0 / g.dx), (y - g.y0) * (1.0 / g.dy), eb);
+    if (p.eb[0]) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+    }
+    boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
+    x += k.cdt_half * ig * ux;
+    y += k.cdt_half * ig * uy;
+    deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt);
+    if (k.wrap & 1) x = fold_coord(x, k.lo[0], k.hi[0]);
+    if (k.wrap & 2) y = fold_coord(y, k.lo[1], k.hi[1]);
+    p.x[ip] = x; p.y[ip] = y;
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+}
+
+__global__ void __launch_bounds__(256) k_push_deposit_global_2d(GridV g, PartV p, PushK k, long first,
+                                                                long count) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    update_global_2d(g, p, k, first + t);
+}
+
+__global__ void __launch_bounds__(256) k_push_deposit_list_2d(GridV g, PartV p, PushK k,
+                                                              const uint32_t *__restrict__ list,
+                                                              const uint32_t *__restrict__ list_count) {
+    long n = *list_count;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        update_global_2d(g, p, k, list[t]);
+}
+
+// =====================================================================================================
+// K1-tiled
+// =====================================================================================================
+constexpr int TILE = LPA_TILE;            // 16 cells
+constexpr int HALO = LPA_TILE_MARGIN + 3; // margin + (1 cell of motion + 2 cells of stencil), see DESIGN.md
+constexpr int RW = TILE + 2 * HALO;       // 24: edge of the staged region in nodes
+constexpr int RS = RW + 1;                // LDS row stride in doubles (odd: spreads rows over banks)
+constexpr int RSZ = RW * RS;
+
+// gather from the LDS copy; (lx, ly) = local index of the stencil centre, guaranteed inside by the
+// margin test (and clamped against non-finite input)
+__device__ __forceinline__ double gather9_l(const double *f, int lx, int ly, const double fx[3],
+                                            const double fy[3]) {
+    const double *c = f + lx * RS + ly;
+    return fy[0] * (fx[0] * c[-RS - 1] + fx[1] * c[-1] + fx[2] * c[RS - 1]) +
+           fy[1] * (fx[0] * c[-RS] + fx[1] * c[0] + fx[2] * c[RS]) +
+           fy[2] * (fx[0] * c[-RS + 1] + fx[1] * c[1] + fx[2] * c[RS + 1]);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <bool WRITE_EB>
+__global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
+                                                              const int32_t *__restrict__ blk_tile,
+                                                              const int32_t *__restrict__ blk_begin,
+                                                              const int32_t *__restrict__ blk_end,
+                                                              const int32_t *__restrict__ n_blocks,
+                                                              int tiles_y, uint32_t *overflow,
+                                                              uint32_t *overflow_count) {
+    __shared__ double s_eb[6][RSZ];
+    __shared__ double s_j[4][RSZ];
+    if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
+    const int tile = blk_tile[blockIdx.x];
+    const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
+    const int tx0 = (tile / tiles_y) * TILE, ty0 = (tile % tiles_y) * TILE;  // first node of the tile
+    const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
+
+    // ---- stage E/B (nodes outside the padded array are never touched by a fast-path particle)
+    {
+        const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
+        for (int t = threadIdx.x; t < RW * RW; t += blockDim.x) {
+            int lx = t / RW, ly = t - lx * RW;
+            int cx = rx0 + lx + g.ng, cy = ry0 + ly + g.ng;
+            bool in = (unsigned)cx < (unsigned)g.NX && (unsigned)cy < (unsigned)g.NY;
+            long gi = (long)cx * g.NY + cy;
+#pragma unroll
+            for (int c = 0; c < 6; c++) s_eb[c][lx * RS + ly] = in ? src[c][gi] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_j[c][lx * RS + ly] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy;
+    for (int ip = begin + threadIdx.x; ip < end; ip += blockDim.x) {
+        double x = p.x[ip], y = p.y[ip];
+        if (isnan(x) || isnan(y)) continue;  // killed since the last sort (migration)
+        // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
+        int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
+        if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TILE + LPA_TILE_MARGIN ||
+            js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TILE + LPA_TILE_MARGIN) {
+            uint32_t slot = atomicAdd(overflow_count, 1u);
+            overflow[slot] = (uint32_t)ip;
+            continue;
+        }
+        double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig = p.ig[ip], w = p.w[ip];
+        x += k.cdt_half * ig * ux;
+        y += k.cdt_half * ig * uy;
+        double eb[6];
+        {
+            double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy;
+            int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo), iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
+            double gx[3], hx[3], gy[3], hy[3];
+            tsc3(ix1 - xo, gx);
+            tsc3(ix2 - xo + 0.5, hx);
+            tsc3(iy1 - yo, gy);
+            tsc3(iy2 - yo + 0.5, hy);
+            int lx1 = clampi(ix1 - rx0, 1, RW - 2), lx2 = clampi(ix2 - rx0, 1, RW - 2);
+            int ly1 = clampi(iy1 - ry0, 1, RW - 2), ly2 = clampi(iy2 - ry0, 1, RW - 2);
+            eb[0] = gather9_l(s_eb[0], lx2, ly1, hx, gy);
+            eb[1] = gather9_l(s_eb[1], lx1, ly2, gx, hy);
+            eb[2] = gather9_l(s_eb[2], lx1, ly1, gx, gy);
+            eb[3] = gather9_l(s_eb[3], lx1, ly2, gx, hy);
+            eb[4] = gather9_l(s_eb[4], lx2, ly1, hx, gy);
+            eb[5] = gather9_l(s_eb[5], lx2, ly2, hx, hy);
+        }
+        if (WRITE_EB) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+        }
+        boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
+        x += k.cdt_half * ig * ux;
+        y += k.cdt_half * ig * uy;
+        {
+            double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+            AxisW ax, ay;
+            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, g.dx);
+            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, g.dy);
+            int bx = clampi(ax.base - rx0, 0, RW - 4), by = clampi(ay.base - ry0, 0, RW - 4);
+            int b0 = bx * RS + by;
+            esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
+                               [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                   int o = b0 + kk * RS + ll;
+                                   atomicAdd(&s_j[0][o], djx);
+                                   atomicAdd(&s_j[1][o], djy);
+                                   atomicAdd(&s_j[2][o], djz);
+                                   atomicAdd(&s_j[3][o], drho);
+                               });
+        }
+        if (k.wrap & 1) x = fold_coord(x, k.lo[0], k.hi[0]);
+        if (k.wrap & 2) y = fold_coord(y, k.lo[1], k.hi[1]);
+        p.x[ip] = x; p.y[ip] = y;
+        p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+    }
+    __syncthreads();
+
+    // ---- flush the J tile: one FP64 global atomic per touched cell and component.  Consecutive
+    //      threads walk consecutive y -> each wave instruction covers contiguous 8-B segments of a row
+    {
+        double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
+        for (int t = threadIdx.x; t < RW * RW; t += blockDim.x) {
+            int lx = t / RW, ly = t - lx * RW;
+            int cx = rx0 + lx + g.ng, cy = ry0 + ly + g.ng;
+            if ((unsigned)cx >= (unsigned)g.NX || (unsigned)cy >= (unsigned)g.NY) continue;
+            long gi = (long)cx * g.NY + cy;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = s_j[c][lx * RS + ly];
+                if (v != 0.0) atomicAdd(&dst[c][gi], v);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// host entry points
+// =====================================================================================================
+static int check_push(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                      const char *name) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1), "%s: bad grid", name);
+    LPA_REQUIRE(lpa_part_ok(p, 2), "%s: bad particle store", name);
+    LPA_REQUIRE(pp && pp->dt > 0 && pp->m > 0, "%s: dt and m must be > 0", name);
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                                   int64_t first, int64_t count, void *stream) {
+    if (int e = check_push(g, p, pp, "lpa_push_deposit_2d")) return e;
+    LPA_REQUIRE(first >= 0 && count >= 0 && first + count <= p->n, "lpa_push_deposit_2d: bad range");
+    if (count == 0) return LPA_OK;
+    long nb = (count + 255) / 256;
+    hipLaunchKernelGGL(k_push_deposit_global_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       make_gridv(g, 2), make_partv(p), make_pushk(pp), (long)first, (long)count);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *p,
+                                        const lpa_push_params *pp, const uint32_t *list,
+                                        const uint32_t *list_count, int64_t max_count, void *stream) {
+    if (int e = check_push(g, p, pp, "lpa_push_deposit_list_2d")) return e;
+    LPA_REQUIRE(list && list_count && max_count >= 0, "lpa_push_deposit_list_2d: bad list");
+    if (max_count == 0 || p->n == 0) return LPA_OK;
+    long nb = (max_count + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_push_deposit_list_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       make_gridv(g, 2), make_partv(p), make_pushk(pp), list, list_count);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_list_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles *p,
+                                         const lpa_push_params *pp, const lpa_tiling *t,
+                                         uint32_t *overflow, uint32_t *overflow_count, void *stream) {
+    if (int e = check_push(g, p, pp, "lpa_push_deposit_tiled_2d")) return e;
+    LPA_REQUIRE(t && t->blk_tile && t->blk_begin && t->blk_end && t->n_blocks && t->max_blocks > 0 &&
+                    overflow && overflow_count,
+                "lpa_push_deposit_tiled_2d: bad tiling");
+    LPA_REQUIRE(t->tiles_x == (g->nx + TILE - 1) / TILE && t->tiles_y == (g->ny + TILE - 1) / TILE,
+                "lpa_push_deposit_tiled_2d: tiling does not match the grid");
+    LPA_REQUIRE(p->is_dead == nullptr,
+                "lpa_push_deposit_tiled_2d: tile-binned stores carry no is_dead array (dead = NaN x)");
+    // the LDS region covers margin + 3 nodes around the tile: one cell of motion per step at most
+    LPA_REQUIRE(LPA_C * pp->dt <= g->dx && LPA_C * pp->dt <= g->dy,
+                "lpa_push_deposit_tiled_2d: c*dt exceeds a cell (CFL); use lpa_push_deposit_2d");
+    if (t->n_sorted == 0) return LPA_OK;
+    GridV gv = make_gridv(g, 2);
+    PartV pv = make_partv(p);
+    PushK k = make_pushk(pp);
+    if (p->part_eb[0])
+        hipLaunchKernelGGL(k_push_deposit_tiled_2d<true>, dim3(t->max_blocks), dim3(256), 0,
+                           (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
+                           t->n_blocks, t->tiles_y, overflow, overflow_count);
+    else
+        hipLaunchKernelGGL(k_push_deposit_tiled_2d<false>, dim3(t->max_blocks), dim3(256), 0,
+                           (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
+                           t->n_blocks, t->tiles_y, overflow, overflow_count);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_2d");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// split kernels (callback-in-pusher-stage path)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_interpolate_2d(GridV g, PartV p) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;  // interpolation/cpu2d.c:127 skips is_dead only
+    double eb[6];
+    gather_global_2d(g, (p.x[ip] - g.x0) / g.dx, (p.y[ip] - g.y0) / g.dy, eb);
+#pragma unroll
+    for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+}
+
+__global__ void __launch_bounds__(256) k_boris(PartV p, double efactor, double bfactor) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;
+    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig;
+    boris(ux, uy, uz, ig, p.eb[0][ip], p.eb[1][ip], p.eb[2][ip], p.eb[3][ip], p.eb[4][ip], p.eb[5][ip],
+          efactor, bfactor);
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+}
+
+__global__ void __launch_bounds__(256) k_push_position_2d(PartV p, double cdt) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;
+    double ig = p.ig[ip];
+    p.x[ip] += cdt * ig * p.ux[ip];
+    p.y[ip] += cdt * ig * p.uy[ip];
+}
+
+__global__ void __launch_bounds__(256) k_deposit_2d(GridV g, PartV p, double dt, double q) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    double x = p.x[ip], y = p.y[ip];
+    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return;
+    deposit_global_2d<false>(g, x, y, p.ux[ip], p.uy[ip], p.uz[ip], p.ig[ip], p.w[ip], q, dt);
+}
+
+extern "C" int lpa_interpolate_2d(const lpa_grid *g, const lpa_particles *p, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && lpa_part_ok(p, 2) && (p->n == 0 || p->part_eb[0]),
+                "lpa_interpolate_2d: bad args (part_eb required)");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_interpolate_2d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_gridv(g, 2), make_partv(p));
+    LPA_CHECK_LAUNCH("lpa_interpolate_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_boris(const lpa_particles *p, double dt, double q, double m, void *stream) {
+    LPA_REQUIRE(p && p->n >= 0 && (p->n == 0 || (p->ux && p->uy && p->uz && p->inv_gamma && p->part_eb[0])) &&
+                    m > 0,
+                "lpa_boris: bad args (part_eb required)");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_boris, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       make_partv(p), q * dt / (2 * m * LPA_C), q * dt / (2 * m));
+    LPA_CHECK_LAUNCH("lpa_boris");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_position_2d(const lpa_particles *p, double dt, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 2), "lpa_push_position_2d: bad particle store");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_push_position_2d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_partv(p), LPA_C * dt);
+    LPA_CHECK_LAUNCH("lpa_push_position_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_deposit_2d(const lpa_grid *g, const lpa_particles *p, double dt, double q,
+                              void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1) && lpa_part_ok(p, 2) && dt > 0, "lpa_deposit_2d: bad args");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_deposit_2d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_gridv(g, 2), make_partv(p), dt, q);
+    LPA_CHECK_LAUNCH("lpa_deposit_2d");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// particle diagnostics: kinetic energy sum w (gamma - 1) m c^2 and live count
+// (reference tests/test_numerical_heating.py:40-50)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_diag_particles(PartV p, double mc2, double *out) {
+    double e = 0.0, n = 0.0;
+    for (long ip = (long)blockIdx.x * blockDim.x + threadIdx.x; ip < p.n;
+         ip += (long)gridDim.x * blockDim.x) {
+        if ((p.dead && p.dead[ip]) || isnan(p.x[ip])) continue;
+        e += p.w[ip] * (1.0 / p.ig[ip] - 1.0);
+        n += 1.0;
+    }
+    block_atomic_sum(e * mc2, out + 0);
+    block_atomic_sum(n, out + 1);
+}
+
+extern "C" int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stream) {
+    LPA_REQUIRE(p && out && p->n >= 0 && (p->n == 0 || (p->x && p->w && p->inv_gamma)),
+                "lpa_diag_particles: bad args");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_diag_particles, dim3(1024), dim3(256), 0, (hipStream_t)stream, make_partv(p),
+                       m * LPA_C * LPA_C, out);
+    LPA_CHECK_LAUNCH("lpa_diag_particles");
+    return LPA_OK;
+}

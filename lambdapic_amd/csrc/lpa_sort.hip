@@ -1,0 +1,344 @@
+// lpa_sort.hip -- cell-index sort (tile binning) and slab migration of particles.
+//
+// The reference sorts every species every step by x-cell buckets in place and keeps dead particles
+// inside the arrays (core/sort/cpu2d.c:9-54,108-189; policy core/sort/particle_sort.py:196-211).  The
+// permutation inside a bucket is implementation defined there; what the rest of the step relies on is
+// only locality.  On the GPU the sort exists to make the LDS-tiled kernel possible:
+//   1. k_tile_count   : tile id of every live particle (16x16 cells, nearest-node cells) + its rank
+//                       inside the tile through wave-aggregated atomics (one atomic per distinct tile
+//                       per wave instruction);
+//   2. k_tile_scan    : one workgroup: exclusive scan of the tile counts, the per-tile interleave
+//                       multiplier and the work-block table of the tiled kernel;
+//   3. k_tile_scatter : out-of-place copy of every attribute to slot
+//                       tile_off + (rank * minv) mod n_tile.
+// The multiplicative permutation makes slot s hold rank (s * G) mod n with G ~ n / golden ratio: 64
+// consecutive slots (= one wave of the tiled kernel) hold ranks spread >= ~n/170 apart, i.e. particles
+// of different cells, so the wave's LDS atomics do not pile up on one address.  Dead / NaN particles
+// are dropped (compaction) -- they are the reference's recycled "dead slots".
+#include "lpa_common.hpp"
+
+constexpr int TILE = LPA_TILE;
+
+struct SortHdr {      // first 64 bytes of the workspace
+    int32_t n_live;   // live particles after the sort
+    int32_t n_blocks; // valid work blocks
+    int32_t pad[14];
+};
+
+struct SortWs {
+    SortHdr *hdr;
+    int32_t *tile_cnt, *tile_off, *blk_tile, *blk_begin, *blk_end;
+    uint32_t *tile_minv, *key, *rank;
+    int ntiles, max_blocks;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
+    int tx = (g->nx + TILE - 1) / TILE, ty = (g->ny + TILE - 1) / TILE;
+    int nt = tx * ty;
+    int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return base ? base + o : nullptr; };
+    char *p;
+    p = take(sizeof(SortHdr)); if (w) w->hdr = (SortHdr *)p;
+    p = take(sizeof(int32_t) * nt); if (w) w->tile_cnt = (int32_t *)p;
+    p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off = (int32_t *)p;
+    p = take(sizeof(uint32_t) * nt); if (w) w->tile_minv = (uint32_t *)p;
+    p = take(sizeof(int32_t) * maxb); if (w) w->blk_tile = (int32_t *)p;
+    p = take(sizeof(int32_t) * maxb); if (w) w->blk_begin = (int32_t *)p;
+    p = take(sizeof(int32_t) * maxb); if (w) w->blk_end = (int32_t *)p;
+    p = take(sizeof(uint32_t) * cap); if (w) w->key = (uint32_t *)p;
+    p = take(sizeof(uint32_t) * cap); if (w) w->rank = (uint32_t *)p;
+    if (w) { w->ntiles = nt; w->max_blocks = (int)maxb; }
+    return (int64_t)off;
+}
+
+extern "C" int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity) {
+    if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;
+    // sized for the smallest block size accepted by lpa_sort_tiles_2d
+    return ws_layout(g, capacity, 1024, nullptr, nullptr);
+}
+
+extern "C" const int32_t *lpa_sort_live_count(void *workspace) {
+    return workspace ? &((SortHdr *)workspace)->n_live : nullptr;
+}
+
+constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256) k_tile_count(PartV p, double x0, double y0, double inv_dx,
+                                                    double inv_dy, int nx, int ny, int tiles_y,
+                                                    int32_t *tile_cnt, uint32_t *key, uint32_t *rank) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    uint32_t tile = KEY_DEAD;
+    if (ip < p.n) {
+        double x = p.x[ip], y = p.y[ip];
+        live = !((p.dead && p.dead[ip]) || isnan(x) || isnan(y));
+        if (live) {
+            // nearest-node cell, clamped into the slab (a particle may sit up to one cell outside
+            // between the push and the migration)
+            int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5);
+            is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
+            js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
+            tile = (uint32_t)((is / TILE) * tiles_y + js / TILE);
+        }
+    }
+    // wave-aggregated rank assignment: lanes that share a tile elect a leader that reserves the
+    // whole group with one atomic
+    uint32_t r = 0;
+    unsigned long long todo = __ballot(live);
+    int lane = threadIdx.x & 63;
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        uint32_t lt = __shfl(tile, leader, 64);
+        unsigned long long grp = __ballot(live && tile == lt) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = (uint32_t)atomicAdd(&tile_cnt[lt], (int32_t)__popcll(grp));
+        base = __shfl(base, leader, 64);
+        if ((grp >> lane) & 1ull) r = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+        todo &= ~grp;
+    }
+    if (ip < p.n) {
+        key[ip] = tile;
+        rank[ip] = r;
+    }
+}
+
+__device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) { uint32_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+// modular inverse of a modulo n (gcd(a, n) == 1, n >= 2) by the extended Euclid recursion
+__device__ __forceinline__ uint32_t modinv_u32(uint32_t a, uint32_t n) {
+    long long t = 0, nt = 1, r = n, nr = a;
+    while (nr) {
+        long long qq = r / nr;
+        long long tmp = t - qq * nt; t = nt; nt = tmp;
+        tmp = r - qq * nr; r = nr; nr = tmp;
+    }
+    if (t < 0) t += n;
+    return (uint32_t)t;
+}
+
+__global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *tile_cnt, int32_t *tile_off,
+                                                    uint32_t *tile_minv, int32_t *blk_tile,
+                                                    int32_t *blk_begin, int32_t *blk_end, SortHdr *hdr,
+                                                    int block_particles, int max_blocks) {
+    __shared__ int32_t s_part[1024], s_blk[1024];
+    int tid = threadIdx.x;
+    int per = (ntiles + 1023) / 1024;
+    int lo = tid * per, hi = min(lo + per, ntiles);
+    int32_t sum = 0, sb = 0;
+    for (int t = lo; t < hi; t++) {
+        int32_t c = tile_cnt[t];
+        sum += c;
+        sb += (c + block_particles - 1) / block_particles;
+    }
+    s_part[tid] = sum;
+    s_blk[tid] = sb;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        int32_t a = tid >= o ? s_part[tid - o] : 0, b = tid >= o ? s_blk[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += a;
+        s_blk[tid] += b;
+        __syncthreads();
+    }
+    int32_t off = s_part[tid] - sum, boff = s_blk[tid] - sb;
+    for (int t = lo; t < hi; t++) {
+        int32_t c = tile_cnt[t];
+        tile_off[t] = off;
+        uint32_t minv = 1;
+        if (c >= 3) {
+            uint32_t G = (uint32_t)((double)c * 0.6180339887498949);
+            if (G < 1) G = 1;
+            while (gcd_u32(G, (uint32_t)c) != 1) G++;
+            minv = modinv_u32(G % (uint32_t)c, (uint32_t)c);
+        }
+        tile_minv[t] = minv;
+        int nb = (c + block_particles - 1) / block_particles;
+        for (int b = 0; b < nb && boff + b < max_blocks; b++) {
+            // equal split of the tile's particles over its blocks
+            long s0 = (long)c * b / nb, s1 = (long)c * (b + 1) / nb;
+            blk_tile[boff + b] = t;
+            blk_begin[boff + b] = off + (int32_t)s0;
+            blk_end[boff + b] = off + (int32_t)s1;
+        }
+        off += c;
+        boff += nb;
+    }
+    if (tid == 1023) {
+        tile_off[ntiles] = s_part[1023];
+        hdr->n_live = s_part[1023];
+        hdr->n_blocks = min(s_blk[1023], max_blocks);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tile_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
+                                                      const uint32_t *__restrict__ rank,
+                                                      const int32_t *__restrict__ tile_off,
+                                                      const int32_t *__restrict__ tile_cnt,
+                                                      const uint32_t *__restrict__ tile_minv) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= s.n) return;
+    uint32_t t = key[ip];
+    if (t == KEY_DEAD) return;
+    uint32_t n = (uint32_t)tile_cnt[t];
+    unsigned long long slot = ((unsigned long long)rank[ip] * tile_minv[t]) % n;
+    long o = (long)tile_off[t] + (long)slot;
+    d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
+    if (s.z && d.z) d.z[o] = s.z[ip];
+    d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
+    d.ig[o] = s.ig[ip]; d.w[o] = s.w[ip];
+    if (s.id && d.id) d.id[o] = s.id[ip];
+    if (s.eb[0] && d.eb[0]) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) d.eb[c][o] = s.eb[c][ip];
+    }
+}
+
+extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                                 void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                                 lpa_tiling *out, void *stream) {
+    LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0, "lpa_sort_tiles_2d: bad grid");
+    LPA_REQUIRE(lpa_part_ok(src, 2) && lpa_part_ok(dst, 2) && workspace && out,
+                "lpa_sort_tiles_2d: bad particle stores / workspace");
+    LPA_REQUIRE(src->n < (1ll << 31) - 1, "lpa_sort_tiles_2d: more than 2^31 particles in one store");
+    LPA_REQUIRE(dst->n >= src->n, "lpa_sort_tiles_2d: dst capacity (dst->n) smaller than src->n");
+    LPA_REQUIRE(block_particles >= 1024, "lpa_sort_tiles_2d: block_particles must be >= 1024");
+    LPA_REQUIRE(dst->x != src->x, "lpa_sort_tiles_2d: the sort is out of place");
+    SortWs w;
+    int64_t need = ws_layout(g, src->n, block_particles, (char *)workspace, &w);
+    if (need > workspace_bytes) {
+        lpa_set_error("lpa_sort_tiles_2d: workspace %lld B < %lld B", (long long)workspace_bytes,
+                      (long long)need);
+        return LPA_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int tiles_x = (g->nx + TILE - 1) / TILE, tiles_y = (g->ny + TILE - 1) / TILE;
+    if (hipMemsetAsync(w.tile_cnt, 0, sizeof(int32_t) * w.ntiles, st) != hipSuccess) {
+        lpa_set_error("lpa_sort_tiles_2d: memset failed");
+        return LPA_ERR_HIP;
+    }
+    PartV sv = make_partv(src), dv = make_partv(dst);
+    if (src->n > 0) {
+        unsigned nb = (unsigned)((src->n + 255) / 256);
+        hipLaunchKernelGGL(k_tile_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
+                           1.0 / g->dy, g->nx, g->ny, tiles_y, w.tile_cnt, w.key, w.rank);
+        LPA_CHECK_LAUNCH("k_tile_count");
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off,
+                       w.tile_minv, w.blk_tile, w.blk_begin, w.blk_end, w.hdr, (int)block_particles,
+                       w.max_blocks);
+    LPA_CHECK_LAUNCH("k_tile_scan");
+    if (src->n > 0) {
+        unsigned nb = (unsigned)((src->n + 255) / 256);
+        hipLaunchKernelGGL(k_tile_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
+                           w.tile_cnt, w.tile_minv);
+        LPA_CHECK_LAUNCH("k_tile_scatter");
+    }
+    out->tiles_x = tiles_x;
+    out->tiles_y = tiles_y;
+    out->n_sorted = src->n;  // upper bound known on the host; the exact count is hdr->n_live
+    out->max_blocks = w.max_blocks;
+    out->tile_off = w.tile_off;
+    out->blk_tile = w.blk_tile;
+    out->blk_begin = w.blk_begin;
+    out->blk_end = w.blk_end;
+    out->n_blocks = &w.hdr->n_blocks;
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// slab migration along x (core/patch/sync_particles_2d.c:204-518, core/mpi/sync_particles_2d.c:274-770):
+// leavers are copied into the low / high send buffer and killed; arrivals are appended to the arrival
+// area behind the tile-ordered particles.  No host round trip: the message has a fixed size and carries
+// its own count.  Buffer layout (doubles): [0] = count (int64 bit pattern), then
+// [LPA_MIG_NATTR][capacity] SoA, attribute order x y z ux uy uz inv_gamma w id.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, double xhi, double *buf_lo,
+                                                        double *buf_hi, long cap) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    double x = p.x[ip];
+    if ((p.dead && p.dead[ip]) || isnan(x)) return;
+    int side = x < xlo ? 0 : (x > xhi ? 1 : -1);
+    if (side < 0) return;
+    double *b = side == 0 ? buf_lo : buf_hi;
+    long slot = (long)atomicAdd((unsigned long long *)b, 1ull);
+    if (slot < cap) {
+        double *d = b + 1;
+        d[0 * cap + slot] = x;
+        d[1 * cap + slot] = p.y[ip];
+        d[2 * cap + slot] = p.z ? p.z[ip] : 0.0;
+        d[3 * cap + slot] = p.ux[ip];
+        d[4 * cap + slot] = p.uy[ip];
+        d[5 * cap + slot] = p.uz[ip];
+        d[6 * cap + slot] = p.ig[ip];
+        d[7 * cap + slot] = p.w[ip];
+        d[8 * cap + slot] = p.id ? __longlong_as_double((long long)p.id[ip]) : 0.0;
+        // the particle now belongs to the neighbour (sync_particles_2d.c:185-202)
+        p.x[ip] = __longlong_as_double(0x7ff8000000000000ll);
+        p.y[ip] = __longlong_as_double(0x7ff8000000000000ll);
+        if (p.dead) p.dead[ip] = 1;
+    }
+    // slot >= cap: the particle is NOT lost -- it stays where it is (outside the slab, handled by the
+    // torus path) and leaves at the next step; count > cap is visible to the host at the next sort.
+}
+
+__global__ void __launch_bounds__(256) k_migrate_unpack(PartV p, long first_slot, long area_cap,
+                                                        int32_t *cursor, const double *buf, long cap,
+                                                        double shift_x) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)*(const unsigned long long *)buf;
+    if (n > cap) n = cap;
+    if (t >= n) return;
+    long slot = atomicAdd(cursor, 1);
+    if (slot >= area_cap) return;  // cursor > area_cap tells the host the area overflowed
+    long o = first_slot + slot;
+    const double *d = buf + 1;
+    p.x[o] = d[0 * cap + t] + shift_x;
+    p.y[o] = d[1 * cap + t];
+    if (p.z) p.z[o] = d[2 * cap + t];
+    p.ux[o] = d[3 * cap + t];
+    p.uy[o] = d[4 * cap + t];
+    p.uz[o] = d[5 * cap + t];
+    p.ig[o] = d[6 * cap + t];
+    p.w[o] = d[7 * cap + t];
+    if (p.id) p.id[o] = (unsigned long long)__double_as_longlong(d[8 * cap + t]);
+    if (p.dead) p.dead[o] = 0;
+}
+
+extern "C" int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
+                                  double *buf_hi, int64_t capacity, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 2) && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
+                "lpa_migrate_pack_x: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(buf_lo, 0, sizeof(double), st) != hipSuccess ||
+        hipMemsetAsync(buf_hi, 0, sizeof(double), st) != hipSuccess) {
+        lpa_set_error("lpa_migrate_pack_x: memset failed");
+        return LPA_ERR_HIP;
+    }
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_migrate_pack_x, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st,
+                       make_partv(p), xlo, xhi, buf_lo, buf_hi, (long)capacity);
+    LPA_CHECK_LAUNCH("lpa_migrate_pack_x");
+    return LPA_OK;
+}
+
+extern "C" int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_capacity,
+                                  int32_t *cursor, const double *buf, int64_t capacity, double shift_x,
+                                  void *stream) {
+    LPA_REQUIRE(p && p->x && p->y && p->ux && p->uy && p->uz && p->inv_gamma && p->w && buf && cursor &&
+                    capacity > 0 && first_slot >= 0 && area_capacity >= 0,
+                "lpa_migrate_unpack: bad args");
+    if (area_capacity == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_migrate_unpack, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_partv(p), (long)first_slot, (long)area_capacity, cursor,
+                       buf, (long)capacity, shift_x);
+    LPA_CHECK_LAUNCH("lpa_migrate_unpack");
+    return LPA_OK;
+}

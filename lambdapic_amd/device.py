@@ -1,0 +1,169 @@
+"""Device-resident state: one field slab and per-species SoA particle stores.
+
+PyTorch is plumbing here (HBM allocation, streams, host<->device copies); every computation
+goes through the C ABI of ``liblambdapic_amd.so``.
+
+HBM layout
+  * fields: ONE allocation ``float64[10][NX][NY]`` (order ex ey ez bx by bz jx jy jz rho,
+    conventional guard layout ``[ng | interior | ng]``, y fastest).  x is the slowest axis, so an
+    x-face halo of a component is ``ng*NY`` contiguous doubles, and jx jy jz rho are contiguous
+    (one memset zeroes all four).
+  * particles: per species TWO sets (ping/pong for the out-of-place tile sort) of SoA arrays
+    ``x y ux uy uz inv_gamma w id`` (+ the six ``*_part`` arrays only when a callback needs them),
+    each ``float64[capacity]``.  Dead slots are marked by ``x = NaN``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
+
+PART_CORE = ("x", "y", "ux", "uy", "uz", "inv_gamma", "w")
+PART_EB = ("ex_part", "ey_part", "ez_part", "bx_part", "by_part", "bz_part")
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DeviceGrid2D:
+    """One rank's slab of the Yee grid in HBM."""
+
+    def __init__(self, nx, ny, dx, dy, x0, y0, n_guard, device):
+        self.nx, self.ny, self.ng = int(nx), int(ny), int(n_guard)
+        self.dx, self.dy, self.x0, self.y0 = float(dx), float(dy), float(x0), float(y0)
+        self.device = torch.device(device)
+        self.NX, self.NY = self.nx + 2 * self.ng, self.ny + 2 * self.ng
+        self.buf = torch.zeros((10, self.NX, self.NY), dtype=torch.float64, device=self.device)
+        g = _lib.lpa_grid()
+        g.nx, g.ny, g.nz, g.ng = self.nx, self.ny, 1, self.ng
+        g.dx, g.dy, g.dz = self.dx, self.dy, 0.0
+        g.x0, g.y0, g.z0 = self.x0, self.y0, 0.0
+        for k, name in enumerate(FIELD_ATTRS):
+            setattr(g, name, self.buf[k].data_ptr())
+        self.c = g
+
+    def view(self, name) -> torch.Tensor:
+        return self.buf[FIELD_ATTRS.index(name)]
+
+    # ---- host mirrors ---------------------------------------------------------------------------
+    def upload(self, name, wrapped: np.ndarray):
+        """host array in λPIC's wrapped guard layout -> device (conventional layout)"""
+        a = np.ascontiguousarray(to_device_layout(wrapped, self.ng))
+        self.view(name).copy_(torch.from_numpy(a))
+
+    def download(self, name) -> np.ndarray:
+        """device -> host array in λPIC's wrapped guard layout"""
+        return np.ascontiguousarray(from_device_layout(self.view(name).cpu().numpy(), self.ng))
+
+    def upload_patches(self, patches, npatch_x, npatch_y, attrs=FIELD_ATTRS):
+        """assemble the patch mirrors (interiors + outer guards) into the slab"""
+        for name in attrs:
+            slab = np.zeros((self.NX, self.NY))
+            for p in patches:
+                f = p.fields
+                a = to_device_layout(getattr(f, name), f.n_guard)
+                i0, j0 = p.ipatch_x * f.nx, p.ipatch_y * f.ny
+                slab[i0:i0 + f.nx + 2 * f.n_guard, j0:j0 + f.ny + 2 * f.n_guard] = a
+            # interiors win over neighbours' guards
+            for p in patches:
+                f = p.fields
+                g = f.n_guard
+                a = to_device_layout(getattr(f, name), g)
+                i0, j0 = p.ipatch_x * f.nx + g, p.ipatch_y * f.ny + g
+                slab[i0:i0 + f.nx, j0:j0 + f.ny] = a[g:g + f.nx, g:g + f.ny]
+            self.view(name).copy_(torch.from_numpy(slab))
+
+    def download_patches(self, patches, attrs=FIELD_ATTRS):
+        """scatter the slab back into the patch mirrors (each patch gets its interior + guards)"""
+        for name in attrs:
+            slab = self.view(name).cpu().numpy()
+            for p in patches:
+                f = p.fields
+                g = f.n_guard
+                i0, j0 = p.ipatch_x * f.nx, p.ipatch_y * f.ny
+                blk = slab[i0:i0 + f.nx + 2 * g, j0:j0 + f.ny + 2 * g]
+                getattr(f, name)[...] = from_device_layout(blk, g)
+
+
+class ParticleSet:
+    """one SoA set; ``c`` is the lpa_particles view of the first ``n`` slots"""
+
+    def __init__(self, capacity, device, with_eb=False):
+        self.capacity = int(capacity)
+        names = list(PART_CORE) + (list(PART_EB) if with_eb else [])
+        self.data = torch.empty((len(names), self.capacity), dtype=torch.float64, device=device)
+        self.names = names
+        self.id = torch.zeros(self.capacity, dtype=torch.int64, device=device)
+        self.with_eb = with_eb
+
+    def arr(self, name) -> torch.Tensor:
+        return self.data[self.names.index(name)]
+
+    def cstruct(self, n) -> _lib.lpa_particles:
+        p = _lib.lpa_particles()
+        p.n = int(n)
+        for name in PART_CORE:
+            setattr(p, name, self.arr(name).data_ptr())
+        p.z = None
+        for k, name in enumerate(PART_EB):
+            p.part_eb[k] = self.arr(name).data_ptr() if self.with_eb else None
+        p.id = self.id.data_ptr()
+        p.is_dead = None
+        return p
+
+
+class DeviceParticles:
+    """One species on one rank: ping/pong SoA sets, tile binning state, arrival area."""
+
+    def __init__(self, capacity, device, q, m, with_eb=False):
+        self.device = torch.device(device)
+        self.q, self.m = float(q), float(m)
+        self.capacity = int(capacity)
+        self.sets = [ParticleSet(capacity, self.device, with_eb), None]
+        self.with_eb = with_eb
+        self.cur = 0
+        self.n = 0            # slots in use in the current set (live + dead + arrival area)
+        self.n_sorted = 0     # [0, n_sorted) is tile ordered
+        self.tiling = None
+        self.steps_since_sort = 0
+
+    @property
+    def cset(self) -> ParticleSet:
+        return self.sets[self.cur]
+
+    def other(self) -> ParticleSet:
+        if self.sets[1 - self.cur] is None:
+            self.sets[1 - self.cur] = ParticleSet(self.capacity, self.device, self.with_eb)
+        return self.sets[1 - self.cur]
+
+    def upload(self, host_particles_list):
+        """concatenate the live particles of the host mirrors into the device store"""
+        cols = {a: [] for a in PART_CORE}
+        ids = []
+        for hp in host_particles_list:
+            live = ~hp.is_dead & ~np.isnan(hp.x) & ~np.isnan(hp.y)
+            for a in PART_CORE:
+                cols[a].append(getattr(hp, a)[live])
+            ids.append(hp._id.view(np.int64)[live])
+        n = int(sum(c.size for c in ids))
+        if n > self.capacity:
+            raise _lib.LpaError(f"particle capacity {self.capacity} < {n}")
+        s = self.cset
+        for a in PART_CORE:
+            s.arr(a)[:n].copy_(torch.from_numpy(np.concatenate(cols[a])))
+        s.id[:n].copy_(torch.from_numpy(np.concatenate(ids)))
+        self.n, self.n_sorted, self.tiling = n, 0, None
+
+    def download(self):
+        """dict of host arrays of the LIVE particles (order = device order)"""
+        s = self.cset
+        x = s.arr("x")[: self.n]
+        live = ~torch.isnan(x)
+        out = {a: s.arr(a)[: self.n][live].cpu().numpy() for a in s.names}
+        out["_id"] = s.id[: self.n][live].cpu().numpy().view(np.float64)
+        return out

@@ -1,0 +1,283 @@
+"""PicEngine2D -- the device-resident PIC inner loop of one rank (one MI355X).
+
+Holds the rank's field slab and particle stores in HBM and exposes the operations the reference's
+facades perform on its patch lists, one call per reference call:
+
+    reference (per step, simulation/simulation.py:937-1122)      engine
+    ---------------------------------------------------------    ---------------------------
+    maxwell.update_efield(dt) / update_bfield(dt)                update_efield / update_bfield
+    patches.sync_guard_fields + mpi.sync_guard_fields_*          sync_guard_fields
+    sorter[ispec]()                                              sort
+    current_depositor.reset()                                    reset_current
+    pusher[ispec](dt, unified=True)                              push_deposit
+    patches.sync_currents + mpi.sync_currents_*                  sync_currents
+    mpi.sync_particles_* + patches.sync_particles                sync_particles
+
+Multi-GPU: the domain is split into 1-D slabs along x, one process per GPU (torch.distributed,
+backend nccl == RCCL); x faces are exchanged with the two ring neighbours (``SlabComm``), y is
+periodic inside the slab.  With one rank both axes are handled locally.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, constants
+from ._lib import LPA_MIG_NATTR, check, lib
+from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr
+from .dist import SlabComm
+
+
+class PicEngine2D:
+    def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
+                 x0=0.0, y0=0.0, sort_interval=8, block_particles=8192, migrate_capacity=32768,
+                 periodic_x=True, periodic_y=True):
+        """``nx`` is the LOCAL number of cells along x (this rank's slab); the global box has
+        ``nx * comm.size`` cells and this slab starts at ``x0 + rank*nx*dx``."""
+        self.L = lib()
+        self.comm = comm or SlabComm(None)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LpaError("PicEngine2D needs a GPU device; there is no CPU path")
+        self.nx, self.ny, self.dx, self.dy, self.ng = int(nx), int(ny), float(dx), float(dy), int(n_guard)
+        if not (periodic_x and periodic_y):
+            raise NotImplementedError("only periodic boundaries in this round (CPML: SURVEY 8f-1)")
+        self.x0_global, self.y0 = float(x0), float(y0)
+        self.x0 = self.x0_global + self.comm.rank * self.nx * self.dx
+        self.Lx, self.Ly = self.nx * self.comm.size * self.dx, self.ny * self.dy
+        self.grid = DeviceGrid2D(self.nx, self.ny, dx, dy, self.x0, self.y0, n_guard, self.device)
+        self.species: list[DeviceParticles] = []
+        self.sort_interval = int(sort_interval)
+        self.block_particles = int(block_particles)
+        self.migrate_capacity = int(migrate_capacity)
+        # axes handled by local periodic wrap: y always; x only when this rank owns the whole box
+        self.local_axes = 2 | (1 if self.comm.size == 1 else 0)
+        self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
+        self._ws = {}
+        self._halo = None
+        self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
+        # bench instrumentation: when a list, (start, end) HIP events are recorded around every
+        # launch of the tiled push+deposit kernel on the stream it runs on
+        self.kernel_events = None
+
+    # ---------------------------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return current_stream_ptr(self.device)
+
+    def add_species(self, q, m, capacity, with_eb=False) -> int:
+        self.species.append(DeviceParticles(capacity, self.device, q, m, with_eb))
+        return len(self.species) - 1
+
+    def _g(self):
+        return C.byref(self.grid.c)
+
+    # ---- Maxwell (MaxwellSolver2D.update_efield/bfield, core/maxwell/solver/solver.py:143-190) ----
+    def update_efield(self, dt):
+        check(self.L.lpa_fdtd_e_2d(self._g(), dt, self.eps0, self.stream), "lpa_fdtd_e_2d")
+
+    def update_bfield(self, dt):
+        check(self.L.lpa_fdtd_b_2d(self._g(), dt, self.stream), "lpa_fdtd_b_2d")
+
+    # ---- guard cells (Patches.sync_guard_fields + MPIManager.sync_guard_fields_start/_wait) --------
+    def _halo_bufs(self):
+        if self._halo is None:
+            n = self.ng * self.grid.NY
+            mk = lambda c: torch.empty(c * n, dtype=torch.float64, device=self.device)
+            self._halo = {"s_lo": mk(4), "s_hi": mk(4), "r_lo": mk(4), "r_hi": mk(4)}
+        return self._halo
+
+    def sync_guard_fields(self, attrs):
+        which = (1 if any(a in attrs for a in ("ex", "ey", "ez")) else 0) | \
+                (2 if any(a in attrs for a in ("bx", "by", "bz")) else 0)
+        st = self.stream
+        check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
+        if self.comm.size > 1:
+            h = self._halo_bufs()
+            ncomp = 3 * bin(which).count("1")
+            n = ncomp * self.ng * self.grid.NY
+            # my low interior edge becomes the LEFT neighbour's high guard and vice versa
+            check(self.L.lpa_halo_pack_guard_src(self._g(), which, 0, h["s_lo"].data_ptr(), st), "pack lo")
+            check(self.L.lpa_halo_pack_guard_src(self._g(), which, 1, h["s_hi"].data_ptr(), st), "pack hi")
+            self.comm.exchange(h["s_lo"][:n], h["s_hi"][:n], h["r_lo"][:n], h["r_hi"][:n])
+            check(self.L.lpa_halo_unpack_guard(self._g(), which, 0, h["r_lo"].data_ptr(), st), "unpack lo")
+            check(self.L.lpa_halo_unpack_guard(self._g(), which, 1, h["r_hi"].data_ptr(), st), "unpack hi")
+
+    # ---- currents (CurrentDeposition2D.reset, Patches.sync_currents + MPIManager.sync_currents_*) --
+    def reset_current(self):
+        check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
+
+    def sync_currents(self):
+        st = self.stream
+        if self.comm.size > 1:
+            h = self._halo_bufs()
+            n = 4 * self.ng * self.grid.NY
+            # my low GUARD planes are added to the LEFT neighbour's high interior edge
+            check(self.L.lpa_halo_pack_current(self._g(), 0, h["s_lo"].data_ptr(), st), "pack cur lo")
+            check(self.L.lpa_halo_pack_current(self._g(), 1, h["s_hi"].data_ptr(), st), "pack cur hi")
+            self.comm.exchange(h["s_lo"][:n], h["s_hi"][:n], h["r_lo"][:n], h["r_hi"][:n])
+            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "unpack cur lo")
+            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "unpack cur hi")
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+
+    # ---- sort (ParticleSort2D.__call__, core/sort/particle_sort.py:196-211) ------------------------
+    def _sort_ws(self, sp: DeviceParticles):
+        key = id(sp)
+        if key not in self._ws:
+            nbytes = self.L.lpa_sort_workspace_bytes(self._g(), sp.capacity)
+            area = self.migrate_capacity * 2 * max(self.sort_interval, 1) if self.comm.size > 1 else 0
+            self._ws[key] = {
+                "sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
+                "overflow": torch.empty(sp.capacity, dtype=torch.int32, device=self.device),
+                "counters": torch.zeros(4, dtype=torch.int32, device=self.device),  # 0: overflow, 1: arrivals
+                "area": area,
+                "tiling": _lib.lpa_tiling(),
+                "mig": None,
+            }
+        return self._ws[key]
+
+    def sort(self, ispec):
+        """tile-bin species ``ispec`` (drops dead slots).  One host sync (live count read-back)."""
+        sp = self.species[ispec]
+        ws = self._ws_checked(sp)
+        src, dst = sp.cset, sp.other()
+        ps, pd = src.cstruct(sp.n), dst.cstruct(dst.capacity)
+        check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
+                                       ws["sort"].numel(), self.block_particles, C.byref(ws["tiling"]),
+                                       self.stream), "lpa_sort_tiles_2d")
+        hdr = ws["sort"][:8].view(torch.int32)
+        n_live = int(hdr[0].item())                      # sync point (once per sort_interval steps)
+        arrivals = int(ws["counters"][1].item())
+        if arrivals > ws["area"]:
+            raise _lib.LpaError(f"arrival area overflow: {arrivals} > {ws['area']} (raise migrate_capacity)")
+        sp.cur = 1 - sp.cur
+        sp.n_sorted = n_live
+        area = ws["area"]
+        if n_live + area > sp.capacity:
+            raise _lib.LpaError(f"particle capacity {sp.capacity} < live {n_live} + arrival area {area}")
+        if area:
+            dst.arr("x")[n_live:n_live + area].fill_(float("nan"))
+        sp.n = n_live + area
+        ws["counters"].zero_()
+        ws["tiling"].n_sorted = n_live
+        sp.tiling = ws["tiling"]
+        sp.steps_since_sort = 0
+
+    def _ws_checked(self, sp):
+        ws = self._sort_ws(sp)
+        if sp.n > sp.capacity:
+            raise _lib.LpaError("particle store over capacity")
+        return ws
+
+    # ---- fused pusher (BorisPusher.__call__(dt, unified=True), core/pusher/pusher.py:116-127) ------
+    def _push_params(self, sp, dt):
+        pp = _lib.lpa_push_params()
+        pp.dt, pp.q, pp.m = dt, sp.q, sp.m
+        pp.wrap = self.local_axes
+        pp.lo[0], pp.hi[0] = self.x0_global - self.dx / 2, self.x0_global + self.Lx - self.dx / 2
+        pp.lo[1], pp.hi[1] = self.y0 - self.dy / 2, self.y0 + self.Ly - self.dy / 2
+        pp.lo[2], pp.hi[2] = 0.0, 0.0
+        return pp
+
+    def push_deposit(self, ispec, dt, tiled=True):
+        sp = self.species[ispec]
+        if sp.n == 0:
+            return
+        st = self.stream
+        pp = self._push_params(sp, dt)
+        pc = sp.cset.cstruct(sp.n)
+        if tiled and sp.tiling is not None and sp.n_sorted > 0:
+            ws = self._sort_ws(sp)
+            ws["counters"][0:1].zero_()
+            cnt = ws["counters"].data_ptr()
+            if self.kernel_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
+            check(self.L.lpa_push_deposit_tiled_2d(self._g(), C.byref(pc), C.byref(pp), C.byref(sp.tiling),
+                                                   ws["overflow"].data_ptr(), cnt, st), "tiled")
+            if self.kernel_events is not None:
+                e1.record(torch.cuda.current_stream(self.device))
+                self.kernel_events.append((e0, e1))
+            check(self.L.lpa_push_deposit_list_2d(self._g(), C.byref(pc), C.byref(pp),
+                                                  ws["overflow"].data_ptr(), cnt, sp.n_sorted, st), "list")
+            loose = sp.n - sp.n_sorted
+            if loose > 0:
+                check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), sp.n_sorted, loose, st),
+                      "loose")
+        else:
+            check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), 0, sp.n, st), "global")
+        sp.steps_since_sort += 1
+
+    # ---- particle ownership (mpi.sync_particles_* + Patches.sync_particles) ------------------------
+    def sync_particles(self, ispec):
+        """periodic wrap is fused into the push kernel; between slabs leavers travel to the ring
+        neighbours in one fixed-size message per face (count in band, no host sync)."""
+        if self.comm.size == 1:
+            return
+        sp = self.species[ispec]
+        ws = self._sort_ws(sp)
+        cap = self.migrate_capacity
+        if ws["mig"] is None:
+            mk = lambda: torch.zeros(1 + LPA_MIG_NATTR * cap, dtype=torch.float64, device=self.device)
+            ws["mig"] = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
+        if sp.tiling is None:
+            raise _lib.LpaError("sync_particles on a slab decomposition needs a sorted store (arrival area)")
+        m, st = ws["mig"], self.stream
+        pc = sp.cset.cstruct(sp.n)
+        xlo = self.x0 - self.dx / 2
+        xhi = self.x0 + (self.nx - 1) * self.dx + self.dx / 2
+        check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
+                                        cap, st), "lpa_migrate_pack_x")
+        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        cur = ws["counters"][1:2].data_ptr()
+        # arrivals through my low face come from the left neighbour; at the global low edge they
+        # crossed the periodic boundary: x > xmax_global -> x - Lx (sync_particles_2d.c:168-182)
+        shift_lo = -self.Lx if self.comm.rank == 0 else 0.0
+        shift_hi = self.Lx if self.comm.rank == self.comm.size - 1 else 0.0
+        check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_lo"].data_ptr(), cap,
+                                        shift_lo, st), "unpack lo")
+        check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_hi"].data_ptr(), cap,
+                                        shift_hi, st), "unpack hi")
+
+    # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
+    def step(self, dt, tiled=True):
+        E, B = ("ex", "ey", "ez"), ("bx", "by", "bz")
+        self.update_efield(0.5 * dt)
+        self.sync_guard_fields(E)
+        self.update_bfield(0.5 * dt)
+        self.sync_guard_fields(B)
+        if tiled:
+            for i, sp in enumerate(self.species):
+                if sp.tiling is None or sp.steps_since_sort >= self.sort_interval:
+                    self.sort(i)
+        self.reset_current()
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt, tiled=tiled)
+        self.sync_currents()
+        for i in range(len(self.species)):
+            self.sync_particles(i)
+        self.update_bfield(0.5 * dt)
+        self.sync_guard_fields(B)
+        self.update_efield(0.5 * dt)
+        self.sync_guard_fields(E)
+
+    # ---- diagnostics ------------------------------------------------------------------------------
+    def diagnostics(self):
+        """dict of field energy (E, B parts), total charge, current sums, kinetic energy and live
+        count per species -- local to this rank (sum over ranks for the global value)."""
+        st = self.stream
+        self._diag.zero_()
+        check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), st), "diag")
+        out = {}
+        f = self._diag.cpu().numpy().copy()
+        out.update(energy_e=f[0], energy_b=f[1], field_energy=f[0] + f[1], charge=f[2],
+                   jx=f[3], jy=f[4], jz=f[5], kinetic=[], nalive=[])
+        for sp in self.species:
+            d = torch.zeros(2, dtype=torch.float64, device=self.device)
+            pc = sp.cset.cstruct(sp.n)
+            check(self.L.lpa_diag_particles(C.byref(pc), sp.m, d.data_ptr(), st), "diag particles")
+            d = d.cpu().numpy()
+            out["kinetic"].append(float(d[0]))
+            out["nalive"].append(int(round(d[1])))
+        return out

@@ -81,18 +81,25 @@ def _dead(p):
 # -------------------------------------------------------------------------------------------------
 # kernel-level entry points with the reference's call signatures (duck-typed particle / field bags)
 # -------------------------------------------------------------------------------------------------
-def unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m):
-    """restates core/pusher/unified/unified_pusher_2d.c:157-365"""
-    L = lib()
-    for p, f in zip(particles_list[:npatches], fields_list[:npatches]):
-        eb = _tab([getattr(f, n) for n in FIELD_ORDER[:6]])
-        pe = _tab([getattr(p, n) for n in PART_EB])
-        L.orc_unified_2d(C.c_long(p.npart), _p(p.x), _p(p.y), _p(p.ux), _p(p.uy), _p(p.uz),
-                         _p(p.inv_gamma), _p(p.w), _p(_dead(p)), pe, eb,
-                         _p(f.rho), _p(f.jx), _p(f.jy), _p(f.jz),
-                         C.c_long(f.nx), C.c_long(f.ny), C.c_long(f.n_guard),
-                         C.c_double(f.dx), C.c_double(f.dy), C.c_double(f.x0), C.c_double(f.y0),
-                         C.c_double(dt), C.c_double(q), C.c_double(m))
+def unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m, native=False):
+    """restates core/pusher/unified/unified_pusher_2d.c:157-365 (OpenMP over patches, static
+    schedule, like the reference's `#pragma omp parallel for`, :213-214)"""
+    L = lib(native)
+    if npatches <= 0:
+        return
+    P, F = particles_list[:npatches], fields_list[:npatches]
+    f0 = F[0]
+    npart = (C.c_long * npatches)(*[p.npart for p in P])
+    tabs = [_tab([getattr(p, a) for p in P]) for a in ("x", "y", "ux", "uy", "uz", "inv_gamma", "w")]
+    dead = _tab([_dead(p) for p in P])
+    part_eb = _tab([getattr(p, n) for p in P for n in PART_EB])
+    fields = _tab([getattr(f, n) for f in F for n in FIELD_ORDER])
+    x0 = (C.c_double * npatches)(*[f.x0 for f in F])
+    y0 = (C.c_double * npatches)(*[f.y0 for f in F])
+    L.orc_unified_2d_patches(C.c_long(npatches), npart, *tabs, dead, part_eb, fields, x0, y0,
+                             C.c_long(f0.nx), C.c_long(f0.ny), C.c_long(f0.n_guard),
+                             C.c_double(f0.dx), C.c_double(f0.dy), C.c_double(dt), C.c_double(q),
+                             C.c_double(m))
 
 
 def unified_boris_pusher_cpu_3d(particles_list, fields_list, npatches, dt, q, m):

@@ -1,0 +1,66 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol the
+header declares; the ctypes binding covers exactly that set.  No compute call is made (no GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from lambdapic_amd import _lib
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def header_symbols():
+    text = (ROOT / "include" / "lambdapic_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lpa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_symbols():
+    syms = header_symbols()
+    assert "lpa_push_deposit_tiled_2d" in syms and "lpa_fdtd_e_2d" in syms
+    assert len(syms) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+    assert _lib.LIB_PATH.exists(), "run __graft_entry__.build() / python -m lambdapic_amd.build"
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    missing = [s for s in header_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_binding_matches_header():
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    L = _lib.lib()
+    assert L.lpa_version() >= 100
+    assert L.lpa_last_error() is not None
+
+
+def test_struct_layout_matches_header():
+    # field counts / sizes of the POD structs (x86-64 SysV, natural alignment)
+    assert ctypes.sizeof(_lib.lpa_grid) == 4 * 4 + 6 * 8 + 10 * 8
+    assert ctypes.sizeof(_lib.lpa_particles) == 8 + 8 * 8 + 6 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.lpa_push_params) == 3 * 8 + 8 + 6 * 8
+    assert ctypes.sizeof(_lib.lpa_tiling) == 8 + 8 + 8 + 5 * 8
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    """argument errors come back as a status + message, like the reference's PyArg_ParseTuple
+    failures (no other error reporting exists there)"""
+    L = _lib.lib()
+    g = _lib.lpa_grid()   # all zero: invalid
+    assert L.lpa_fdtd_b_2d(ctypes.byref(g), 1e-17, None) == -1
+    assert b"bad grid" in L.lpa_last_error()
+    with pytest.raises(_lib.LpaError):
+        _lib.check(-1, "x")
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lambdapic_amd import kernels
+    from lambdapic_amd.fields import Fields2D
+    with pytest.raises(_lib.LpaError):
+        kernels.update_bfield_2d(Fields2D(8, 8, 1e-8, 1e-8, 0, 0, 3), 1e-17)

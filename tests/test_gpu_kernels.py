@@ -1,0 +1,247 @@
+"""GPU parity tests of the HIP kernels, through the C ABI (via the kernel-level drop-ins), against
+(a) the committed golden vectors recorded from the reference's own kernels and (b) the oracle on
+the same seeded inputs.
+
+Tolerances (FP64, stated per quantity):
+  * pushed particle attributes: 1e-12 of the array's max -- few-ulp differences from FMA
+    contraction (hipcc contracts, the reference build contracts differently);
+  * gathered E/B at the particle: 1e-11 of the max (9/27-term sums of O(1e12) random fields);
+  * grid rho/J: 1e-12 of the max entry -- atomics change the summation order only;
+  * FDTD: 1e-14.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import PEB, assert_close, fields2d_from, fields3d_from, particles_from
+from lambdapic_amd import kernels
+from lambdapic_amd.fields import Fields2D
+from lambdapic_amd.particles import ParticlesBase
+
+pytestmark = pytest.mark.gpu
+
+C = 299792458.0
+QE, ME = -1.602176634e-19, 9.1093837139e-31
+
+
+def _cmp_fused_2d(g, k, tiled):
+    f = fields2d_from(g, f"in{k}_", g[f"x0_{k}"], g[f"y0_{k}"])
+    p = particles_from(g, f"in{k}_")
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, float(g["dt"]), float(g["q"]), float(g["m"]),
+                                        tiled=tiled)
+    for a in ["x", "y", "ux", "uy", "uz", "inv_gamma"]:
+        assert_close(getattr(p, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
+    alive = ~(p.is_dead | np.isnan(g[f"in{k}_x"]) | np.isnan(g[f"in{k}_y"]))
+    for a in PEB:
+        assert_close(getattr(p, a)[alive], g[f"out{k}_{a}"][alive], 1e-11, what=f"patch{k} {a}")
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_fused_2d_vs_golden(golden, tiled):
+    g = golden("g1_fused_2d")
+    for k in range(int(g["npatches"])):
+        _cmp_fused_2d(g, k, tiled)
+
+
+def test_fused_3d_vs_golden(golden):
+    g = golden("g2_fused_3d")
+    f = fields3d_from(g, "in_")
+    p = particles_from(g, "in_")
+    kernels.unified_boris_pusher_cpu_3d([p], [f], 1, float(g["dt"]), float(g["q"]), float(g["m"]))
+    for a in ["x", "y", "z", "ux", "uy", "uz", "inv_gamma"]:
+        assert_close(getattr(p, a), g[f"out_{a}"], 1e-12, what=a)
+    alive = ~(p.is_dead | np.isnan(g["in_x"]) | np.isnan(g["in_y"]) | np.isnan(g["in_z"]))
+    for a in PEB:
+        assert_close(getattr(p, a)[alive], g[f"out_{a}"][alive], 1e-11, what=a)
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+
+
+def test_standalone_deposit_and_interpolation_vs_golden(golden):
+    g = golden("g3_deposit_2d")
+    f = fields2d_from(g, "none_", g["x0"], g["y0"])
+    p = particles_from(g, "in_")
+    kernels.current_deposition_cpu_2d([f], [p], 1, float(g["dt"]), float(g["q"]))
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+    g = golden("g4_interp_2d")
+    f = fields2d_from(g, "in_", g["x0"], g["y0"])
+    p = particles_from(g, "in_", ["x", "y"])
+    kernels.interpolation_patches_2d([p], [f], 1)
+    for a in PEB:
+        assert_close(getattr(p, a)[~p.is_dead], g[f"out_{a}"][~p.is_dead], 1e-11, what=a)
+
+
+def test_fdtd_vs_golden(golden):
+    g = golden("g5_fdtd_2d")
+    f = fields2d_from(g, "in_", 0.0, 0.0)
+    kernels.update_efield_2d(f, float(g["dt"]))
+    for a in ["ex", "ey", "ez"]:
+        assert_close(getattr(f, a), g[f"outE_{a}"], 1e-14, what=a)
+    kernels.update_bfield_2d(f, float(g["dt"]))
+    for a in ["bx", "by", "bz"]:
+        assert_close(getattr(f, a), g[f"outB_{a}"], 1e-14, what=a)
+    g = golden("g5_fdtd_3d")
+    f = fields3d_from({**{k: g[k] for k in g.files}, "x0": 0.0, "y0": 0.0, "z0": 0.0}, "in_")
+    kernels.update_efield_3d(f, float(g["dt"]))
+    for a in ["ex", "ey", "ez"]:
+        assert_close(getattr(f, a), g[f"outE_{a}"], 1e-14, what=a)
+    kernels.update_bfield_3d(f, float(g["dt"]))
+    for a in ["bx", "by", "bz"]:
+        assert_close(getattr(f, a), g[f"outB_{a}"], 1e-14, what=a)
+
+
+def _random_case(nx, ny, n, seed, u_scale):
+    rng = np.random.default_rng(seed)
+    dx, dy = 4e-8, 5e-8
+    f = Fields2D(nx, ny, dx, dy, 3 * dx, -2 * dy, 3)
+    for a in ("ex", "ey", "ez"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e12
+    for a in ("bx", "by", "bz"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e4
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = f.x0 + rng.uniform(-0.5, nx - 0.5, n) * dx
+    p.y[:] = f.y0 + rng.uniform(-0.5, ny - 0.5, n) * dy
+    for a in ("ux", "uy", "uz"):
+        getattr(p, a)[:] = rng.normal(size=n) * u_scale
+    p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+    p.w[:] = rng.uniform(0.5, 1.5, n) * 1e27 * dx * dy / 10
+    p.is_dead[rng.random(n) < 0.03] = True
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    return f, p, dt
+
+
+def _copy_case(f, p):
+    import copy
+    return copy.deepcopy(f), copy.deepcopy(p)
+
+
+@pytest.mark.parametrize("tiled,u_scale", [(False, 1.0), (True, 1.0), (True, 0.05)])
+def test_fused_2d_vs_oracle_multi_tile(tiled, u_scale):
+    """80x48 cells (5x3 tiles), 200k particles incl. relativistic ones: every tile edge, the torus
+    wrap at the patch edge, dead slots."""
+    f, p, dt = _random_case(80, 48, 200_000, 11, u_scale)
+    fo, po = _copy_case(f, p)
+    oracle.unified_boris_pusher_cpu_2d([po], [fo], 1, dt, QE, ME)
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, dt, QE, ME, tiled=tiled)
+    for a in ["x", "y", "ux", "uy", "uz", "inv_gamma"]:
+        assert_close(getattr(p, a), getattr(po, a), 1e-12, what=a)
+    live = ~p.is_dead
+    for a in PEB:
+        assert_close(getattr(p, a)[live], getattr(po, a)[live], 1e-11, what=a)
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
+
+
+def test_dead_particle_invariance():
+    """reference tests/core/pusher/test_unified_pusher_2d.py:159-208: a dead particle changes
+    nothing (2-particle run == 1-particle run at rtol 1e-10)"""
+    dx = dy = 1e-8
+    def run(n, dead):
+        f = Fields2D(16, 16, dx, dy, 0.0, 0.0, 3)
+        f.ez[...] = 1e10
+        f.bz[...] = 3.0
+        p = ParticlesBase(0, 0)
+        p.initialize(n)
+        p.x[:] = 5.3 * dx
+        p.y[:] = 7.1 * dy
+        p.ux[:] = 0.1
+        p.inv_gamma[:] = 1 / np.sqrt(1.01)
+        p.w[:] = 1e27 * dx * dy / 10
+        if dead:
+            p.is_dead[1] = True
+        kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME)
+        return f, p
+    f1, p1 = run(1, False)
+    f2, p2 = run(2, True)
+    for a in ["rho", "jx", "jy", "jz"]:
+        np.testing.assert_allclose(getattr(f2, a), getattr(f1, a), rtol=1e-10, atol=0)
+    assert p2.x[1] == 5.3 * dx and p2.ux[1] == 0.1          # untouched
+    np.testing.assert_allclose(p2.x[0], p1.x[0], rtol=1e-15)
+
+
+def test_known_answer_charge_and_current():
+    """reference tests/core/current/test_current_deposition.py:328-369: sum rho = q n,
+    sum J = q n v for a single particle (1e-10 rel)"""
+    dx = dy = 1e-8
+    f = Fields2D(16, 16, dx, dy, 0.0, 0.0, 3)
+    p = ParticlesBase(0, 0)
+    p.initialize(1)
+    p.x[:], p.y[:] = 6.3 * dx, 9.8 * dy
+    p.ux[:], p.uy[:], p.uz[:] = 0.3, -0.2, 0.1
+    p.inv_gamma[:] = 1 / np.sqrt(1 + 0.09 + 0.04 + 0.01)
+    p.w[:] = 1e27 * dx * dy / 10
+    dt = 1e-17
+    kernels.current_deposition_cpu_2d([f], [p], 1, dt, QE)
+    n = p.w[0] / (dx * dy)
+    v = np.array([0.3, -0.2, 0.1]) * p.inv_gamma[0] * C
+    assert f.rho.sum() == pytest.approx(QE * n, rel=1e-10)
+    assert f.jx.sum() == pytest.approx(QE * n * v[0], rel=1e-10)
+    assert f.jy.sum() == pytest.approx(QE * n * v[1], rel=1e-10)
+    assert f.jz.sum() == pytest.approx(QE * n * v[2], rel=1e-10)
+
+
+def test_boundary_wrap_deposits_through_the_torus():
+    """reference tests/core/pusher/test_unified_pusher_2d.py:218-252: particle at the patch corner
+    moving out with u = (-1,-1) deposits through the wrap; compare with the oracle cell by cell"""
+    dx = dy = 1e-8
+    def mk():
+        f = Fields2D(8, 8, dx, dy, 0.0, 0.0, 3)
+        f.ez[...] = 1e10
+        f.bx[...], f.by[...], f.bz[...] = 1.0, 2.0, 3.0
+        p = ParticlesBase(0, 0)
+        p.initialize(1)
+        p.x[:], p.y[:] = 0.1 * dx, 0.1 * dy
+        p.ux[:], p.uy[:] = -1.0, -1.0
+        p.inv_gamma[:] = 1 / np.sqrt(3.0)
+        p.w[:] = 1e27 * dx * dy / 10
+        return f, p
+    f, p = mk()
+    fo, po = mk()
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME)
+    oracle.unified_boris_pusher_cpu_2d([po], [fo], 1, 1e-17, QE, ME)
+    assert f.rho.sum() != 0.0
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
+    assert_close(p.x, po.x, 1e-13)
+
+
+def test_empty_and_all_dead_inputs():
+    dx = dy = 1e-8
+    f = Fields2D(8, 8, dx, dy, 0.0, 0.0, 3)
+    p = ParticlesBase(0, 0)
+    p.initialize(0)
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME)           # no particles
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 0, 1e-17, QE, ME)           # npatches <= 0
+    p.initialize(5)
+    p.is_dead[:] = True
+    for tiled in (False, True):
+        kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME, tiled=tiled)
+    assert not f.rho.any() and not f.jx.any()
+
+
+def test_split_kernels_vs_oracle():
+    """the non-fused path: push_position, interpolate, boris, push_position, deposit"""
+    f, p, dt = _random_case(32, 32, 20_000, 5, 0.5)
+    fo, po = _copy_case(f, p)
+    kernels.push_position_2d(p, 0.5 * dt)
+    oracle.push_position_2d(po, 0.5 * dt)
+    assert_close(p.x, po.x, 1e-15)
+    kernels.interpolation_patches_2d([p], [f], 1)
+    oracle.interpolation_patches_2d([po], [fo], 1)
+    live = ~p.is_dead
+    for a in PEB:
+        assert_close(getattr(p, a)[live], getattr(po, a)[live], 1e-11, what=a)
+    kernels.boris_push(p, QE, ME, dt)
+    oracle.boris_push(po, QE, ME, dt)
+    for a in ["ux", "uy", "uz", "inv_gamma"]:
+        assert_close(getattr(p, a), getattr(po, a), 1e-12, what=a)
+    kernels.current_deposition_cpu_2d([f], [p], 1, dt, QE)
+    oracle.current_deposition_cpu_2d([fo], [po], 1, dt, QE)
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
+    kernels.reset_current_cpu_2d([f], 1)
+    assert not f.jx.any() and not f.rho.any()
