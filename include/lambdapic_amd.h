@@ -192,6 +192,10 @@ int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_
 int lpa_diag_fields(const lpa_grid *g, double eps0, double mu0, double *out, void *stream);
 int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stream);
 
+/* ---- self test of the wave-level reduce-scatter used by the tiled deposit: in[64][64] doubles
+ *      (value index, lane) -> out[lane] = sum over lanes of in[lane][.]; one wave. */
+int lpa_selftest_wave_reduce(const double *in, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

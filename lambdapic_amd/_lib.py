@@ -78,6 +78,7 @@ SIGNATURES = {
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
+    "lpa_selftest_wave_reduce": (_i, [_vp, _vp, _vp]),
 }
 
 _LIB = None

@@ -198,6 +198,53 @@ __device__ __forceinline__ void esirkepov_2d(const AxisW &ax, const AxisW &ay, d
     }
 }
 
+// ---- wave-level reduce-scatter of 64 FP64 values across the 64 lanes of a wave -----------------------
+// Every lane contributes v[0..63]; afterwards lane L holds sum over lanes of v[L].  Six butterfly
+// stages, each halving the number of live values: lane-xor 32 and 16 with the CDNA4 half-wave / row
+// swap instructions (v_permlane32_swap / v_permlane16_swap: one instruction exchanges the halves of
+// two registers), lane-xor 8, 7, 2, 1 with DPP moves (row_ror:8, row_half_mirror, quad_perm).  Pure
+// VALU: nothing goes through the LDS crossbar, which is the unit this reduction is meant to unload.
+typedef unsigned lpa_u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wr_red32(double a, double b) {  // lanes <32 keep a, lanes >=32 keep b
+    lpa_u2 l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    lpa_u2 h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+}
+
+__device__ __forceinline__ double wr_red16(double a, double b) {  // even 16-lane rows keep a, odd keep b
+    lpa_u2 l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    lpa_u2 h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double wr_dpp(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// lanes with bit BIT clear keep a, the others keep b; the partner (CTRL) supplies its copy of the kept one
+template <int CTRL, int BIT>
+__device__ __forceinline__ double wr_redd(double a, double b, int lane) {
+    bool up = (lane >> BIT) & 1;
+    double keep = up ? b : a, send = up ? a : b;
+    return keep + wr_dpp<CTRL>(send);
+}
+
+// last four stages: 16 values (index c = bits 3..0) -> this lane's value (c == lane & 15)
+__device__ __forceinline__ double wr_finish16(const double s16[16], int lane) {
+    double s8[8], s4[4], s2[2];
+#pragma unroll
+    for (int c = 0; c < 8; c++) s8[c] = wr_redd<0x128, 3>(s16[c], s16[c + 8], lane);  // row_ror:8
+#pragma unroll
+    for (int c = 0; c < 4; c++) s4[c] = wr_redd<0x141, 2>(s8[c], s8[c + 4], lane);    // row_half_mirror
+#pragma unroll
+    for (int c = 0; c < 2; c++) s2[c] = wr_redd<0x4E, 1>(s4[c], s4[c + 2], lane);     // quad_perm 2,3,0,1
+    return wr_redd<0xB1, 0>(s2[0], s2[1], lane);                                      // quad_perm 1,0,3,2
+}
+
 // block-wide sum of `v` into *out with one atomic per block (blockDim.x multiple of 64, <= 1024)
 __device__ __forceinline__ void block_atomic_sum(double v, double *out) {
     __shared__ double red[16];

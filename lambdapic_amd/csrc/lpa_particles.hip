@@ -162,6 +162,11 @@ __device__ __forceinline__ double gather9_l(const double *f, int lx, int ly, con
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// minimum number of lanes sharing one deposit window for the wave reduction to pay; smaller groups go
+// straight to LDS atomics
+constexpr int WR_MIN_GROUP = 12;
+constexpr int WR_MAX_ROUNDS = 2;
+
 template <bool WRITE_EB>
 __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
@@ -177,6 +182,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
     const int tx0 = (tile / tiles_y) * TILE, ty0 = (tile % tiles_y) * TILE;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
+    const int lane = threadIdx.x & 63;
 
     // ---- stage E/B (nodes outside the padded array are never touched by a fast-path particle)
     {
@@ -195,65 +201,128 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
     __syncthreads();
 
     const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy;
-    for (int ip = begin + threadIdx.x; ip < end; ip += blockDim.x) {
-        double x = p.x[ip], y = p.y[ip];
-        if (isnan(x) || isnan(y)) continue;  // killed since the last sort (migration)
-        // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
-        int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
-        if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TILE + LPA_TILE_MARGIN ||
-            js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TILE + LPA_TILE_MARGIN) {
-            uint32_t slot = atomicAdd(overflow_count, 1u);
-            overflow[slot] = (uint32_t)ip;
-            continue;
+    // wave-uniform trip count: every lane of a wave runs the same iterations (the deposit below uses
+    // wave-wide DPP / permlane operations)
+    for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
+        const int ip = it + lane;
+        bool valid = ip < end;
+        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 0.0, ig = 1.0, w = 0.0;
+        if (valid) {
+            x = p.x[ip];
+            y = p.y[ip];
+            valid = !(isnan(x) || isnan(y));  // killed since the last sort (migration)
         }
-        double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig = p.ig[ip], w = p.w[ip];
-        x += k.cdt_half * ig * ux;
-        y += k.cdt_half * ig * uy;
-        double eb[6];
-        {
-            double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy;
-            int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo), iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
-            double gx[3], hx[3], gy[3], hy[3];
-            tsc3(ix1 - xo, gx);
-            tsc3(ix2 - xo + 0.5, hx);
-            tsc3(iy1 - yo, gy);
-            tsc3(iy2 - yo + 0.5, hy);
-            int lx1 = clampi(ix1 - rx0, 1, RW - 2), lx2 = clampi(ix2 - rx0, 1, RW - 2);
-            int ly1 = clampi(iy1 - ry0, 1, RW - 2), ly2 = clampi(iy2 - ry0, 1, RW - 2);
-            eb[0] = gather9_l(s_eb[0], lx2, ly1, hx, gy);
-            eb[1] = gather9_l(s_eb[1], lx1, ly2, gx, hy);
-            eb[2] = gather9_l(s_eb[2], lx1, ly1, gx, gy);
-            eb[3] = gather9_l(s_eb[3], lx1, ly2, gx, hy);
-            eb[4] = gather9_l(s_eb[4], lx2, ly1, hx, gy);
-            eb[5] = gather9_l(s_eb[5], lx2, ly2, hx, hy);
+        if (valid) {
+            // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
+            int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
+            if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TILE + LPA_TILE_MARGIN ||
+                js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TILE + LPA_TILE_MARGIN) {
+                uint32_t slot = atomicAdd(overflow_count, 1u);
+                overflow[slot] = (uint32_t)ip;
+                valid = false;
+            }
         }
-        if (WRITE_EB) {
+        AxisW ax, ay;
+        double vz = 0.0;
+        int b0 = 0;
+        if (valid) {
+            ux = p.ux[ip]; uy = p.uy[ip]; uz = p.uz[ip]; ig = p.ig[ip]; w = p.w[ip];
+            x += k.cdt_half * ig * ux;
+            y += k.cdt_half * ig * uy;
+            double eb[6];
+            {
+                double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy;
+                int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo), iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
+                double gx[3], hx[3], gy[3], hy[3];
+                tsc3(ix1 - xo, gx);
+                tsc3(ix2 - xo + 0.5, hx);
+                tsc3(iy1 - yo, gy);
+                tsc3(iy2 - yo + 0.5, hy);
+                int lx1 = clampi(ix1 - rx0, 1, RW - 2), lx2 = clampi(ix2 - rx0, 1, RW - 2);
+                int ly1 = clampi(iy1 - ry0, 1, RW - 2), ly2 = clampi(iy2 - ry0, 1, RW - 2);
+                eb[0] = gather9_l(s_eb[0], lx2, ly1, hx, gy);
+                eb[1] = gather9_l(s_eb[1], lx1, ly2, gx, hy);
+                eb[2] = gather9_l(s_eb[2], lx1, ly1, gx, gy);
+                eb[3] = gather9_l(s_eb[3], lx1, ly2, gx, hy);
+                eb[4] = gather9_l(s_eb[4], lx2, ly1, hx, gy);
+                eb[5] = gather9_l(s_eb[5], lx2, ly2, hx, hy);
+            }
+            if (WRITE_EB) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
-        }
-        boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
-        x += k.cdt_half * ig * ux;
-        y += k.cdt_half * ig * uy;
-        {
-            double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
-            AxisW ax, ay;
+                for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+            }
+            boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
+            x += k.cdt_half * ig * ux;
+            y += k.cdt_half * ig * uy;
+            double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig;
+            vz = uz * LPA_C * ig;
             axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, g.dx);
             axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, g.dy);
             int bx = clampi(ax.base - rx0, 0, RW - 4), by = clampi(ay.base - ry0, 0, RW - 4);
-            int b0 = bx * RS + by;
-            esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
-                               [&](int kk, int ll, double djx, double djy, double djz, double drho) {
-                                   int o = b0 + kk * RS + ll;
-                                   atomicAdd(&s_j[0][o], djx);
-                                   atomicAdd(&s_j[1][o], djy);
-                                   atomicAdd(&s_j[2][o], djz);
-                                   atomicAdd(&s_j[3][o], drho);
-                               });
+            b0 = bx * RS + by;
+            double xs = x, ys = y;
+            if (k.wrap & 1) xs = fold_coord(x, k.lo[0], k.hi[0]);
+            if (k.wrap & 2) ys = fold_coord(y, k.lo[1], k.hi[1]);
+            p.x[ip] = xs; p.y[ip] = ys;
+            p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                ax.S0[c] = ax.S1[c] = ax.DS[c] = 0.0;
+                ay.S0[c] = ay.S1[c] = ay.DS[c] = 0.0;
+            }
+            ax.base = ay.base = 0;
+            ax.tail_zero = ay.tail_zero = false;
         }
-        if (k.wrap & 1) x = fold_coord(x, k.lo[0], k.hi[0]);
-        if (k.wrap & 2) y = fold_coord(y, k.lo[1], k.hi[1]);
-        p.x[ip] = x; p.y[ip] = y;
-        p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+
+        // ---- deposit.  Particles are cell sorted, so most lanes of the wave share one 4x4 window:
+        // those are summed across the wave in registers (reduce-scatter: lane L ends with the total
+        // of window value L = quantity*16 + kx*4 + ly) and leave ONE ds_add_f64 per lane, all to
+        // different addresses.  Lanes with another window (cell-crossers, wave straddling two cells)
+        // form a second group or fall back to per-lane LDS atomics.
+        unsigned long long todo = __ballot(valid);
+        int round = 0;
+        while (todo) {  // wave-uniform
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lb = __builtin_amdgcn_readlane(b0, leader);
+            const bool mine = ((todo >> lane) & 1ull) != 0;
+            const unsigned long long grp = __ballot(mine && b0 == lb);
+            if (__popcll(grp) >= WR_MIN_GROUP && round < WR_MAX_ROUNDS) {
+                const bool ing = (grp >> lane) & 1ull;
+                double s16[16];
+                esirkepov_2d<true>(ax, ay, vz, ing ? w : 0.0, k.q, g.dx, g.dy, k.dt,
+                                   [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                       double r0 = wr_red32(djx, djz);   // lanes <32: jx, >=32: jz
+                                       double r1 = wr_red32(djy, drho);  // lanes <32: jy, >=32: rho
+                                       s16[kk * 4 + ll] = wr_red16(r0, r1);  // rows: jx jy jz rho
+                                       __builtin_amdgcn_sched_barrier(0);    // bound live registers
+                                   });
+                double tot = wr_finish16(s16, lane);
+                if (tot != 0.0) atomicAdd(&s_j[lane >> 4][lb + ((lane >> 2) & 3) * RS + (lane & 3)], tot);
+                todo &= ~grp;
+                round++;
+            } else {
+                if (mine) {
+                    // opaque copies: keeps the compiler from sharing sub-expressions between this
+                    // cold path and the reduction above (that sharing cost 120 extra VGPRs)
+                    AxisW cx = ax, cy = ay;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        asm volatile("" : "+v"(cx.S0[c]), "+v"(cx.S1[c]), "+v"(cx.DS[c]));
+                        asm volatile("" : "+v"(cy.S0[c]), "+v"(cy.S1[c]), "+v"(cy.DS[c]));
+                    }
+                    esirkepov_2d<true>(cx, cy, vz, w, k.q, g.dx, g.dy, k.dt,
+                                       [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                           int o = b0 + kk * RS + ll;
+                                           if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
+                                           if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
+                                           if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
+                                           if (drho != 0.0) atomicAdd(&s_j[3][o], drho);
+                                       });
+                }
+                todo = 0;
+            }
+        }
     }
     __syncthreads();
 
@@ -273,6 +342,26 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             }
         }
     }
+}
+
+// self-test of the wave reduce-scatter: in[64][64] (value, lane) -> out[lane] = sum over lanes of in[lane][.]
+__global__ void __launch_bounds__(64) k_selftest_wave_reduce(const double *in, double *out) {
+    int lane = threadIdx.x;
+    double s16[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        double r0 = wr_red32(in[(0 * 16 + c) * 64 + lane], in[(2 * 16 + c) * 64 + lane]);
+        double r1 = wr_red32(in[(1 * 16 + c) * 64 + lane], in[(3 * 16 + c) * 64 + lane]);
+        s16[c] = wr_red16(r0, r1);
+    }
+    out[lane] = wr_finish16(s16, lane);
+}
+
+extern "C" int lpa_selftest_wave_reduce(const double *in, double *out, void *stream) {
+    LPA_REQUIRE(in && out, "lpa_selftest_wave_reduce: bad args");
+    hipLaunchKernelGGL(k_selftest_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    LPA_CHECK_LAUNCH("lpa_selftest_wave_reduce");
+    return LPA_OK;
 }
 
 // =====================================================================================================

@@ -1,23 +1,26 @@
-// lpa_sort.hip -- cell-index sort (tile binning) and slab migration of particles.
+// lpa_sort.hip -- cell-index sort and slab migration of particles.
 //
 // The reference sorts every species every step by x-cell buckets in place and keeps dead particles
 // inside the arrays (core/sort/cpu2d.c:9-54,108-189; policy core/sort/particle_sort.py:196-211).  The
 // permutation inside a bucket is implementation defined there; what the rest of the step relies on is
-// only locality.  On the GPU the sort exists to make the LDS-tiled kernel possible:
-//   1. k_tile_count   : tile id of every live particle (16x16 cells, nearest-node cells) + its rank
-//                       inside the tile through wave-aggregated atomics (one atomic per distinct tile
-//                       per wave instruction);
-//   2. k_tile_scan    : one workgroup: exclusive scan of the tile counts, the per-tile interleave
-//                       multiplier and the work-block table of the tiled kernel;
-//   3. k_tile_scatter : out-of-place copy of every attribute to slot
-//                       tile_off + (rank * minv) mod n_tile.
-// The multiplicative permutation makes slot s hold rank (s * G) mod n with G ~ n / golden ratio: 64
-// consecutive slots (= one wave of the tiled kernel) hold ranks spread >= ~n/170 apart, i.e. particles
-// of different cells, so the wave's LDS atomics do not pile up on one address.  Dead / NaN particles
-// are dropped (compaction) -- they are the reference's recycled "dead slots".
+// only locality.  On the GPU the sort is what makes the LDS-tiled kernel possible and fast:
+//   key = tile-major cell index: (tile_x * tiles_y + tile_y) * 256 + (cell_x_in_tile * 16 + cell_y_in_tile)
+//   with 16x16-cell tiles and nearest-node cells, so that
+//     * a tile's particles are one contiguous range (one LDS staging of E/B/J per work block), and
+//     * the 64 lanes of a wave hold particles of the SAME cell (their deposit windows coincide and are
+//       summed in registers before touching LDS; their gather reads are LDS broadcasts).
+// Counting sort, out of place, stable up to atomic arrival order:
+//   1. k_cell_count   : key + rank of every live particle (wave-aggregated atomics: one atomic per
+//                       distinct cell per wave instruction for already-sorted input);
+//   2. k_tile_sum / k_tile_scan / k_cell_scan : exclusive scan of the 256 counters of every tile, of
+//                       the tile totals, and the work-block table of the tiled kernel;
+//   3. k_cell_scatter : copy of every attribute to slot cell_off[key] + rank (contiguous per cell, so
+//                       for nearly sorted input both the reads and the writes are coalesced).
+// Dead / NaN particles are dropped (compaction) -- they are the reference's recycled "dead slots".
 #include "lpa_common.hpp"
 
 constexpr int TILE = LPA_TILE;
+constexpr int TCELLS = TILE * TILE;
 
 struct SortHdr {      // first 64 bytes of the workspace
     int32_t n_live;   // live particles after the sort
@@ -27,8 +30,8 @@ struct SortHdr {      // first 64 bytes of the workspace
 
 struct SortWs {
     SortHdr *hdr;
-    int32_t *tile_cnt, *tile_off, *blk_tile, *blk_begin, *blk_end;
-    uint32_t *tile_minv, *key, *rank;
+    int32_t *cell_cnt, *cell_off, *tile_cnt, *tile_off, *blk_tile, *blk_begin, *blk_end;
+    uint32_t *key, *rank;
     int ntiles, max_blocks;
 };
 
@@ -42,9 +45,10 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return base ? base + o : nullptr; };
     char *p;
     p = take(sizeof(SortHdr)); if (w) w->hdr = (SortHdr *)p;
+    p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_cnt = (int32_t *)p;
+    p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_off = (int32_t *)p;
     p = take(sizeof(int32_t) * nt); if (w) w->tile_cnt = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off = (int32_t *)p;
-    p = take(sizeof(uint32_t) * nt); if (w) w->tile_minv = (uint32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_tile = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_begin = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_end = (int32_t *)p;
@@ -66,12 +70,12 @@ extern "C" const int32_t *lpa_sort_live_count(void *workspace) {
 
 constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;
 
-__global__ void __launch_bounds__(256) k_tile_count(PartV p, double x0, double y0, double inv_dx,
+__global__ void __launch_bounds__(256) k_cell_count(PartV p, double x0, double y0, double inv_dx,
                                                     double inv_dy, int nx, int ny, int tiles_y,
-                                                    int32_t *tile_cnt, uint32_t *key, uint32_t *rank) {
+                                                    int32_t *cell_cnt, uint32_t *key, uint32_t *rank) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = false;
-    uint32_t tile = KEY_DEAD;
+    uint32_t ck = KEY_DEAD;
     if (ip < p.n) {
         double x = p.x[ip], y = p.y[ip];
         live = !((p.dead && p.dead[ip]) || isnan(x) || isnan(y));
@@ -81,51 +85,48 @@ __global__ void __launch_bounds__(256) k_tile_count(PartV p, double x0, double y
             int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5);
             is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
             js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
-            tile = (uint32_t)((is / TILE) * tiles_y + js / TILE);
+            int tile = (is / TILE) * tiles_y + js / TILE;
+            ck = (uint32_t)(tile * TCELLS + (is % TILE) * TILE + (js % TILE));
         }
     }
-    // wave-aggregated rank assignment: lanes that share a tile elect a leader that reserves the
-    // whole group with one atomic
+    // wave-aggregated rank assignment: lanes that share a cell elect a leader that reserves the whole
+    // group with one atomic.  Sorted input needs 1-3 rounds; after 4 rounds (unsorted input) the
+    // remaining lanes reserve their slots individually.
     uint32_t r = 0;
     unsigned long long todo = __ballot(live);
-    int lane = threadIdx.x & 63;
-    while (todo) {
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; round < 4 && todo; round++) {
         int leader = __ffsll((long long)todo) - 1;
-        uint32_t lt = __shfl(tile, leader, 64);
-        unsigned long long grp = __ballot(live && tile == lt) & todo;
+        uint32_t lk = __shfl(ck, leader, 64);
+        unsigned long long grp = __ballot(live && ck == lk) & todo;
         uint32_t base = 0;
-        if (lane == leader) base = (uint32_t)atomicAdd(&tile_cnt[lt], (int32_t)__popcll(grp));
+        if (lane == leader) base = (uint32_t)atomicAdd(&cell_cnt[lk], (int32_t)__popcll(grp));
         base = __shfl(base, leader, 64);
         if ((grp >> lane) & 1ull) r = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
         todo &= ~grp;
     }
+    if ((todo >> lane) & 1ull) r = (uint32_t)atomicAdd(&cell_cnt[ck], 1);
     if (ip < p.n) {
-        key[ip] = tile;
+        key[ip] = ck;
         rank[ip] = r;
     }
 }
 
-__device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
-    while (b) { uint32_t t = a % b; a = b; b = t; }
-    return a;
+// one workgroup per tile: total of its 256 cell counters
+__global__ void __launch_bounds__(256) k_tile_sum(const int32_t *__restrict__ cell_cnt, int32_t *tile_cnt) {
+    __shared__ int32_t red[4];
+    int v = cell_cnt[(long)blockIdx.x * TCELLS + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// modular inverse of a modulo n (gcd(a, n) == 1, n >= 2) by the extended Euclid recursion
-__device__ __forceinline__ uint32_t modinv_u32(uint32_t a, uint32_t n) {
-    long long t = 0, nt = 1, r = n, nr = a;
-    while (nr) {
-        long long qq = r / nr;
-        long long tmp = t - qq * nt; t = nt; nt = tmp;
-        tmp = r - qq * nr; r = nr; nr = tmp;
-    }
-    if (t < 0) t += n;
-    return (uint32_t)t;
-}
-
+// one workgroup: exclusive scan of the tile totals + the work-block table
 __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *tile_cnt, int32_t *tile_off,
-                                                    uint32_t *tile_minv, int32_t *blk_tile,
-                                                    int32_t *blk_begin, int32_t *blk_end, SortHdr *hdr,
-                                                    int block_particles, int max_blocks) {
+                                                    int32_t *blk_tile, int32_t *blk_begin, int32_t *blk_end,
+                                                    SortHdr *hdr, int block_particles, int max_blocks) {
     __shared__ int32_t s_part[1024], s_blk[1024];
     int tid = threadIdx.x;
     int per = (ntiles + 1023) / 1024;
@@ -151,18 +152,11 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
     for (int t = lo; t < hi; t++) {
         int32_t c = tile_cnt[t];
         tile_off[t] = off;
-        uint32_t minv = 1;
-        if (c >= 3) {
-            uint32_t G = (uint32_t)((double)c * 0.6180339887498949);
-            if (G < 1) G = 1;
-            while (gcd_u32(G, (uint32_t)c) != 1) G++;
-            minv = modinv_u32(G % (uint32_t)c, (uint32_t)c);
-        }
-        tile_minv[t] = minv;
         int nb = (c + block_particles - 1) / block_particles;
         for (int b = 0; b < nb && boff + b < max_blocks; b++) {
-            // equal split of the tile's particles over its blocks
-            long s0 = (long)c * b / nb, s1 = (long)c * (b + 1) / nb;
+            // equal split of the tile's particles over its blocks, on 64-particle boundaries so that
+            // a wave never straddles two work blocks
+            long s0 = ((long)c * b / nb) & ~63l, s1 = b + 1 == nb ? c : (((long)c * (b + 1) / nb) & ~63l);
             blk_tile[boff + b] = t;
             blk_begin[boff + b] = off + (int32_t)s0;
             blk_end[boff + b] = off + (int32_t)s1;
@@ -177,18 +171,33 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
     }
 }
 
-__global__ void __launch_bounds__(256) k_tile_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
+// one workgroup per tile: exclusive scan of its 256 cell counters, offset by the tile's start
+__global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ cell_cnt,
+                                                   const int32_t *__restrict__ tile_off, int32_t *cell_off) {
+    __shared__ int32_t wsum[4];
+    int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int c = cell_cnt[(long)blockIdx.x * TCELLS + tid];
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = tile_off[blockIdx.x];
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    cell_off[(long)blockIdx.x * TCELLS + tid] = base + inc - c;
+}
+
+__global__ void __launch_bounds__(256) k_cell_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
                                                       const uint32_t *__restrict__ rank,
-                                                      const int32_t *__restrict__ tile_off,
-                                                      const int32_t *__restrict__ tile_cnt,
-                                                      const uint32_t *__restrict__ tile_minv) {
+                                                      const int32_t *__restrict__ cell_off) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
-    uint32_t t = key[ip];
-    if (t == KEY_DEAD) return;
-    uint32_t n = (uint32_t)tile_cnt[t];
-    unsigned long long slot = ((unsigned long long)rank[ip] * tile_minv[t]) % n;
-    long o = (long)tile_off[t] + (long)slot;
+    uint32_t ck = key[ip];
+    if (ck == KEY_DEAD) return;
+    long o = (long)cell_off[ck] + rank[ip];
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
     d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
@@ -219,26 +228,28 @@ extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, co
     }
     hipStream_t st = (hipStream_t)stream;
     int tiles_x = (g->nx + TILE - 1) / TILE, tiles_y = (g->ny + TILE - 1) / TILE;
-    if (hipMemsetAsync(w.tile_cnt, 0, sizeof(int32_t) * w.ntiles, st) != hipSuccess) {
+    if (hipMemsetAsync(w.cell_cnt, 0, sizeof(int32_t) * (size_t)w.ntiles * TCELLS, st) != hipSuccess) {
         lpa_set_error("lpa_sort_tiles_2d: memset failed");
         return LPA_ERR_HIP;
     }
     PartV sv = make_partv(src), dv = make_partv(dst);
     if (src->n > 0) {
         unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_tile_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
-                           1.0 / g->dy, g->nx, g->ny, tiles_y, w.tile_cnt, w.key, w.rank);
-        LPA_CHECK_LAUNCH("k_tile_count");
+        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
+                           1.0 / g->dy, g->nx, g->ny, tiles_y, w.cell_cnt, w.key, w.rank);
+        LPA_CHECK_LAUNCH("k_cell_count");
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off,
-                       w.tile_minv, w.blk_tile, w.blk_begin, w.blk_end, w.hdr, (int)block_particles,
-                       w.max_blocks);
+    hipLaunchKernelGGL(k_tile_sum, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_cnt);
+    LPA_CHECK_LAUNCH("k_tile_sum");
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off, w.blk_tile,
+                       w.blk_begin, w.blk_end, w.hdr, (int)block_particles, w.max_blocks);
     LPA_CHECK_LAUNCH("k_tile_scan");
+    hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
+    LPA_CHECK_LAUNCH("k_cell_scan");
     if (src->n > 0) {
         unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_tile_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
-                           w.tile_cnt, w.tile_minv);
-        LPA_CHECK_LAUNCH("k_tile_scatter");
+        hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.cell_off);
+        LPA_CHECK_LAUNCH("k_cell_scatter");
     }
     out->tiles_x = tiles_x;
     out->tiles_y = tiles_y;

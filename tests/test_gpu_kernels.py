@@ -245,3 +245,65 @@ def test_split_kernels_vs_oracle():
         assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
     kernels.reset_current_cpu_2d([f], 1)
     assert not f.jx.any() and not f.rho.any()
+
+
+def test_wave_reduce_scatter_selftest():
+    """the DPP / permlane reduce-scatter used by the tiled deposit: lane L must end with the sum
+    over lanes of value L (all 64 x 64 inputs distinct)"""
+    import ctypes as C
+    import torch
+    from lambdapic_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(64, 64))
+    d_in = torch.from_numpy(a).cuda()
+    d_out = torch.zeros(64, dtype=torch.float64, device="cuda")
+    _lib.check(L.lpa_selftest_wave_reduce(d_in.data_ptr(), d_out.data_ptr(), None), "selftest")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d_out.cpu().numpy(), a.sum(axis=1), rtol=1e-13, atol=1e-13)
+
+
+def test_cell_sort_properties():
+    """reference tests/test_sort.py:38-117,201-251 restated for the device sort: per-cell counts
+    equal a numpy histogram, output keys are non-decreasing (tile-major cell order), the multiset
+    of live particles is preserved, dead / NaN particles are dropped, a second sort is a no-op
+    on the keys."""
+    import torch
+    from lambdapic_amd.engine import PicEngine2D
+    rng = np.random.default_rng(9)
+    nx, ny, dx, dy = 40, 24, 4e-8, 5e-8      # 3 x 2 tiles, ragged edges
+    n = 30_000
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx
+    p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    p.ux[:] = rng.normal(size=n)
+    p.w[:] = rng.uniform(1, 2, n)
+    p.is_dead[rng.random(n) < 0.1] = True
+    p.x[7] = np.nan
+    live = ~p.is_dead & ~np.isnan(p.x)
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024)
+    eng.add_species(QE, ME, capacity=n + 64)
+    eng.species[0].upload([p])
+    assert eng.species[0].n == live.sum()
+    eng.sort(0)
+    out = eng.species[0].download()
+    assert out["x"].size == live.sum()
+
+    def keys(x, y):
+        i = np.clip(np.floor(x / dx + 0.5).astype(int), 0, nx - 1)
+        j = np.clip(np.floor(y / dy + 0.5).astype(int), 0, ny - 1)
+        tiles_y = (ny + 15) // 16
+        return ((i // 16) * tiles_y + j // 16) * 256 + (i % 16) * 16 + (j % 16)
+
+    k_out = keys(out["x"], out["y"])
+    assert np.all(np.diff(k_out) >= 0)
+    assert np.array_equal(np.bincount(k_out), np.bincount(keys(p.x[live], p.y[live])))
+    order_in = np.argsort(p.id[live])
+    order_out = np.argsort(out["_id"].view(np.uint64))
+    assert np.array_equal(p.id[live][order_in], out["_id"].view(np.uint64)[order_out])
+    for a in ("x", "y", "ux", "w"):
+        assert np.array_equal(getattr(p, a)[live][order_in], out[a][order_out])
+    eng.sort(0)
+    out2 = eng.species[0].download()
+    assert np.array_equal(keys(out2["x"], out2["y"]), k_out)
