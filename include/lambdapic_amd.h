@@ -62,9 +62,10 @@ typedef struct {
 /* Tile binning of a particle store (product of lpa_sort_tiles_2d, consumed by
  * lpa_push_deposit_tiled_2d).  All pointers are device memory inside the sort workspace. */
 typedef struct {
-    int32_t tiles_x, tiles_y;  /* tile grid; tile = LPA_TILE x LPA_TILE cells                    */
+    int32_t tiles_x, tiles_y;  /* tile grid; tile = LPA_TILE_X x LPA_TILE_Y cells                */
     int64_t n_sorted;          /* particles [0, n_sorted) are tile ordered; the rest are "loose" */
     int32_t max_blocks;        /* launch bound for the tiled kernel                              */
+    int32_t order;             /* LPA_ORDER_* the store was sorted into                          */
     const int32_t *tile_off;   /* [ntiles+1] first particle of each tile                         */
     const int32_t *blk_tile;   /* [max_blocks] tile of each work block                           */
     const int32_t *blk_begin;  /* [max_blocks] first particle of each work block                 */
@@ -72,8 +73,18 @@ typedef struct {
     const int32_t *n_blocks;   /* [1] number of valid work blocks                                */
 } lpa_tiling;
 
-#define LPA_TILE 16        /* cells per tile edge                                               */
+#define LPA_TILE_X 8       /* cells per tile along x                                            */
+#define LPA_TILE_Y 32      /* cells per tile along y (the fastest axis): one half-wave = one row */
 #define LPA_TILE_MARGIN 1  /* cells a particle may sit outside its tile and stay on the LDS path */
+/* order of the particles inside a tile:
+ *   CELL_MAJOR : all particles of cell 0, then of cell 1, ... -- the lanes of a wave share a cell;
+ *                the tiled kernel sums their deposit windows across the wave in registers
+ *                (permlane-swap / DPP reduce-scatter) and issues one LDS atomic per lane.
+ *   STRIPED    : the r-th particle of every cell, for r = 0, 1, ... (cells y-fastest) -- the lanes
+ *                of a half-wave sit in 32 consecutive y-cells, so their LDS gather reads and LDS
+ *                atomics fall on 32 different bank pairs (conflict free). */
+#define LPA_ORDER_CELL_MAJOR 0
+#define LPA_ORDER_STRIPED 1
 
 const char *lpa_last_error(void);
 int lpa_version(void);
@@ -153,14 +164,14 @@ int lpa_deposit_2d(const lpa_grid *g, const lpa_particles *p, double dt, double 
 
 /* ---- cell-index sort (replaces sort_particles_patches_2d, core/sort/cpu2d.c:220-303, as driven
  *      by ParticleSort2D.__call__, core/sort/particle_sort.py:196-211).  Out of place: `src` is
- *      binned by LPA_TILE x LPA_TILE cell tiles into `dst` (same capacity), dead / NaN particles
- *      are dropped (they sort behind every live particle in the reference and are recycled by
- *      sync_particles); within a tile the order is deliberately cell-interleaved.  The number
- *      of live particles is written to the workspace header and returned through lpa_tiling. */
+ *      binned by LPA_TILE_X x LPA_TILE_Y cell tiles into `dst` (same capacity), dead / NaN
+ *      particles are dropped (they sort behind every live particle in the reference and are
+ *      recycled by sync_particles); the order inside a tile is `order` (LPA_ORDER_*).  The number
+ *      of live particles is written to the workspace header (lpa_sort_live_count). */
 int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
-                      lpa_tiling *out, void *stream);
+                      int32_t order, lpa_tiling *out, void *stream);
 /* number of live particles after the last sort (device pointer inside the workspace) */
 const int32_t *lpa_sort_live_count(void *workspace);
 

@@ -11,7 +11,10 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "liblambdapic_amd.so"
 
-LPA_TILE = 16
+LPA_TILE_X = 8
+LPA_TILE_Y = 32
+LPA_ORDER_CELL_MAJOR = 0
+LPA_ORDER_STRIPED = 1
 LPA_TILE_MARGIN = 1
 LPA_MIG_NATTR = 9
 
@@ -35,7 +38,7 @@ class lpa_particles(C.Structure):
 
 class lpa_tiling(C.Structure):
     _fields_ = [("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("n_sorted", C.c_int64),
-                ("max_blocks", C.c_int32),
+                ("max_blocks", C.c_int32), ("order", C.c_int32),
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p)]
 
@@ -72,7 +75,7 @@ SIGNATURES = {
     "lpa_push_position_2d": (_i, [_P, _d, _vp]),
     "lpa_deposit_2d": (_i, [_G, _P, _d, _d, _vp]),
     "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),
-    "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, _T, _vp]),
+    "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),

@@ -4,12 +4,14 @@
 //  K1-global  any particle order; gathers E/B from global memory (L1/L2) and deposits with FP64
 //             global atomics on the torus.  Correct for every input; used for loose particles, for
 //             the overflow list of the tiled kernel and as the drop-in for unsorted patch arrays.
-//  K1-tiled   particles binned by 16x16-cell tiles (lpa_sort.hip).  One workgroup per work block of
-//             a tile: the tile's E/B (+4-cell halo) are staged once in LDS, particles stream through
+//  K1-tiled   particles binned by 8x32-cell tiles (lpa_sort.hip).  One workgroup per work block of
+//             a tile: the tile's E/B (+4-node halo) are staged once in LDS, particles stream through
 //             in SoA order (fully coalesced 512-B wave loads), J/rho accumulate in an LDS tile with
-//             ds_add_f64 and are flushed with one global atomic per touched cell.  Lanes of a wave
-//             hold particles of different cells (cell-interleaved tile order), so the LDS atomics of
-//             one wave instruction hit different addresses.
+//             ds_add_f64 and are flushed with one global atomic per touched cell.  Two deposit forms,
+//             chosen by the order the sort produced (LPA_ORDER_*): STRIPED stores put the lanes of a
+//             half-wave in consecutive y-cells (conflict-free LDS atomics and gather reads);
+//             CELL_MAJOR stores put a wave in one cell and sum the deposit windows across the wave in
+//             registers (permlane-swap / DPP reduce-scatter) before one LDS atomic per lane.
 //
 // Restates unified_boris_pusher_cpu_2d (core/pusher/unified/unified_pusher_2d.c:157-365).
 #include "lpa_common.hpp"
@@ -144,11 +146,12 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_2d(GridV g, PartV p, 
 // =====================================================================================================
 // K1-tiled
 // =====================================================================================================
-constexpr int TILE = LPA_TILE;            // 16 cells
-constexpr int HALO = LPA_TILE_MARGIN + 3; // margin + (1 cell of motion + 2 cells of stencil), see DESIGN.md
-constexpr int RW = TILE + 2 * HALO;       // 24: edge of the staged region in nodes
-constexpr int RS = RW + 1;                // LDS row stride in doubles (odd: spreads rows over banks)
-constexpr int RSZ = RW * RS;
+constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;  // 8 x 32 cells
+constexpr int HALO = LPA_TILE_MARGIN + 3;  // margin + (1 cell of motion + 2 cells of stencil), see DESIGN.md
+constexpr int RWX = TX + 2 * HALO;         // 16: staged region, nodes along x
+constexpr int RWY = TY + 2 * HALO;         // 40: staged region, nodes along y
+constexpr int RS = RWY + 1;                // LDS row stride in doubles
+constexpr int RSZ = RWX * RS;
 
 // gather from the LDS copy; (lx, ly) = local index of the stencil centre, guaranteed inside by the
 // margin test (and clamped against non-finite input)
@@ -167,7 +170,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 constexpr int WR_MIN_GROUP = 12;
 constexpr int WR_MAX_ROUNDS = 2;
 
-template <bool WRITE_EB>
+template <bool WRITE_EB, bool WAVE_REDUCE>
 __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
@@ -180,15 +183,15 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
-    const int tx0 = (tile / tiles_y) * TILE, ty0 = (tile % tiles_y) * TILE;  // first node of the tile
+    const int tx0 = (tile / tiles_y) * TX, ty0 = (tile % tiles_y) * TY;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
 
     // ---- stage E/B (nodes outside the padded array are never touched by a fast-path particle)
     {
         const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
-        for (int t = threadIdx.x; t < RW * RW; t += blockDim.x) {
-            int lx = t / RW, ly = t - lx * RW;
+        for (int t = threadIdx.x; t < RWX * RWY; t += blockDim.x) {
+            int lx = t / RWY, ly = t - lx * RWY;
             int cx = rx0 + lx + g.ng, cy = ry0 + ly + g.ng;
             bool in = (unsigned)cx < (unsigned)g.NX && (unsigned)cy < (unsigned)g.NY;
             long gi = (long)cx * g.NY + cy;
@@ -215,8 +218,8 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
         if (valid) {
             // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
             int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
-            if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TILE + LPA_TILE_MARGIN ||
-                js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TILE + LPA_TILE_MARGIN) {
+            if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TX + LPA_TILE_MARGIN ||
+                js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TY + LPA_TILE_MARGIN) {
                 uint32_t slot = atomicAdd(overflow_count, 1u);
                 overflow[slot] = (uint32_t)ip;
                 valid = false;
@@ -238,8 +241,8 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
                 tsc3(ix2 - xo + 0.5, hx);
                 tsc3(iy1 - yo, gy);
                 tsc3(iy2 - yo + 0.5, hy);
-                int lx1 = clampi(ix1 - rx0, 1, RW - 2), lx2 = clampi(ix2 - rx0, 1, RW - 2);
-                int ly1 = clampi(iy1 - ry0, 1, RW - 2), ly2 = clampi(iy2 - ry0, 1, RW - 2);
+                int lx1 = clampi(ix1 - rx0, 1, RWX - 2), lx2 = clampi(ix2 - rx0, 1, RWX - 2);
+                int ly1 = clampi(iy1 - ry0, 1, RWY - 2), ly2 = clampi(iy2 - ry0, 1, RWY - 2);
                 eb[0] = gather9_l(s_eb[0], lx2, ly1, hx, gy);
                 eb[1] = gather9_l(s_eb[1], lx1, ly2, gx, hy);
                 eb[2] = gather9_l(s_eb[2], lx1, ly1, gx, gy);
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             vz = uz * LPA_C * ig;
             axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, g.dx);
             axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, g.dy);
-            int bx = clampi(ax.base - rx0, 0, RW - 4), by = clampi(ay.base - ry0, 0, RW - 4);
+            int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
             b0 = bx * RS + by;
             double xs = x, ys = y;
             if (k.wrap & 1) xs = fold_coord(x, k.lo[0], k.hi[0]);
@@ -275,6 +278,22 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             ax.tail_zero = ay.tail_zero = false;
         }
 
+        if (!WAVE_REDUCE) {
+            // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
+            // ds_add_f64 below hits 32 different bank pairs.  Exact zeros (the window cells a particle
+            // that does not change cell never reaches) are skipped.
+            if (valid) {
+                esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
+                                   [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                       int o = b0 + kk * RS + ll;
+                                       if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
+                                       if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
+                                       if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
+                                       if (drho != 0.0) atomicAdd(&s_j[3][o], drho);
+                                   });
+            }
+            continue;
+        }
         // ---- deposit.  Particles are cell sorted, so most lanes of the wave share one 4x4 window:
         // those are summed across the wave in registers (reduce-scatter: lane L ends with the total
         // of window value L = quantity*16 + kx*4 + ly) and leave ONE ds_add_f64 per lane, all to
@@ -330,8 +349,8 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
     //      threads walk consecutive y -> each wave instruction covers contiguous 8-B segments of a row
     {
         double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
-        for (int t = threadIdx.x; t < RW * RW; t += blockDim.x) {
-            int lx = t / RW, ly = t - lx * RW;
+        for (int t = threadIdx.x; t < RWX * RWY; t += blockDim.x) {
+            int lx = t / RWY, ly = t - lx * RWY;
             int cx = rx0 + lx + g.ng, cy = ry0 + ly + g.ng;
             if ((unsigned)cx >= (unsigned)g.NX || (unsigned)cy >= (unsigned)g.NY) continue;
             long gi = (long)cx * g.NY + cy;
@@ -408,7 +427,7 @@ extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles 
     LPA_REQUIRE(t && t->blk_tile && t->blk_begin && t->blk_end && t->n_blocks && t->max_blocks > 0 &&
                     overflow && overflow_count,
                 "lpa_push_deposit_tiled_2d: bad tiling");
-    LPA_REQUIRE(t->tiles_x == (g->nx + TILE - 1) / TILE && t->tiles_y == (g->ny + TILE - 1) / TILE,
+    LPA_REQUIRE(t->tiles_x == (g->nx + TX - 1) / TX && t->tiles_y == (g->ny + TY - 1) / TY,
                 "lpa_push_deposit_tiled_2d: tiling does not match the grid");
     LPA_REQUIRE(p->is_dead == nullptr,
                 "lpa_push_deposit_tiled_2d: tile-binned stores carry no is_dead array (dead = NaN x)");
@@ -419,14 +438,17 @@ extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles 
     GridV gv = make_gridv(g, 2);
     PartV pv = make_partv(p);
     PushK k = make_pushk(pp);
-    if (p->part_eb[0])
-        hipLaunchKernelGGL(k_push_deposit_tiled_2d<true>, dim3(t->max_blocks), dim3(256), 0,
-                           (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
-                           t->n_blocks, t->tiles_y, overflow, overflow_count);
-    else
-        hipLaunchKernelGGL(k_push_deposit_tiled_2d<false>, dim3(t->max_blocks), dim3(256), 0,
-                           (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
-                           t->n_blocks, t->tiles_y, overflow, overflow_count);
+    // CELL_MAJOR stores use the wave reduce-scatter deposit, STRIPED stores the conflict-free atomics
+    const bool eb = p->part_eb[0] != nullptr, wr = t->order == LPA_ORDER_CELL_MAJOR;
+#define LPA_LAUNCH_TILED(E, W)                                                                          \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W>), dim3(t->max_blocks), dim3(256), 0,             \
+                       (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
+                       t->tiles_y, overflow, overflow_count)
+    if (eb && wr) LPA_LAUNCH_TILED(true, true);
+    else if (eb) LPA_LAUNCH_TILED(true, false);
+    else if (wr) LPA_LAUNCH_TILED(false, true);
+    else LPA_LAUNCH_TILED(false, false);
+#undef LPA_LAUNCH_TILED
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_2d");
     return LPA_OK;
 }

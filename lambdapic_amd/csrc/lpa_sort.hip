@@ -4,23 +4,31 @@
 // inside the arrays (core/sort/cpu2d.c:9-54,108-189; policy core/sort/particle_sort.py:196-211).  The
 // permutation inside a bucket is implementation defined there; what the rest of the step relies on is
 // only locality.  On the GPU the sort is what makes the LDS-tiled kernel possible and fast:
-//   key = tile-major cell index: (tile_x * tiles_y + tile_y) * 256 + (cell_x_in_tile * 16 + cell_y_in_tile)
-//   with 16x16-cell tiles and nearest-node cells, so that
-//     * a tile's particles are one contiguous range (one LDS staging of E/B/J per work block), and
-//     * the 64 lanes of a wave hold particles of the SAME cell (their deposit windows coincide and are
-//       summed in registers before touching LDS; their gather reads are LDS broadcasts).
-// Counting sort, out of place, stable up to atomic arrival order:
-//   1. k_cell_count   : key + rank of every live particle (wave-aggregated atomics: one atomic per
-//                       distinct cell per wave instruction for already-sorted input);
-//   2. k_tile_sum / k_tile_scan / k_cell_scan : exclusive scan of the 256 counters of every tile, of
-//                       the tile totals, and the work-block table of the tiled kernel;
-//   3. k_cell_scatter : copy of every attribute to slot cell_off[key] + rank (contiguous per cell, so
-//                       for nearly sorted input both the reads and the writes are coalesced).
+//   key = (tile_x * tiles_y + tile_y) * 256 + (cell_x_in_tile * 32 + cell_y_in_tile)
+//   with 8 x 32-cell tiles (y is the fastest grid axis) and nearest-node cells, so that a tile's
+//   particles are one contiguous range (one LDS staging of E/B/J per work block).
+// Inside a tile two orders are produced (LPA_ORDER_*):
+//   CELL_MAJOR: cell by cell.  The 64 lanes of a wave share a cell: identical deposit windows, summed
+//               across the wave in registers before touching LDS.
+//   STRIPED   : rank by rank -- first the 0-th particle of every cell (cells in index order, y
+//               fastest), then the 1-st of every cell that has one, ...  A half-wave (32 lanes) then
+//               sits in 32 consecutive y-cells of one grid row: its LDS gather reads and its LDS
+//               atomics go to 32 consecutive doubles = 32 different bank pairs, conflict free.
+// Counting sort, out of place:
+//   1. k_cell_count   : key + rank-in-cell of every live particle (atomics on the cell counters,
+//                       wave-aggregated when lanes share a cell);
+//   2. k_tile_sum / k_tile_scan : tile totals, their exclusive scan, the work-block table;
+//   3a. CELL_MAJOR: k_cell_scan (per-tile scan of the 256 counters) + k_cell_scatter;
+//   3b. STRIPED   : k_stripe_table (per tile and rank r < 128: 256-bit mask of the cells that have an
+//                   r-th particle + running total) + k_stripe_scatter
+//                   (slot = tile_off + total[r] + popcount(mask[r] below the cell)).
 // Dead / NaN particles are dropped (compaction) -- they are the reference's recycled "dead slots".
 #include "lpa_common.hpp"
 
-constexpr int TILE = LPA_TILE;
-constexpr int TCELLS = TILE * TILE;
+constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;
+constexpr int TCELLS = TX * TY;  // 256
+constexpr int RMAX = 128;        // ranks that are striped; deeper particles follow cell by cell
+static_assert(TCELLS == 256, "one workgroup thread per tile cell");
 
 struct SortHdr {      // first 64 bytes of the workspace
     int32_t n_live;   // live particles after the sort
@@ -30,7 +38,8 @@ struct SortHdr {      // first 64 bytes of the workspace
 
 struct SortWs {
     SortHdr *hdr;
-    int32_t *cell_cnt, *cell_off, *tile_cnt, *tile_off, *blk_tile, *blk_begin, *blk_end;
+    int32_t *cell_cnt, *cell_off, *tile_cnt, *tile_off, *blk_tile, *blk_begin, *blk_end, *apre;
+    unsigned long long *masks;
     uint32_t *key, *rank;
     int ntiles, max_blocks;
 };
@@ -38,7 +47,7 @@ struct SortWs {
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
-    int tx = (g->nx + TILE - 1) / TILE, ty = (g->ny + TILE - 1) / TILE;
+    int tx = (g->nx + TX - 1) / TX, ty = (g->ny + TY - 1) / TY;
     int nt = tx * ty;
     int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1;
     size_t off = 0;
@@ -52,6 +61,8 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_tile = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_begin = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_end = (int32_t *)p;
+    p = take(sizeof(unsigned long long) * (size_t)nt * RMAX * 4); if (w) w->masks = (unsigned long long *)p;
+    p = take(sizeof(int32_t) * (size_t)nt * (RMAX + 1)); if (w) w->apre = (int32_t *)p;
     p = take(sizeof(uint32_t) * cap); if (w) w->key = (uint32_t *)p;
     p = take(sizeof(uint32_t) * cap); if (w) w->rank = (uint32_t *)p;
     if (w) { w->ntiles = nt; w->max_blocks = (int)maxb; }
@@ -85,13 +96,13 @@ __global__ void __launch_bounds__(256) k_cell_count(PartV p, double x0, double y
             int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5);
             is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
             js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
-            int tile = (is / TILE) * tiles_y + js / TILE;
-            ck = (uint32_t)(tile * TCELLS + (is % TILE) * TILE + (js % TILE));
+            int tile = (is / TX) * tiles_y + js / TY;
+            ck = (uint32_t)(tile * TCELLS + (is % TX) * TY + (js % TY));
         }
     }
-    // wave-aggregated rank assignment: lanes that share a cell elect a leader that reserves the whole
-    // group with one atomic.  Sorted input needs 1-3 rounds; after 4 rounds (unsorted input) the
-    // remaining lanes reserve their slots individually.
+    // rank inside the cell.  Lanes that share a cell elect a leader that reserves the whole group
+    // with one atomic (cell-major input: 1-3 rounds); after 4 rounds (striped or unsorted input:
+    // every lane in a different cell) the remaining lanes reserve their slots individually.
     uint32_t r = 0;
     unsigned long long todo = __ballot(live);
     const int lane = threadIdx.x & 63;
@@ -154,8 +165,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
         tile_off[t] = off;
         int nb = (c + block_particles - 1) / block_particles;
         for (int b = 0; b < nb && boff + b < max_blocks; b++) {
-            // equal split of the tile's particles over its blocks, on 64-particle boundaries so that
-            // a wave never straddles two work blocks
+            // equal split of the tile's particles over its blocks, on 64-particle boundaries
             long s0 = ((long)c * b / nb) & ~63l, s1 = b + 1 == nb ? c : (((long)c * (b + 1) / nb) & ~63l);
             blk_tile[boff + b] = t;
             blk_begin[boff + b] = off + (int32_t)s0;
@@ -171,33 +181,89 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
     }
 }
 
-// one workgroup per tile: exclusive scan of its 256 cell counters, offset by the tile's start
-__global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ cell_cnt,
-                                                   const int32_t *__restrict__ tile_off, int32_t *cell_off) {
+// exclusive scan of 256 per-thread values inside one workgroup; returns the prefix, *total gets the sum
+__device__ __forceinline__ int block_excl_scan256(int c, int *total) {
     __shared__ int32_t wsum[4];
     int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int c = cell_cnt[(long)blockIdx.x * TCELLS + tid];
     int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         int t = __shfl_up(inc, o, 64);
         if (lane >= o) inc += t;
     }
+    __syncthreads();
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    int base = tile_off[blockIdx.x];
+    int base = 0;
     for (int w = 0; w < wv; w++) base += wsum[w];
-    cell_off[(long)blockIdx.x * TCELLS + tid] = base + inc - c;
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - c;
 }
 
-__global__ void __launch_bounds__(256) k_cell_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
-                                                      const uint32_t *__restrict__ rank,
-                                                      const int32_t *__restrict__ cell_off) {
+// CELL_MAJOR: one workgroup per tile: exclusive scan of its 256 cell counters, offset by the tile's start
+__global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ cell_cnt,
+                                                   const int32_t *__restrict__ tile_off, int32_t *cell_off) {
+    int c = cell_cnt[(long)blockIdx.x * TCELLS + threadIdx.x];
+    int ex = block_excl_scan256(c, nullptr);
+    cell_off[(long)blockIdx.x * TCELLS + threadIdx.x] = tile_off[blockIdx.x] + ex;
+}
+
+// STRIPED: one workgroup per tile, thread c = cell c.  For every rank r < RMAX: the 256-bit mask of the
+// cells with more than r particles and the number of striped slots before rank r; cells deeper than
+// RMAX keep their surplus cell by cell behind the striped part (cell_off = offset of that surplus
+// relative to the tile start).
+__global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict__ cell_cnt,
+                                                      unsigned long long *masks, int32_t *apre,
+                                                      int32_t *cell_off) {
+    __shared__ unsigned long long s_mask[4];
+    const int c = threadIdx.x, lane = c & 63, wv = c >> 6;
+    const long t = blockIdx.x;
+    const int n = cell_cnt[t * TCELLS + c];
+    int run = 0;
+    for (int r = 0; r < RMAX; r++) {
+        unsigned long long m = __ballot(n > r);
+        if (lane == 0) s_mask[wv] = m;
+        __syncthreads();
+        unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
+        if (c < 4) masks[(t * RMAX + r) * 4 + c] = s_mask[c];
+        if (c == 0) apre[t * (RMAX + 1) + r] = run;
+        run += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        __syncthreads();
+        if (!(m0 | m1 | m2 | m3)) break;  // block-uniform: no cell is this deep; later rows are never read
+    }
+    if (c == 0) apre[t * (RMAX + 1) + RMAX] = run;
+    int extra = n > RMAX ? n - RMAX : 0;
+    int ex = block_excl_scan256(extra, nullptr);
+    cell_off[t * TCELLS + c] = run + ex;
+}
+
+__global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
+                                                 const uint32_t *__restrict__ rank,
+                                                 const int32_t *__restrict__ tile_off,
+                                                 const int32_t *__restrict__ cell_off,
+                                                 const unsigned long long *__restrict__ masks,
+                                                 const int32_t *__restrict__ apre, int striped) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
     uint32_t ck = key[ip];
     if (ck == KEY_DEAD) return;
-    long o = (long)cell_off[ck] + rank[ip];
+    uint32_t r = rank[ip];
+    long o;
+    if (!striped) {
+        o = (long)cell_off[ck] + r;
+    } else {
+        long t = ck >> 8;
+        int c = ck & 255;
+        if (r < RMAX) {
+            const unsigned long long *m = masks + (t * RMAX + r) * 4;
+            int w = c >> 6, b = c & 63, below = 0;
+            for (int q = 0; q < w; q++) below += __popcll(m[q]);
+            below += __popcll(m[w] & ((1ull << b) - 1ull));
+            o = (long)tile_off[t] + apre[t * (RMAX + 1) + r] + below;
+        } else {
+            o = (long)tile_off[t] + cell_off[ck] + (r - RMAX);
+        }
+    }
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
     d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
@@ -211,10 +277,11 @@ __global__ void __launch_bounds__(256) k_cell_scatter(PartV s, PartV d, const ui
 
 extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                                  void *workspace, int64_t workspace_bytes, int32_t block_particles,
-                                 lpa_tiling *out, void *stream) {
+                                 int32_t order, lpa_tiling *out, void *stream) {
     LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0, "lpa_sort_tiles_2d: bad grid");
     LPA_REQUIRE(lpa_part_ok(src, 2) && lpa_part_ok(dst, 2) && workspace && out,
                 "lpa_sort_tiles_2d: bad particle stores / workspace");
+    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED, "lpa_sort_tiles_2d: bad order");
     LPA_REQUIRE(src->n < (1ll << 31) - 1, "lpa_sort_tiles_2d: more than 2^31 particles in one store");
     LPA_REQUIRE(dst->n >= src->n, "lpa_sort_tiles_2d: dst capacity (dst->n) smaller than src->n");
     LPA_REQUIRE(block_particles >= 1024, "lpa_sort_tiles_2d: block_particles must be >= 1024");
@@ -227,7 +294,7 @@ extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, co
         return LPA_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int tiles_x = (g->nx + TILE - 1) / TILE, tiles_y = (g->ny + TILE - 1) / TILE;
+    int tiles_x = (g->nx + TX - 1) / TX, tiles_y = (g->ny + TY - 1) / TY;
     if (hipMemsetAsync(w.cell_cnt, 0, sizeof(int32_t) * (size_t)w.ntiles * TCELLS, st) != hipSuccess) {
         lpa_set_error("lpa_sort_tiles_2d: memset failed");
         return LPA_ERR_HIP;
@@ -244,17 +311,23 @@ extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, co
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off, w.blk_tile,
                        w.blk_begin, w.blk_end, w.hdr, (int)block_particles, w.max_blocks);
     LPA_CHECK_LAUNCH("k_tile_scan");
-    hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
-    LPA_CHECK_LAUNCH("k_cell_scan");
+    if (order == LPA_ORDER_STRIPED)
+        hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre,
+                           w.cell_off);
+    else
+        hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
+    LPA_CHECK_LAUNCH("k_cell_scan / k_stripe_table");
     if (src->n > 0) {
         unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.cell_off);
-        LPA_CHECK_LAUNCH("k_cell_scatter");
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
+                           w.cell_off, w.masks, w.apre, (int)(order == LPA_ORDER_STRIPED));
+        LPA_CHECK_LAUNCH("k_scatter");
     }
     out->tiles_x = tiles_x;
     out->tiles_y = tiles_y;
     out->n_sorted = src->n;  // upper bound known on the host; the exact count is hdr->n_live
     out->max_blocks = w.max_blocks;
+    out->order = order;
     out->tile_off = w.tile_off;
     out->blk_tile = w.blk_tile;
     out->blk_begin = w.blk_begin;

@@ -32,7 +32,7 @@ from .dist import SlabComm
 class PicEngine2D:
     def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
                  x0=0.0, y0=0.0, sort_interval=8, block_particles=8192, migrate_capacity=32768,
-                 periodic_x=True, periodic_y=True):
+                 periodic_x=True, periodic_y=True, order=_lib.LPA_ORDER_STRIPED):
         """``nx`` is the LOCAL number of cells along x (this rank's slab); the global box has
         ``nx * comm.size`` cells and this slab starts at ``x0 + rank*nx*dx``."""
         self.L = lib()
@@ -51,6 +51,7 @@ class PicEngine2D:
         self.sort_interval = int(sort_interval)
         self.block_particles = int(block_particles)
         self.migrate_capacity = int(migrate_capacity)
+        self.order = int(order)   # LPA_ORDER_STRIPED (conflict-free LDS atomics) or LPA_ORDER_CELL_MAJOR
         # axes handled by local periodic wrap: y always; x only when this rank owns the whole box
         self.local_axes = 2 | (1 if self.comm.size == 1 else 0)
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
@@ -144,8 +145,8 @@ class PicEngine2D:
         src, dst = sp.cset, sp.other()
         ps, pd = src.cstruct(sp.n), dst.cstruct(dst.capacity)
         check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), self.block_particles, C.byref(ws["tiling"]),
-                                       self.stream), "lpa_sort_tiles_2d")
+                                       ws["sort"].numel(), self.block_particles, self.order,
+                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
         hdr = ws["sort"][:8].view(torch.int32)
         n_live = int(hdr[0].item())                      # sync point (once per sort_interval steps)
         arrivals = int(ws["counters"][1].item())

@@ -98,11 +98,12 @@ def _push_params(dt, q, m):
     return pp
 
 
-def unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m, tiled=False):
+def unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m, tiled=False,
+                                order=_lib.LPA_ORDER_STRIPED):
     """GPU drop-in for `core/pusher/unified/unified_pusher_2d.c:157-365`
     (``unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m) -> None``).
-    ``tiled=True`` runs the LDS-tiled kernel (tile sort + tiled + overflow list) instead of the
-    global-atomics kernel; results agree to summation order."""
+    ``tiled=True`` runs the LDS-tiled kernel (cell sort into ``order`` + tiled + overflow list)
+    instead of the global-atomics kernel; results agree to summation order."""
     L, dev = lib(), _device()
     if npatches <= 0:
         return None
@@ -115,13 +116,13 @@ def unified_boris_pusher_cpu_2d(particles_list, fields_list, npatches, dt, q, m,
                   "lpa_push_deposit_2d")
             d.download(list(PART_CORE[:6]) + list(PART_EB))
         else:
-            _unified_tiled_patch(L, dev, g, p, pp)
+            _unified_tiled_patch(L, dev, g, p, pp, order=order)
         g.download(["rho", "jx", "jy", "jz"])
     torch.cuda.synchronize(dev)
     return None
 
 
-def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024):
+def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024, order=_lib.LPA_ORDER_STRIPED):
     """tile-bin the live particles of one host bag, run the tiled kernel + overflow list, and
     scatter the results back to the host slots (the original slot travels in the id field)."""
     n = p.npart
@@ -153,7 +154,7 @@ def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024):
     tiling = _lib.lpa_tiling()
     st = _stream(dev)
     check(L.lpa_sort_tiles_2d(g.ref(), C.byref(ps), C.byref(pd), ws.data_ptr(), nbytes, block_particles,
-                              C.byref(tiling), st), "lpa_sort_tiles_2d")
+                              order, C.byref(tiling), st), "lpa_sort_tiles_2d")
     n_live = int(ws[:4].view(torch.int32)[0].item())
     assert n_live == nl
     tiling.n_sorted = nl

@@ -28,8 +28,8 @@ def _engine_from_patches(P, nx, ny, dx, dy, q, m, **kw):
     return eng
 
 
-@pytest.mark.parametrize("tiled,sort_interval", [(False, 8), (True, 1), (True, 7)])
-def test_g8_trace(golden, tiled, sort_interval):
+@pytest.mark.parametrize("tiled,sort_interval,order", [(False, 8, 1), (True, 1, 1), (True, 7, 1), (True, 5, 0)])
+def test_g8_trace(golden, tiled, sort_interval, order):
     g = golden("g8_trace_2d")
     nx, ny, dx, dy = int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"])
     P = make_patches_2d(nx, ny, dx, dy, int(g["npx"]), int(g["npy"]))
@@ -39,7 +39,7 @@ def test_g8_trace(golden, tiled, sort_interval):
         for a in ["x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id"]:
             getattr(q, a)[:] = g[f"in{k}_{a}"]
     eng = _engine_from_patches(P, nx, ny, dx, dy, float(g["q"]), float(g["m"]),
-                               sort_interval=sort_interval, block_particles=1024)
+                               sort_interval=sort_interval, block_particles=1024, order=order)
     dt = float(g["dt"])
     fe, ke, ch, na = [], [], [], []
     for _ in range(int(g["nsteps"])):

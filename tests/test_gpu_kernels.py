@@ -24,11 +24,15 @@ C = 299792458.0
 QE, ME = -1.602176634e-19, 9.1093837139e-31
 
 
-def _cmp_fused_2d(g, k, tiled):
+STRIPED, CELL_MAJOR = 1, 0   # LPA_ORDER_*
+MODES = [(False, STRIPED), (True, STRIPED), (True, CELL_MAJOR)]   # global atomics / tiled x 2 orders
+
+
+def _cmp_fused_2d(g, k, tiled, order):
     f = fields2d_from(g, f"in{k}_", g[f"x0_{k}"], g[f"y0_{k}"])
     p = particles_from(g, f"in{k}_")
     kernels.unified_boris_pusher_cpu_2d([p], [f], 1, float(g["dt"]), float(g["q"]), float(g["m"]),
-                                        tiled=tiled)
+                                        tiled=tiled, order=order)
     for a in ["x", "y", "ux", "uy", "uz", "inv_gamma"]:
         assert_close(getattr(p, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
     alive = ~(p.is_dead | np.isnan(g[f"in{k}_x"]) | np.isnan(g[f"in{k}_y"]))
@@ -38,11 +42,11 @@ def _cmp_fused_2d(g, k, tiled):
         assert_close(getattr(f, a), g[f"out{k}_{a}"], 1e-12, what=f"patch{k} {a}")
 
 
-@pytest.mark.parametrize("tiled", [False, True])
-def test_fused_2d_vs_golden(golden, tiled):
+@pytest.mark.parametrize("tiled,order", MODES)
+def test_fused_2d_vs_golden(golden, tiled, order):
     g = golden("g1_fused_2d")
     for k in range(int(g["npatches"])):
-        _cmp_fused_2d(g, k, tiled)
+        _cmp_fused_2d(g, k, tiled, order)
 
 
 def test_fused_3d_vs_golden(golden):
@@ -119,14 +123,15 @@ def _copy_case(f, p):
     return copy.deepcopy(f), copy.deepcopy(p)
 
 
-@pytest.mark.parametrize("tiled,u_scale", [(False, 1.0), (True, 1.0), (True, 0.05)])
-def test_fused_2d_vs_oracle_multi_tile(tiled, u_scale):
-    """80x48 cells (5x3 tiles), 200k particles incl. relativistic ones: every tile edge, the torus
-    wrap at the patch edge, dead slots."""
+@pytest.mark.parametrize("tiled,order,u_scale", [(False, STRIPED, 1.0), (True, STRIPED, 1.0), (True, STRIPED, 0.05),
+                                                 (True, CELL_MAJOR, 1.0), (True, CELL_MAJOR, 0.05)])
+def test_fused_2d_vs_oracle_multi_tile(tiled, order, u_scale):
+    """80x48 cells (10x2 tiles, ragged in y), 200k particles incl. relativistic ones: every tile edge,
+    the torus wrap at the patch edge, dead slots."""
     f, p, dt = _random_case(80, 48, 200_000, 11, u_scale)
     fo, po = _copy_case(f, p)
     oracle.unified_boris_pusher_cpu_2d([po], [fo], 1, dt, QE, ME)
-    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, dt, QE, ME, tiled=tiled)
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, dt, QE, ME, tiled=tiled, order=order)
     for a in ["x", "y", "ux", "uy", "uz", "inv_gamma"]:
         assert_close(getattr(p, a), getattr(po, a), 1e-12, what=a)
     live = ~p.is_dead
@@ -218,8 +223,8 @@ def test_empty_and_all_dead_inputs():
     kernels.unified_boris_pusher_cpu_2d([p], [f], 0, 1e-17, QE, ME)           # npatches <= 0
     p.initialize(5)
     p.is_dead[:] = True
-    for tiled in (False, True):
-        kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME, tiled=tiled)
+    for tiled, order in MODES:
+        kernels.unified_boris_pusher_cpu_2d([p], [f], 1, 1e-17, QE, ME, tiled=tiled, order=order)
     assert not f.rho.any() and not f.jx.any()
 
 
@@ -263,42 +268,57 @@ def test_wave_reduce_scatter_selftest():
     np.testing.assert_allclose(d_out.cpu().numpy(), a.sum(axis=1), rtol=1e-13, atol=1e-13)
 
 
-def test_cell_sort_properties():
+@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR])
+def test_cell_sort_properties(order):
     """reference tests/test_sort.py:38-117,201-251 restated for the device sort: per-cell counts
-    equal a numpy histogram, output keys are non-decreasing (tile-major cell order), the multiset
-    of live particles is preserved, dead / NaN particles are dropped, a second sort is a no-op
-    on the keys."""
+    equal a numpy histogram, tiles are contiguous and in order, inside a tile the particles are cell
+    by cell (CELL_MAJOR) or rank by rank with cells ascending inside a rank (STRIPED), the multiset
+    of live particles is preserved, dead / NaN particles are dropped, re-sorting keeps the keys."""
     import torch
     from lambdapic_amd.engine import PicEngine2D
     rng = np.random.default_rng(9)
-    nx, ny, dx, dy = 40, 24, 4e-8, 5e-8      # 3 x 2 tiles, ragged edges
-    n = 30_000
+    nx, ny, dx, dy = 20, 72, 4e-8, 5e-8      # 3 x 3 tiles of 8 x 32 cells, ragged edges
+    n = 60_000
     p = ParticlesBase(0, 0)
     p.initialize(n)
     p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx
     p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    # a few very deep cells (> 128 particles) exercise the un-striped tail
+    p.x[:2000] = 3.2 * dx
+    p.y[:2000] = rng.choice([5.1, 6.0, 40.2], 2000) * dy
     p.ux[:] = rng.normal(size=n)
     p.w[:] = rng.uniform(1, 2, n)
     p.is_dead[rng.random(n) < 0.1] = True
     p.x[7] = np.nan
     live = ~p.is_dead & ~np.isnan(p.x)
-    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024)
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024, order=order)
     eng.add_species(QE, ME, capacity=n + 64)
     eng.species[0].upload([p])
     assert eng.species[0].n == live.sum()
     eng.sort(0)
     out = eng.species[0].download()
     assert out["x"].size == live.sum()
+    tiles_y = (ny + 31) // 32
 
     def keys(x, y):
         i = np.clip(np.floor(x / dx + 0.5).astype(int), 0, nx - 1)
         j = np.clip(np.floor(y / dy + 0.5).astype(int), 0, ny - 1)
-        tiles_y = (ny + 15) // 16
-        return ((i // 16) * tiles_y + j // 16) * 256 + (i % 16) * 16 + (j % 16)
+        return ((i // 8) * tiles_y + j // 32) * 256 + (i % 8) * 32 + (j % 32)
 
     k_out = keys(out["x"], out["y"])
-    assert np.all(np.diff(k_out) >= 0)
     assert np.array_equal(np.bincount(k_out), np.bincount(keys(p.x[live], p.y[live])))
+    tile = k_out >> 8
+    assert np.all(np.diff(tile) >= 0)
+    if order == CELL_MAJOR:
+        assert np.all(np.diff(k_out) >= 0)
+    else:
+        for t in np.unique(tile):
+            kt = k_out[tile == t] & 255
+            cnt = np.bincount(kt, minlength=256)
+            # expected sequence: for r < 128 the cells with count > r ascending, then the deep tails
+            exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), 128))]
+            exp += [np.repeat(c, cnt[c] - 128) for c in np.nonzero(cnt > 128)[0]]
+            assert np.array_equal(kt, np.concatenate(exp)), t
     order_in = np.argsort(p.id[live])
     order_out = np.argsort(out["_id"].view(np.uint64))
     assert np.array_equal(p.id[live][order_in], out["_id"].view(np.uint64)[order_out])
