@@ -150,8 +150,14 @@ constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;  // 8 x 32 cells
 constexpr int HALO = LPA_TILE_MARGIN + 3;  // margin + (1 cell of motion + 2 cells of stencil), see DESIGN.md
 constexpr int RWX = TX + 2 * HALO;         // 16: staged region, nodes along x
 constexpr int RWY = TY + 2 * HALO;         // 40: staged region, nodes along y
-constexpr int RS = RWY + 1;                // LDS row stride in doubles
+constexpr int RS = RWY + 1;                // LDS row stride of the E/B copies, in doubles
 constexpr int RSZ = RWX * RS;
+// LDS row stride of the J/rho accumulators: a multiple of 32 doubles, so that consecutive y-cells map to
+// consecutive bank pairs ACROSS a row wrap too -- a half-wave whose lanes run from the end of one grid
+// row into the start of the next still touches 32 different bank pairs.
+constexpr int RSJ = 64;
+constexpr int RSZJ = RWX * RSJ;
+constexpr int K1_THREADS = 512;
 
 // gather from the LDS copy; (lx, ly) = local index of the stencil centre, guaranteed inside by the
 // margin test (and clamped against non-finite input)
@@ -171,7 +177,7 @@ constexpr int WR_MIN_GROUP = 12;
 constexpr int WR_MAX_ROUNDS = 2;
 
 template <bool WRITE_EB, bool WAVE_REDUCE>
-__global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
+__global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
                                                               const int32_t *__restrict__ blk_end,
@@ -179,7 +185,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
                                                               int tiles_y, uint32_t *overflow,
                                                               uint32_t *overflow_count) {
     __shared__ double s_eb[6][RSZ];
-    __shared__ double s_j[4][RSZ];
+    __shared__ double s_j[4][RSZJ];
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
@@ -198,7 +204,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
 #pragma unroll
             for (int c = 0; c < 6; c++) s_eb[c][lx * RS + ly] = in ? src[c][gi] : 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_j[c][lx * RS + ly] = 0.0;
+            for (int c = 0; c < 4; c++) s_j[c][lx * RSJ + ly] = 0.0;
         }
     }
     __syncthreads();
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, g.dx);
             axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, g.dy);
             int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
-            b0 = bx * RS + by;
+            b0 = bx * RSJ + by;
             double xs = x, ys = y;
             if (k.wrap & 1) xs = fold_coord(x, k.lo[0], k.hi[0]);
             if (k.wrap & 2) ys = fold_coord(y, k.lo[1], k.hi[1]);
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             if (valid) {
                 esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                    [&](int kk, int ll, double djx, double djy, double djz, double drho) {
-                                       int o = b0 + kk * RS + ll;
+                                       int o = b0 + kk * RSJ + ll;
                                        if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
                                        if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
                                        if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
@@ -317,7 +323,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
                                        __builtin_amdgcn_sched_barrier(0);    // bound live registers
                                    });
                 double tot = wr_finish16(s16, lane);
-                if (tot != 0.0) atomicAdd(&s_j[lane >> 4][lb + ((lane >> 2) & 3) * RS + (lane & 3)], tot);
+                if (tot != 0.0) atomicAdd(&s_j[lane >> 4][lb + ((lane >> 2) & 3) * RSJ + (lane & 3)], tot);
                 todo &= ~grp;
                 round++;
             } else {
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
                     }
                     esirkepov_2d<true>(cx, cy, vz, w, k.q, g.dx, g.dy, k.dt,
                                        [&](int kk, int ll, double djx, double djy, double djz, double drho) {
-                                           int o = b0 + kk * RS + ll;
+                                           int o = b0 + kk * RSJ + ll;
                                            if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
                                            if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
                                            if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
@@ -356,7 +362,7 @@ __global__ void __launch_bounds__(256) k_push_deposit_tiled_2d(GridV g, PartV p,
             long gi = (long)cx * g.NY + cy;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                double v = s_j[c][lx * RS + ly];
+                double v = s_j[c][lx * RSJ + ly];
                 if (v != 0.0) atomicAdd(&dst[c][gi], v);
             }
         }
@@ -441,7 +447,7 @@ extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles 
     // CELL_MAJOR stores use the wave reduce-scatter deposit, STRIPED stores the conflict-free atomics
     const bool eb = p->part_eb[0] != nullptr, wr = t->order == LPA_ORDER_CELL_MAJOR;
 #define LPA_LAUNCH_TILED(E, W)                                                                          \
-    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W>), dim3(t->max_blocks), dim3(256), 0,             \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W>), dim3(t->max_blocks), dim3(K1_THREADS), 0,      \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
                        t->tiles_y, overflow, overflow_count)
     if (eb && wr) LPA_LAUNCH_TILED(true, true);
