@@ -15,8 +15,8 @@ import torch.distributed as dist
 
 
 class SlabComm:
-    def __init__(self, group=None, periodic=True):
-        if dist.is_available() and dist.is_initialized():
+    def __init__(self, group=None, periodic=True, single=False):
+        if not single and dist.is_available() and dist.is_initialized():
             self.group = group
             self.rank = dist.get_rank(group)
             self.size = dist.get_world_size(group)
@@ -32,21 +32,33 @@ class SlabComm:
         Posting order matters when left == right (two ranks): messages between one pair of ranks
         match in posting order, so the sends are posted (hi, lo) and the receives (lo, hi): the
         peer's first receive (its low face) takes my high face.
+
+        With the ``gloo`` backend (CPU rehearsal of the multi-rank path, or several ranks sharing
+        one GPU in a test) device tensors are staged through host memory.
         """
         if self.size == 1:
             recv_lo.copy_(send_hi)   # my own high edge is my low guard's periodic source
             recv_hi.copy_(send_lo)
             return []
+        staged = send_lo.is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:
+            s_lo, s_hi = send_lo.cpu(), send_hi.cpu()
+            r_lo, r_hi = torch.empty_like(s_lo), torch.empty_like(s_hi)
+        else:
+            s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
         ops = [
-            dist.P2POp(dist.isend, send_hi, self.right, self.group),
-            dist.P2POp(dist.isend, send_lo, self.left, self.group),
-            dist.P2POp(dist.irecv, recv_lo, self.left, self.group),
-            dist.P2POp(dist.irecv, recv_hi, self.right, self.group),
+            dist.P2POp(dist.isend, s_hi, self.right, self.group, tag=1),
+            dist.P2POp(dist.isend, s_lo, self.left, self.group, tag=0),
+            dist.P2POp(dist.irecv, r_lo, self.left, self.group, tag=1),
+            dist.P2POp(dist.irecv, r_hi, self.right, self.group, tag=0),
         ]
         reqs = dist.batch_isend_irecv(ops)
-        if wait:
+        if wait or staged:
             for r in reqs:
                 r.wait()
+            if staged:
+                recv_lo.copy_(r_lo)
+                recv_hi.copy_(r_hi)
         return reqs
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
@@ -58,3 +70,21 @@ class SlabComm:
     def barrier(self):
         if self.size > 1:
             dist.barrier(group=self.group)
+
+
+def exchange_faces(comm: SlabComm, pack, unpack, bufs):
+    """One nearest-neighbour halo step of the slab decomposition, shared by guard copies, current
+    folds and particle migration:
+
+        pack(side, buf)    fills ``buf`` with what leaves through face ``side`` (0 = low x, 1 = high x)
+        unpack(side, buf)  consumes what arrived through face ``side``
+
+    What leaves my low face arrives at the LEFT neighbour's high face and vice versa (the ring is
+    periodic, `core/patch/patch.py:446-507` neighbour tables for periodic x).  ``bufs`` is a dict
+    with tensors ``s_lo s_hi r_lo r_hi``.
+    """
+    pack(0, bufs["s_lo"])
+    pack(1, bufs["s_hi"])
+    comm.exchange(bufs["s_lo"], bufs["s_hi"], bufs["r_lo"], bufs["r_hi"])
+    unpack(0, bufs["r_lo"])
+    unpack(1, bufs["r_hi"])

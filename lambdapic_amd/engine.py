@@ -26,7 +26,7 @@ import torch
 from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr
-from .dist import SlabComm
+from .dist import SlabComm, exchange_faces
 
 
 class PicEngine2D:
@@ -95,15 +95,16 @@ class PicEngine2D:
         st = self.stream
         check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
         if self.comm.size > 1:
-            h = self._halo_bufs()
-            ncomp = 3 * bin(which).count("1")
-            n = ncomp * self.ng * self.grid.NY
+            n = 3 * bin(which).count("1") * self.ng * self.grid.NY
+            h = {k: v[:n] for k, v in self._halo_bufs().items()}
             # my low interior edge becomes the LEFT neighbour's high guard and vice versa
-            check(self.L.lpa_halo_pack_guard_src(self._g(), which, 0, h["s_lo"].data_ptr(), st), "pack lo")
-            check(self.L.lpa_halo_pack_guard_src(self._g(), which, 1, h["s_hi"].data_ptr(), st), "pack hi")
-            self.comm.exchange(h["s_lo"][:n], h["s_hi"][:n], h["r_lo"][:n], h["r_hi"][:n])
-            check(self.L.lpa_halo_unpack_guard(self._g(), which, 0, h["r_lo"].data_ptr(), st), "unpack lo")
-            check(self.L.lpa_halo_unpack_guard(self._g(), which, 1, h["r_hi"].data_ptr(), st), "unpack hi")
+            exchange_faces(
+                self.comm,
+                lambda side, b: check(self.L.lpa_halo_pack_guard_src(self._g(), which, side, b.data_ptr(), st),
+                                      "lpa_halo_pack_guard_src"),
+                lambda side, b: check(self.L.lpa_halo_unpack_guard(self._g(), which, side, b.data_ptr(), st),
+                                      "lpa_halo_unpack_guard"),
+                h)
 
     # ---- currents (CurrentDeposition2D.reset, Patches.sync_currents + MPIManager.sync_currents_*) --
     def reset_current(self):
@@ -112,14 +113,16 @@ class PicEngine2D:
     def sync_currents(self):
         st = self.stream
         if self.comm.size > 1:
-            h = self._halo_bufs()
             n = 4 * self.ng * self.grid.NY
+            h = {k: v[:n] for k, v in self._halo_bufs().items()}
             # my low GUARD planes are added to the LEFT neighbour's high interior edge
-            check(self.L.lpa_halo_pack_current(self._g(), 0, h["s_lo"].data_ptr(), st), "pack cur lo")
-            check(self.L.lpa_halo_pack_current(self._g(), 1, h["s_hi"].data_ptr(), st), "pack cur hi")
-            self.comm.exchange(h["s_lo"][:n], h["s_hi"][:n], h["r_lo"][:n], h["r_hi"][:n])
-            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "unpack cur lo")
-            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "unpack cur hi")
+            exchange_faces(
+                self.comm,
+                lambda side, b: check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st),
+                                      "lpa_halo_pack_current"),
+                lambda side, b: check(self.L.lpa_halo_unpack_current(self._g(), side, b.data_ptr(), st),
+                                      "lpa_halo_unpack_current"),
+                h)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
 
     # ---- sort (ParticleSort2D.__call__, core/sort/particle_sort.py:196-211) ------------------------

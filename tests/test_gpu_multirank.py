@@ -1,0 +1,112 @@
+"""The slab-decomposed engine with 2 and 3 ranks against the single-rank engine on the same global
+problem.  The ranks share the box's one GPU and talk through `gloo` (device buffers staged through
+the host by SlabComm) -- the RCCL path differs only in the transport of the same messages.
+
+Checks per-step field energy / charge / kinetic energy / particle count (summed over ranks) and the
+final E, B, rho arrays gathered from the slabs, tolerance 1e-10 (summation order only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+C = 299792458.0
+NXG, NY, PPC, NSTEPS = 96, 64, 6, 24
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    lam = 0.8e-6
+    dx = dy = lam / 20
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    rng = np.random.default_rng(77)
+    n = NXG * NY * PPC
+    cell = np.arange(n) // PPC
+    x = ((cell // NY) + rng.uniform(-0.5, 0.5, n)) * dx
+    y = ((cell % NY) + rng.uniform(-0.5, 0.5, n)) * dy
+    # hot plasma (u ~ 0.3): plenty of slab crossings within a few steps
+    u = rng.normal(size=(3, n)) * 0.3
+    ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
+    w = np.full(n, 1.7e27 * dx * dy / PPC)
+    return dx, dy, dt, x, y, u, ig, w
+
+
+def _run(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.engine import PicEngine2D
+    comm = SlabComm(None, single=(world == 1))
+    dx, dy, dt, x, y, u, ig, w = _problem()
+    nx = NXG // world
+    eng = PicEngine2D(nx, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
+                      migrate_capacity=4096)
+    lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
+    mine = (x >= lo) & (x < hi)
+    n = int(mine.sum())
+    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=3 * n + 8 * 4096 * 5)
+    s = eng.species[0].cset
+    for name, arr in (("x", x), ("y", y), ("ux", u[0]), ("uy", u[1]), ("uz", u[2]), ("inv_gamma", ig), ("w", w)):
+        s.arr(name)[:n] = torch.from_numpy(arr[mine]).cuda()
+    s.id[:n] = torch.from_numpy(np.nonzero(mine)[0]).cuda()
+    eng.species[0].n = n
+    trace = []
+    for _ in range(NSTEPS):
+        eng.step(dt)
+        d = eng.diagnostics()
+        trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+    g = eng.grid
+    sl = slice(3, 3 + nx)
+    fields = {a: g.view(a)[sl, 3:3 + NY].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trace = sum(r[1] for r in res)
+    fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+    return trace, fields
+
+
+@pytest.fixture(scope="module")
+def single():
+    return _launch(1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_match_single_rank(single, world):
+    t1, f1 = single
+    tn, fn = _launch(world)
+    assert np.array_equal(tn[:, 3], t1[:, 3])                       # particle count conserved
+    np.testing.assert_allclose(tn[:, 0], t1[:, 0], rtol=1e-10)      # field energy
+    np.testing.assert_allclose(tn[:, 1], t1[:, 1], rtol=1e-12)      # total charge
+    np.testing.assert_allclose(tn[:, 2], t1[:, 2], rtol=1e-12)      # kinetic energy
+    for a in f1:
+        scale = np.abs(f1[a]).max()
+        assert np.abs(fn[a] - f1[a]).max() <= 1e-9 * scale, a
