@@ -161,6 +161,10 @@ int lpa_interpolate_2d(const lpa_grid *g, const lpa_particles *p, void *stream);
 int lpa_boris(const lpa_particles *p, double dt, double q, double m, void *stream);
 int lpa_push_position_2d(const lpa_particles *p, double dt, void *stream);
 int lpa_deposit_2d(const lpa_grid *g, const lpa_particles *p, double dt, double q, void *stream);
+/* periodic fold of the positions into the global box (pp->wrap, lo, hi): what Patches.sync_particles
+ * does for a patch that is its own neighbour (core/patch/sync_particles_2d.c:168-182); the fused
+ * kernels apply it themselves, the split path calls this after the deposit */
+int lpa_wrap_positions_2d(const lpa_particles *p, const lpa_push_params *pp, void *stream);
 
 /* ---- cell-index sort (replaces sort_particles_patches_2d, core/sort/cpu2d.c:220-303, as driven
  *      by ParticleSort2D.__call__, core/sort/particle_sort.py:196-211).  Out of place: `src` is

@@ -499,6 +499,26 @@ __global__ void __launch_bounds__(256) k_deposit_2d(GridV g, PartV p, double dt,
     deposit_global_2d<false>(g, x, y, p.ux[ip], p.uy[ip], p.uz[ip], p.ig[ip], p.w[ip], q, dt);
 }
 
+__global__ void __launch_bounds__(256) k_wrap_positions_2d(PartV p, PushK k) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;
+    if (k.wrap & 1) { double x = p.x[ip]; if (!isnan(x)) p.x[ip] = fold_coord(x, k.lo[0], k.hi[0]); }
+    if (k.wrap & 2) { double y = p.y[ip]; if (!isnan(y)) p.y[ip] = fold_coord(y, k.lo[1], k.hi[1]); }
+}
+
+extern "C" int lpa_wrap_positions_2d(const lpa_particles *p, const lpa_push_params *pp, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 2) && pp, "lpa_wrap_positions_2d: bad args");
+    if (p->n == 0 || !pp->wrap) return LPA_OK;
+    lpa_push_params q = *pp;
+    if (!(q.dt > 0)) q.dt = 1.0;
+    if (!(q.m > 0)) q.m = 1.0;
+    hipLaunchKernelGGL(k_wrap_positions_2d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_partv(p), make_pushk(&q));
+    LPA_CHECK_LAUNCH("lpa_wrap_positions_2d");
+    return LPA_OK;
+}
+
 extern "C" int lpa_interpolate_2d(const lpa_grid *g, const lpa_particles *p, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && lpa_part_ok(p, 2) && (p->n == 0 || p->part_eb[0]),
                 "lpa_interpolate_2d: bad args (part_eb required)");

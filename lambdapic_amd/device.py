@@ -104,14 +104,14 @@ class ParticleSet:
     def arr(self, name) -> torch.Tensor:
         return self.data[self.names.index(name)]
 
-    def cstruct(self, n) -> _lib.lpa_particles:
+    def cstruct(self, n, eb=True) -> _lib.lpa_particles:
         p = _lib.lpa_particles()
         p.n = int(n)
         for name in PART_CORE:
             setattr(p, name, self.arr(name).data_ptr())
         p.z = None
         for k, name in enumerate(PART_EB):
-            p.part_eb[k] = self.arr(name).data_ptr() if self.with_eb else None
+            p.part_eb[k] = self.arr(name).data_ptr() if (self.with_eb and eb) else None
         p.id = self.id.data_ptr()
         p.is_dead = None
         return p

@@ -61,6 +61,9 @@ class PicEngine2D:
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every
         # launch of the tiled push+deposit kernel on the stream it runs on
         self.kernel_events = None
+        # the fused kernel stores the gathered E/B per particle (the reference's ex_part..bz_part side
+        # effect, +48 B/particle) only when asked: callbacks that read them set this
+        self.write_part_eb = False
 
     # ---------------------------------------------------------------------------------------------
     @property
@@ -190,7 +193,7 @@ class PicEngine2D:
             return
         st = self.stream
         pp = self._push_params(sp, dt)
-        pc = sp.cset.cstruct(sp.n)
+        pc = sp.cset.cstruct(sp.n, eb=self.write_part_eb)
         if tiled and sp.tiling is not None and sp.n_sorted > 0:
             ws = self._sort_ws(sp)
             ws["counters"][0:1].zero_()
@@ -211,6 +214,36 @@ class PicEngine2D:
                       "loose")
         else:
             check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), 0, sp.n, st), "global")
+        sp.steps_since_sort += 1
+
+    # ---- split kernels: the path the reference takes when a callback sits in a pusher stage --------
+    # (`simulation/simulation.py:993-1038`): push_position, interpolate, boris, push_position, deposit
+    def _pc_eb(self, ispec):
+        sp = self.species[ispec]
+        if not sp.with_eb:
+            raise _lib.LpaError("the split pusher path needs per-particle E/B arrays: add_species(with_eb=True)")
+        return sp, sp.cset.cstruct(sp.n)
+
+    def push_position(self, ispec, dt):
+        sp = self.species[ispec]
+        pc = sp.cset.cstruct(sp.n)
+        check(self.L.lpa_push_position_2d(C.byref(pc), dt, self.stream), "lpa_push_position_2d")
+
+    def interpolate(self, ispec):
+        sp, pc = self._pc_eb(ispec)
+        check(self.L.lpa_interpolate_2d(self._g(), C.byref(pc), self.stream), "lpa_interpolate_2d")
+
+    def boris(self, ispec, dt):
+        sp, pc = self._pc_eb(ispec)
+        check(self.L.lpa_boris(C.byref(pc), dt, sp.q, sp.m, self.stream), "lpa_boris")
+
+    def deposit(self, ispec, dt):
+        """standalone Esirkepov deposit + the periodic position fold the fused kernel applies itself"""
+        sp = self.species[ispec]
+        pc = sp.cset.cstruct(sp.n)
+        check(self.L.lpa_deposit_2d(self._g(), C.byref(pc), dt, sp.q, self.stream), "lpa_deposit_2d")
+        pp = self._push_params(sp, dt)
+        check(self.L.lpa_wrap_positions_2d(C.byref(pc), C.byref(pp), self.stream), "lpa_wrap_positions_2d")
         sp.steps_since_sort += 1
 
     # ---- particle ownership (mpi.sync_particles_* + Patches.sync_particles) ------------------------

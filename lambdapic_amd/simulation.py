@@ -1,0 +1,385 @@
+"""Host-side mirror of the reference's facade / stage-callback interface for the hot path.
+
+The reference's ``Simulation.run`` (`simulation/simulation.py:858-1141`) walks fixed stages per step
+and calls one facade method per stage; callbacks ``cb(sim)`` with ``.stage`` / ``.interval`` run
+between them and may read or write any field / particle array of ``sim.patches``.  This module
+reproduces exactly that protocol on top of ``PicEngine2D``:
+
+    sim.maxwell.update_efield(dt) / update_bfield(dt)       MaxwellSolver2D   (core/maxwell/solver/solver.py:143-190)
+    sim.patches.sync_guard_fields(attrs) / sync_currents() / sync_particles()   (core/patch/patch.py:670-764)
+    sim.sorter[ispec]()                                     ParticleSort2D    (core/sort/particle_sort.py:196-211)
+    sim.current_depositor.reset() / (ispec, dt)             CurrentDeposition2D (core/current/deposition.py:138-208)
+    sim.pusher[ispec](dt, unified=True) / .push_position(dt)  BorisPusher     (core/pusher/pusher.py:102-141)
+    sim.interpolator(ispec)                                 FieldInterpolation2D (core/interpolation/field_interpolation.py:149-180)
+
+The device owns the state; ``sim.patches[i].fields.*`` / ``.particles[ispec].*`` are host MIRRORS in
+λPIC's layout.  They are refreshed (device -> host) before a stage that has a triggered callback and
+written back (host -> device) after it, so reference-style callbacks run unchanged.  Out of scope
+here: PML, lasers, QED, collisions, load balancing, I/O.
+"""
+from __future__ import annotations
+
+import time as _time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import constants
+from .dist import SlabComm
+from .engine import PicEngine2D
+from .patch import make_patches_2d
+
+
+@dataclass
+class Species:
+    """subset of the reference's ``Species`` (`core/species.py:50-182`) the hot path needs"""
+    name: str
+    charge: float            # in units of e
+    mass: float              # in units of m_e
+    density: object = None   # callable (x, y) -> n [m^-3] or a float
+    ppc: int = 0
+    momentum_sigma: float = 0.0   # thermal u = gamma*beta spread per axis (SetTemperature stand-in)
+    ispec: int = field(default=-1, init=False)
+
+    @property
+    def q(self):
+        return self.charge * constants.E_CHARGE
+
+    @property
+    def m(self):
+        return self.mass * constants.M_E
+
+
+def callback(stage="end", interval=1):
+    """decorator mirroring `callback/callback.py:48-109`: attaches ``stage`` and ``interval``"""
+    def wrap(fn):
+        fn.stage, fn.interval = stage, interval
+        return fn
+    return wrap
+
+
+class _Facade:
+    def __init__(self, sim):
+        self.sim = sim
+        self._enabled = True
+
+    # EnableMixin (`core/utils/enable_mixin.py:4-38`)
+    def enable(self):
+        self._enabled = True
+
+    def disable(self):
+        self._enabled = False
+
+    def is_enabled(self):
+        return self._enabled
+
+
+class MaxwellSolver2D(_Facade):
+    def update_efield(self, dt):
+        if self._enabled:
+            self.sim.engine.update_efield(dt)
+
+    def update_bfield(self, dt):
+        if self._enabled:
+            self.sim.engine.update_bfield(dt)
+
+
+class CurrentDeposition2D(_Facade):
+    def reset(self):
+        if self._enabled:
+            self.sim.engine.reset_current()
+
+    def __call__(self, ispec, dt):
+        if self._enabled:
+            self.sim.engine.deposit(ispec, dt)
+
+
+class FieldInterpolation2D(_Facade):
+    def __call__(self, ispec):
+        if self._enabled:
+            self.sim.engine.interpolate(ispec)
+
+
+class BorisPusher(_Facade):
+    def __init__(self, sim, ispec):
+        super().__init__(sim)
+        self.ispec = ispec
+
+    def __call__(self, dt, unified=False):
+        if not self._enabled:
+            return
+        if unified:
+            self.sim.engine.push_deposit(self.ispec, dt)
+        else:
+            self.sim.engine.boris(self.ispec, dt)
+
+    def push_position(self, dt):
+        if self._enabled:
+            self.sim.engine.push_position(self.ispec, dt)
+
+
+class ParticleSort2D(_Facade):
+    """the reference re-sorts every step (cheap there: in-place, nothing moves when already
+    sorted); the device sort is out of place, so it runs when the engine's cadence says so"""
+
+    def __init__(self, sim, ispec):
+        super().__init__(sim)
+        self.ispec = ispec
+        self.nbuf_last = 0
+
+    def __call__(self, force=False):
+        if not self._enabled:
+            return 0
+        sp = self.sim.engine.species[self.ispec]
+        if force or sp.tiling is None or sp.steps_since_sort >= self.sim.engine.sort_interval:
+            self.sim.engine.sort(self.ispec)
+            self.nbuf_last = sp.n_sorted
+        else:
+            self.nbuf_last = 0
+        return self.nbuf_last
+
+
+class DevicePatches:
+    """``sim.patches``: list-like over the host mirrors + the sync entry points of ``Patches``"""
+
+    def __init__(self, sim, mirrors):
+        self.sim, self._m = sim, mirrors
+        self.species = sim.species
+
+    def __getitem__(self, i):
+        return self._m[i]
+
+    def __len__(self):
+        return len(self._m)
+
+    def __iter__(self):
+        return iter(self._m)
+
+    def __getattr__(self, name):       # nx, ny, dx, dy, n_guard, npatches, xmin_global, ...
+        return getattr(self._m, name)
+
+    def sync_guard_fields(self, attrs=("ex", "ey", "ez", "bx", "by", "bz")):
+        self.sim.engine.sync_guard_fields(attrs)
+
+    def sync_currents(self):
+        self.sim.engine.sync_currents()
+
+    def sync_particles(self):
+        for i in range(len(self.sim.species)):
+            self.sim.engine.sync_particles(i)
+
+
+class Simulation:
+    """2-D periodic simulation driver with the reference's constructor vocabulary
+    (`simulation/simulation.py:118-168`) and stage list (`:170-184`)."""
+
+    STAGES = ["init", "start", "maxwell_1", "_push_position_1", "_interpolator", "_qed", "_push_momentum",
+              "_push_position_2", "current_deposition", "qed_create_particles", "_laser", "maxwell_2", "end",
+              "final"]
+    DEFAULT_STAGE = "end"
+    _PUSHER_STAGES = {"_push_position_1", "_interpolator", "_qed", "_push_momentum", "_push_position_2"}
+
+    def __init__(self, nx, ny, dx, dy, npatch_x=1, npatch_y=1, nsteps=None, sim_time=None, dt_cfl=0.95,
+                 n_guard=3, boundary_conditions=None, random_seed=None, device="cuda:0", comm=None,
+                 sort_interval=16, capacity_factor=1.5):
+        bc = boundary_conditions or {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")}
+        if any(v != "periodic" for v in bc.values()):
+            raise NotImplementedError("only periodic boundaries: CPML is the first 'next' row (SURVEY 8f-1)")
+        if dt_cfl > 1.0:
+            raise ValueError("dt_cfl must be <= 1")
+        self.comm = comm or SlabComm(None)
+        self.nx, self.ny, self.dx, self.dy = int(nx), int(ny), float(dx), float(dy)
+        if self.nx % self.comm.size or (self.nx // self.comm.size) % npatch_x or self.ny % npatch_y:
+            raise ValueError("nx must split evenly over ranks and patches")
+        self.npatch_x, self.npatch_y, self.n_guard = npatch_x, npatch_y, n_guard
+        self.dt = dt_cfl * (self.dx ** -2 + self.dy ** -2) ** -0.5 / constants.C_LIGHT   # simulation.py:219
+        self.Lx, self.Ly = self.nx * self.dx, self.ny * self.dy
+        self.nsteps, self.sim_time = nsteps, sim_time
+        self.boundary_conditions = bc
+        self.random_seed = random_seed
+        self.device, self.sort_interval, self.capacity_factor = device, sort_interval, capacity_factor
+        self.species: list[Species] = []
+        self.itime, self.time, self.ispec = 0, 0.0, None
+        self.initialized = False
+        self.current_synced = False
+        self.stages = list(self.STAGES)
+
+    def add_species(self, species):
+        for s in species if isinstance(species, (list, tuple)) else [species]:
+            s.ispec = len(self.species)
+            self.species.append(s)
+
+    # ---- initialisation (`simulation.py:284-423` for the in-scope parts) ----------------------------
+    def initialize(self):
+        nx_loc = self.nx // self.comm.size
+        self.nx_per_patch, self.ny_per_patch = nx_loc // self.npatch_x, self.ny // self.npatch_y
+        self.engine = PicEngine2D(nx_loc, self.ny, self.dx, self.dy, self.n_guard, self.device, self.comm,
+                                  sort_interval=self.sort_interval)
+        mirrors = make_patches_2d(nx_loc, self.ny, self.dx, self.dy, self.npatch_x, self.npatch_y, self.n_guard,
+                                  nspecies=len(self.species))
+        for p in mirrors:                       # patch origins in global coordinates
+            p.x0 += self.engine.x0
+            p.fields.x0 = p.x0
+            p.fields.xaxis += self.engine.x0
+        mirrors.xmin_global, mirrors.xmax_global = -self.dx / 2, self.Lx - self.dx / 2
+        self.patches = DevicePatches(self, mirrors)
+        rng = np.random.default_rng(None if self.random_seed is None else self.random_seed + self.comm.rank)
+        for s in self.species:
+            n_tot = 0
+            for p in mirrors:
+                q = p.particles[s.ispec]
+                n_tot += self._fill(p, q, s, rng)
+            self.engine.add_species(s.q, s.m, capacity=int(n_tot * self.capacity_factor) + 65536, with_eb=True)
+            self.engine.species[s.ispec].upload([p.particles[s.ispec] for p in mirrors])
+        self.maxwell = MaxwellSolver2D(self)
+        self.interpolator = FieldInterpolation2D(self)
+        self.current_depositor = CurrentDeposition2D(self)
+        self.pusher = [BorisPusher(self, i) for i in range(len(self.species))]
+        self.sorter = [ParticleSort2D(self, i) for i in range(len(self.species))]
+        self.initialized = True
+
+    @staticmethod
+    def _fill(p, q, s, rng):
+        """uniform loading, ppc per cell with density > 0 (`core/patch/cpu.py:21-44`)"""
+        if not s.ppc or s.density is None:
+            q.initialize(0)
+            return 0
+        xs = p.x0 + np.arange(p.nx) * p.dx
+        ys = p.y0 + np.arange(p.ny) * p.dy
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        dens = s.density(X, Y) if callable(s.density) else np.full(X.shape, float(s.density))
+        sel = np.nonzero(dens.ravel() > 0)[0]
+        n = sel.size * s.ppc
+        q.initialize(n)
+        cx, cy, d = np.repeat(X.ravel()[sel], s.ppc), np.repeat(Y.ravel()[sel], s.ppc), np.repeat(dens.ravel()[sel], s.ppc)
+        q.x[:] = cx + rng.uniform(-0.5, 0.5, n) * p.dx
+        q.y[:] = cy + rng.uniform(-0.5, 0.5, n) * p.dy
+        q.w[:] = d * p.dx * p.dy / s.ppc
+        if s.momentum_sigma:
+            for a in ("ux", "uy", "uz"):
+                getattr(q, a)[:] = rng.normal(0.0, s.momentum_sigma, n)
+            q.inv_gamma[:] = 1.0 / np.sqrt(1 + q.ux ** 2 + q.uy ** 2 + q.uz ** 2)
+        return n
+
+    # ---- host mirrors <-> device --------------------------------------------------------------------
+    def download(self):
+        """device -> ``sim.patches`` mirrors (fields with guards, live particles binned by patch)"""
+        self.engine.grid.download_patches(list(self.patches))
+        nxp, nyp = self.nx_per_patch, self.ny_per_patch
+        for s in self.species:
+            d = self.engine.species[s.ispec].download()
+            i = np.clip(np.floor((d["x"] - self.engine.x0) / self.dx + 0.5).astype(int) // nxp, 0, self.npatch_x - 1)
+            j = np.clip(np.floor(d["y"] / self.dy + 0.5).astype(int) // nyp, 0, self.npatch_y - 1)
+            owner = i + j * self.npatch_x
+            for k, p in enumerate(self.patches):
+                sel = owner == k
+                q = p.particles[s.ispec]
+                q.initialize(int(sel.sum()))
+                for a in d:
+                    if hasattr(q, a):
+                        getattr(q, a)[:] = d[a][sel]
+
+    def upload(self):
+        """``sim.patches`` mirrors -> device (after a callback modified them)"""
+        self.engine.grid.upload_patches(list(self.patches), self.npatch_x, self.npatch_y)
+        for s in self.species:
+            self.engine.species[s.ispec].upload([p.particles[s.ispec] for p in self.patches])
+
+    # ---- the stage loop (`simulation.py:937-1130`) ----------------------------------------------------
+    def _triggered(self, cbs):
+        out = []
+        for cb in cbs:
+            iv = getattr(cb, "interval", 1)
+            if callable(iv):
+                hit = bool(iv(self))
+            elif isinstance(iv, float):
+                hit = int(self.time / iv) > int((self.time - self.dt) / iv) or self.itime == 0
+            else:
+                hit = self.itime % int(iv) == 0
+            if hit:
+                out.append(cb)
+        return out
+
+    def _run_stage(self, table, stage):
+        cbs = self._triggered(table.get(stage, []))
+        if not cbs:
+            return
+        self.download()
+        for cb in cbs:
+            cb(self)
+        self.upload()
+
+    def sync_currents(self):
+        if not self.current_synced:
+            self.patches.sync_currents()
+            self.current_synced = True
+
+    def maxwell_stage(self):
+        """`simulation.py:743-761`"""
+        self.maxwell.update_efield(0.5 * self.dt)
+        self.patches.sync_guard_fields(["ex", "ey", "ez"])
+        self.maxwell.update_bfield(0.5 * self.dt)
+        self.patches.sync_guard_fields(["bx", "by", "bz"])
+
+    def run(self, nsteps=None, sim_time=None, callbacks=None, stop_callback=lambda: False):
+        if nsteps is not None and sim_time is not None:
+            raise ValueError("Cannot specify both nsteps and sim_time in run() method")
+        if not self.initialized:
+            self.initialize()
+        table = {}
+        for cb in callbacks or []:
+            table.setdefault(getattr(cb, "stage", self.DEFAULT_STAGE), []).append(cb)
+        for st in table:
+            if st not in self.STAGES:
+                raise ValueError(f"unknown stage {st!r}")
+        if nsteps is None:
+            nsteps = int(sim_time / self.dt) if sim_time is not None else \
+                (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
+        self.engine.write_part_eb = bool(table)     # callbacks may read ex_part..bz_part
+        self._run_stage(table, "init")
+        unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
+        E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+        for self.istep in range(self.itime, self.itime + nsteps):
+            self._run_stage(table, "start")
+            self.maxwell.update_efield(0.5 * self.dt)
+            self.patches.sync_guard_fields(E)
+            self.maxwell.update_bfield(0.5 * self.dt)
+            self.patches.sync_guard_fields(B)
+            self._run_stage(table, "maxwell_1")
+            for ispec in range(len(self.species)):
+                self.ispec = ispec
+                self.sorter[ispec]()
+            self.current_depositor.reset()
+            self.current_synced = False
+            for ispec in range(len(self.species)):
+                self.ispec = ispec
+                if unified:
+                    self.pusher[ispec](self.dt, unified=True)
+                else:
+                    self.pusher[ispec].push_position(0.5 * self.dt)
+                    self._run_stage(table, "_push_position_1")
+                    self.interpolator(ispec)
+                    self._run_stage(table, "_interpolator")
+                    self._run_stage(table, "_qed")
+                    self.pusher[ispec](self.dt)
+                    self._run_stage(table, "_push_momentum")
+                    self.pusher[ispec].push_position(0.5 * self.dt)
+                    self._run_stage(table, "_push_position_2")
+                    self.current_depositor(ispec, self.dt)
+                self._run_stage(table, "current_deposition")
+            self.sync_currents()
+            self.ispec = None
+            self.patches.sync_particles()
+            self._run_stage(table, "qed_create_particles")
+            self.maxwell.update_bfield(0.5 * self.dt)
+            self._run_stage(table, "_laser")
+            self.patches.sync_guard_fields(B)
+            self.maxwell.update_efield(0.5 * self.dt)
+            self.patches.sync_guard_fields(E)
+            self._run_stage(table, "maxwell_2")
+            self._run_stage(table, "end")
+            self.time += self.dt
+            self.itime += 1
+            if stop_callback():
+                return "stop by callback"
+        self._run_stage(table, "final")

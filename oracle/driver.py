@@ -97,6 +97,45 @@ def step(patches, ks: KernelSet, dt, species, do_sort=True):
     ks.sync_guard(fl, pl, E, n, nx, ny, ng)
 
 
+def step_split(patches, dt, species, hook=None):
+    """one step on the NON-unified path the reference takes when a callback sits in a pusher stage
+    (simulation.py:993-1038): push_position(dt/2), interpolate, [hook = the '_interpolator'
+    callback], Boris on the stored *_part, push_position(dt/2), standalone deposit."""
+    import oracle
+    from oracle import sync
+
+    fl, pl = [p.fields for p in patches], list(patches)
+    n, nx, ny, ng = patches.npatches, patches.nx, patches.ny, patches.n_guard
+    E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+    for f in fl:
+        oracle.update_efield_2d(f, 0.5 * dt)
+    sync.sync_guard_fields_2d(fl, pl, E, n, nx, ny, ng)
+    for f in fl:
+        oracle.update_bfield_2d(f, 0.5 * dt)
+    sync.sync_guard_fields_2d(fl, pl, B, n, nx, ny, ng)
+    oracle.reset_current(fl, n)
+    for ispec, (q, m) in enumerate(species):
+        parts = [p.particles[ispec] for p in patches]
+        for pr in parts:
+            oracle.push_position_2d(pr, 0.5 * dt)
+        oracle.interpolation_patches_2d(parts, fl, n)
+        if hook is not None:
+            hook(patches, ispec)
+        for pr in parts:
+            oracle.boris_push(pr, q, m, dt)
+            oracle.push_position_2d(pr, 0.5 * dt)
+        oracle.current_deposition_cpu_2d(fl, parts, n, dt, q)
+    sync.sync_currents_2d(fl, pl, n, nx, ny, ng)
+    for ispec in range(len(species)):
+        sync.sync_particles_2d(patches, ispec, patches.dx, patches.dy)
+    for f in fl:
+        oracle.update_bfield_2d(f, 0.5 * dt)
+    sync.sync_guard_fields_2d(fl, pl, B, n, nx, ny, ng)
+    for f in fl:
+        oracle.update_efield_2d(f, 0.5 * dt)
+    sync.sync_guard_fields_2d(fl, pl, E, n, nx, ny, ng)
+
+
 def field_energy(patches) -> float:
     """sum over patch interiors of (eps0 E^2 + B^2/mu0)/2 * dx*dy
     (reference tests/test_numerical_heating.py:19-37)"""

@@ -1,0 +1,141 @@
+"""The facade / stage-callback mirror (lambdapic_amd.simulation) driven the way the reference's
+integration tests drive ``Simulation``: real simulation, callbacks that read (and write) the patch
+mirrors, no mocks (reference tests/test_numerical_heating.py, tests/test_callback.py,
+docs/source/write_callbacks.rst 'External fields')."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import driver
+from lambdapic_amd import constants
+from lambdapic_amd.patch import make_patches_2d
+from lambdapic_amd.simulation import Simulation, Species, callback
+
+pytestmark = pytest.mark.gpu
+
+LAMBDA = 0.8e-6
+C = 299792458.0
+
+
+def _sim(nx=64, ny=64, npx=2, npy=2, ppc=16, seed=3, **kw):
+    dx = dy = LAMBDA / 20
+    sim = Simulation(nx, ny, dx, dy, npatch_x=npx, npatch_y=npy, random_seed=seed, **kw)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / LAMBDA) ** 2 / constants.E_CHARGE ** 2
+    sim.add_species(Species("electron", charge=-1, mass=1, density=nc, ppc=ppc, momentum_sigma=0.0442))
+    return sim, nc
+
+
+def test_numerical_heating_energy_conservation():
+    """reference tests/test_numerical_heating.py:103-133: 64x64 periodic thermal plasma, total
+    (field + kinetic) energy conserved to < 1 %; energies computed by an 'end' callback from the
+    patch mirrors exactly like the reference's get_field_energy / get_kinetic_energy (:19-50)"""
+    sim, _ = _sim(ppc=16)
+    hist = []
+
+    @callback("end", interval=10)
+    def energies(s):
+        ef = 0.0
+        ek = 0.0
+        for p in s.patches:
+            f = p.fields
+            sl = (slice(0, f.nx), slice(0, f.ny))
+            ef += (0.5 * constants.EPSILON_0 * (f.ex[sl] ** 2 + f.ey[sl] ** 2 + f.ez[sl] ** 2).sum()
+                   + 0.5 / constants.MU_0 * (f.bx[sl] ** 2 + f.by[sl] ** 2 + f.bz[sl] ** 2).sum()) * f.dx * f.dy
+            q = p.particles[0]
+            live = ~q.is_dead
+            ek += (q.w[live] * (1 / q.inv_gamma[live] - 1)).sum() * constants.M_E * C ** 2
+        hist.append((s.itime, ef, ek))
+
+    sim.run(101, callbacks=[energies])
+    tot = np.array([h[1] + h[2] for h in hist])
+    assert len(hist) == 11
+    assert np.all(np.abs(tot / tot[0] - 1) < 0.01)
+    d = sim.engine.diagnostics()     # the mirror-based numbers equal the device reductions
+    assert hist[-1][1] == pytest.approx(d["field_energy"], rel=1e-12)
+    assert hist[-1][2] == pytest.approx(d["kinetic"][0], rel=1e-12)
+
+
+def test_stage_order_and_intervals():
+    """callbacks fire at their stage, in the reference's stage order, honouring int intervals
+    (reference tests/test_callback.py; STAGES simulation.py:170-184)"""
+    sim, _ = _sim(nx=32, ny=32, npx=1, npy=1, ppc=4)
+    seen = []
+
+    def mk(stage, interval=1):
+        @callback(stage, interval)
+        def cb(s):
+            seen.append((s.itime, stage))
+        return cb
+
+    def plain(s):                      # undecorated callables default to stage 'end'
+        seen.append((s.itime, "plain"))
+
+    cbs = [mk("end"), mk("start"), mk("maxwell_1"), mk("current_deposition"), mk("_laser", 2), mk("init"),
+           mk("final"), plain]
+    sim.run(3, callbacks=cbs)
+    per_step = lambda it: [st for t, st in seen if t == it]
+    assert seen[0] == (0, "init") and seen[-1][1] == "final"
+    assert per_step(1) == ["start", "maxwell_1", "current_deposition", "end", "plain"]
+    assert "_laser" in per_step(0) and "_laser" in per_step(2) and "_laser" not in per_step(1)
+    with pytest.raises(ValueError):
+        sim.run(1, callbacks=[mk("no_such_stage")])
+    with pytest.raises(ValueError):
+        sim.run(nsteps=1, sim_time=1e-15)
+
+
+def test_interpolator_callback_external_field_vs_oracle():
+    """a callback in a pusher stage forces the split path (simulation.py:896-911); an external
+    field added to ex_part at '_interpolator' (docs write_callbacks.rst 'External fields') must act
+    exactly as in the CPU restatement of that path"""
+    sim, nc = _sim(nx=32, ny=32, npx=2, npy=1, ppc=8, seed=11, sort_interval=4)
+    sim.initialize()
+    # same initial particles for the oracle
+    P = make_patches_2d(32, 32, sim.dx, sim.dy, 2, 1)
+    for p, m in zip(P, sim.patches):
+        q, s = p.particles[0], m.particles[0]
+        q.initialize(s.npart)
+        for a in ("x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id"):
+            getattr(q, a)[:] = getattr(s, a)
+    E0 = 3e11
+
+    @callback("_interpolator")
+    def external(s):
+        for p in s.patches:
+            q = p.particles[s.ispec]
+            q.ex_part[~q.is_dead] += E0 * np.sin(2 * np.pi * q.y[~q.is_dead] / s.Ly)
+
+    def hook(patches, ispec):
+        for p in patches:
+            q = p.particles[ispec]
+            q.ex_part[~q.is_dead] += E0 * np.sin(2 * np.pi * q.y[~q.is_dead] / (32 * sim.dy))
+
+    nsteps = 6
+    sim.run(nsteps, callbacks=[external])
+    qm = [(-constants.E_CHARGE, constants.M_E)]
+    for _ in range(nsteps):
+        driver.step_split(P, sim.dt, qm, hook)
+    d = sim.engine.diagnostics()
+    assert d["field_energy"] == pytest.approx(driver.field_energy(P), rel=1e-10)
+    assert d["kinetic"][0] == pytest.approx(driver.kinetic_energy(P, 0, constants.M_E), rel=1e-12)
+    assert d["charge"] == pytest.approx(driver.total_charge(P), rel=1e-12)
+    sim.download()
+    for m, p in zip(sim.patches, P):
+        for a in ("ex", "ey", "bz", "jx", "rho"):
+            A, B = getattr(m.fields, a)[: p.nx, : p.ny], getattr(p.fields, a)[: p.nx, : p.ny]
+            assert np.abs(A - B).max() <= 1e-10 * np.abs(getattr(p.fields, a)).max(), a
+
+
+def test_mirror_round_trip_is_lossless():
+    """download -> upload through the patch mirrors must not change the device state"""
+    sim, _ = _sim(nx=48, ny=32, npx=3, npy=2, ppc=4, seed=5)
+    sim.run(5)
+    before = sim.engine.diagnostics()
+    ex0 = sim.engine.grid.view("ex").clone()
+    sim.download()
+    sim.upload()
+    after = sim.engine.diagnostics()
+    assert before["field_energy"] == after["field_energy"] and before["nalive"] == after["nalive"]
+    assert before["kinetic"][0] == pytest.approx(after["kinetic"][0], rel=1e-14)
+    assert (sim.engine.grid.view("ex") - ex0).abs().max().item() == 0.0
+    sim.run(3)                                    # and the run continues from the uploaded state
+    assert sim.itime == 8
