@@ -79,6 +79,13 @@ def cpu_baseline(args):
     from oracle import driver, sync
     from lambdapic_amd.patch import make_patches_2d
 
+    # the box gives one GPU a share of the host cores: use the cores this process may run on,
+    # at most 16 (the per-GPU share), and say how many
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(avail, args.cpu_threads)))
     L = oracle.lib(native=True)
     threads = int(L.orc_num_threads())
     nx = ny = args.cpu_cells
@@ -103,15 +110,18 @@ def cpu_baseline(args):
         L.orc_fdtd_b_2d_patches(C.c_long(npat), ftab, C.c_long(P.nx), C.c_long(P.ny), C.c_long(ng),
                                 C.c_double(dx), C.c_double(dy), C.c_double(h))
 
+    def guards(attrs):
+        oracle.sync_guard_fields_2d_c(fl, pl, attrs, npat, P.nx, P.ny, ng, native=True)
+
     def one_step():
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
-        fdtd_e(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, E, npat, P.nx, P.ny, ng)
-        fdtd_b(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, B, npat, P.nx, P.ny, ng)
+        fdtd_e(0.5 * dt); guards(E)
+        fdtd_b(0.5 * dt); guards(B)
         oracle.reset_current(fl, npat)
         oracle.unified_boris_pusher_cpu_2d(parts, fl, npat, dt, q, m, native=True)
-        sync.sync_currents_2d(fl, pl, npat, P.nx, P.ny, ng)
-        fdtd_b(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, B, npat, P.nx, P.ny, ng)
-        fdtd_e(0.5 * dt); sync.sync_guard_fields_2d(fl, pl, E, npat, P.nx, P.ny, ng)
+        oracle.sync_currents_2d_c(fl, pl, npat, P.nx, P.ny, ng, native=True)
+        fdtd_b(0.5 * dt); guards(B)
+        fdtd_e(0.5 * dt); guards(E)
 
     one_step()                      # warm-up (page faults, thread pool)
     n = nx * ny * ppc
@@ -135,10 +145,11 @@ def main():
     ap.add_argument("--nx", type=int, default=1024)
     ap.add_argument("--ny", type=int, default=1024)
     ap.add_argument("--ppc", type=int, default=64)
-    ap.add_argument("--sort-interval", type=int, default=8)
+    ap.add_argument("--sort-interval", type=int, default=20)
     ap.add_argument("--block-particles", type=int, default=8192)
     ap.add_argument("--cpu-cells", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -143,18 +143,19 @@ class DeviceParticles:
 
     def upload(self, host_particles_list):
         """concatenate the live particles of the host mirrors into the device store"""
-        cols = {a: [] for a in PART_CORE}
+        names = self.cset.names           # core attributes (+ ex_part..bz_part when carried)
+        cols = {a: [] for a in names}
         ids = []
         for hp in host_particles_list:
             live = ~hp.is_dead & ~np.isnan(hp.x) & ~np.isnan(hp.y)
-            for a in PART_CORE:
+            for a in names:
                 cols[a].append(getattr(hp, a)[live])
             ids.append(hp._id.view(np.int64)[live])
         n = int(sum(c.size for c in ids))
         if n > self.capacity:
             raise _lib.LpaError(f"particle capacity {self.capacity} < {n}")
         s = self.cset
-        for a in PART_CORE:
+        for a in names:
             s.arr(a)[:n].copy_(torch.from_numpy(np.concatenate(cols[a])))
         s.id[:n].copy_(torch.from_numpy(np.concatenate(ids)))
         self.n, self.n_sorted, self.tiling = n, 0, None

@@ -215,6 +215,24 @@ def update_bfield_3d(f, dt):
                         C.c_double(f.dx), C.c_double(f.dy), C.c_double(f.dz), C.c_double(dt))
 
 
+def sync_guard_fields_2d_c(fields_list, patches_list, attrs, npatches, nx, ny, ng, native=False):
+    """C/OpenMP twin of oracle.sync.sync_guard_fields_2d (core/patch/sync_fields2d.c:150-255)"""
+    L = lib(native)
+    nb = np.ascontiguousarray(np.stack([p.neighbor_ipatch for p in patches_list[:npatches]]).astype(np.int64))
+    for a in attrs:
+        L.orc_sync_guard_2d_patches(C.c_long(npatches), _tab([getattr(f, a) for f in fields_list[:npatches]]),
+                                    _p(nb), C.c_long(nx), C.c_long(ny), C.c_long(ng))
+
+
+def sync_currents_2d_c(fields_list, patches_list, npatches, nx, ny, ng, native=False):
+    """C/OpenMP twin of oracle.sync.sync_currents_2d (core/patch/sync_fields2d.c:43-148)"""
+    L = lib(native)
+    nb = np.ascontiguousarray(np.stack([p.neighbor_ipatch for p in patches_list[:npatches]]).astype(np.int64))
+    for a in ("jx", "jy", "jz", "rho"):
+        L.orc_sync_currents_2d_patches(C.c_long(npatches), _tab([getattr(f, a) for f in fields_list[:npatches]]),
+                                       _p(nb), C.c_long(nx), C.c_long(ny), C.c_long(ng))
+
+
 def bucket_index_2d(x, y, is_dead, nx, ny, dx, dy, x0, y0, reverse_x=False):
     """restates core/sort/cpu2d.c:9-54; returns (particle_index, bucket_count)"""
     n = x.size

@@ -590,6 +590,63 @@ void orc_bucket_index_2d(long npart, const double *x, const double *y, const u8 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * a10 / a11  intra-rank guard copy and current fold over a patch set (OpenMP over patches, like
+ *            patch/sync_fields2d.c:62-63,172-173).  Same semantics as oracle/sync.py (which the tests
+ *            pin to the reference); this C form exists so that the CPU baseline is not timed through
+ *            numpy.  `arr[p]` = one attribute's array of patch p (wrapped guard layout), `nb[8*p+b]`
+ *            = neighbour patch across boundary b (Boundary2D order) or -1.
+ * ------------------------------------------------------------------------------------------- */
+static const int SIDE_X[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+static const int SIDE_Y[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+
+static inline void range_guard(int side, long n, long ng, long *dst0, long *src0, long *len) {
+    if (side == 0) { *dst0 = 0; *src0 = 0; *len = n; }
+    else if (side < 0) { *dst0 = -ng; *src0 = n - ng; *len = ng; }  /* my low guard <- nb's top edge */
+    else { *dst0 = n; *src0 = 0; *len = ng; }                       /* my high guard <- nb's bottom edge */
+}
+static inline void range_fold(int side, long n, long ng, long *dst0, long *src0, long *len) {
+    if (side == 0) { *dst0 = 0; *src0 = 0; *len = n; }
+    else if (side < 0) { *dst0 = 0; *src0 = n; *len = ng; }         /* my low edge += nb's high guard */
+    else { *dst0 = n - ng; *src0 = -ng; *len = ng; }                /* my high edge += nb's low guard */
+}
+
+void orc_sync_guard_2d_patches(long npatches, double **arr, const int64_t *nb, long nx, long ny,
+                               long ng) {
+    const long NX = nx + 2 * ng, NY = ny + 2 * ng;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npatches; p++)
+        for (int b = 0; b < 8; b++) {
+            long q = nb[8 * p + b];
+            if (q < 0) continue;
+            long dx0, sx0, lx, dy0, sy0, ly;
+            range_guard(SIDE_X[b], nx, ng, &dx0, &sx0, &lx);
+            range_guard(SIDE_Y[b], ny, ng, &dy0, &sy0, &ly);
+            for (long i = 0; i < lx; i++)
+                for (long j = 0; j < ly; j++)
+                    arr[p][I2(dx0 + i, dy0 + j)] = arr[q][I2(sx0 + i, sy0 + j)];
+        }
+}
+
+void orc_sync_currents_2d_patches(long npatches, double **arr, const int64_t *nb, long nx, long ny,
+                                  long ng) {
+    const long NX = nx + 2 * ng, NY = ny + 2 * ng;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npatches; p++)
+        for (int b = 0; b < 8; b++) {
+            long q = nb[8 * p + b];
+            if (q < 0) continue;
+            long dx0, sx0, lx, dy0, sy0, ly;
+            range_fold(SIDE_X[b], nx, ng, &dx0, &sx0, &lx);
+            range_fold(SIDE_Y[b], ny, ng, &dy0, &sy0, &ly);
+            for (long i = 0; i < lx; i++)
+                for (long j = 0; j < ly; j++) {
+                    arr[p][I2(dx0 + i, dy0 + j)] += arr[q][I2(sx0 + i, sy0 + j)];
+                    arr[q][I2(sx0 + i, sy0 + j)] = 0.0;
+                }
+        }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -137,6 +137,20 @@ def test_g7_sync_fields(golden):
             assert_close(getattr(p.fields, a), g[f"out{k}_{a}"], 1e-15, what=f"{k} {a}")
 
 
+def test_g7_sync_fields_c_twin(golden):
+    """the OpenMP C form used by the CPU baseline gives the same arrays"""
+    g = golden("g7_sync_2d")
+    P = _patches_from_g7(g)
+    fl = [p.fields for p in P]
+    oracle.sync_guard_fields_2d_c(fl, list(P), ["ex", "ey", "ez", "bx", "by", "bz"], 4, P.nx, P.ny, 3)
+    oracle.sync_currents_2d_c(fl, list(P), 4, P.nx, P.ny, 3)
+    for k, p in enumerate(P):
+        for a in ["ex", "ey", "ez", "bx", "by", "bz"]:
+            assert np.array_equal(getattr(p.fields, a), g[f"out{k}_{a}"]), (k, a)
+        for a in ["jx", "jy", "jz", "rho"]:
+            assert_close(getattr(p.fields, a), g[f"out{k}_{a}"], 1e-15, what=f"{k} {a}")
+
+
 def test_g7_sync_particles(golden):
     g = golden("g7_sync_2d")
     P = _patches_from_g7(g)
