@@ -85,8 +85,8 @@ def cpu_baseline(args):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    os.environ["OMP_NUM_THREADS"] = str(max(1, min(avail, args.cpu_threads)))
     L = oracle.lib(native=True)
+    L.orc_set_num_threads(max(1, min(avail, args.cpu_threads)))
     threads = int(L.orc_num_threads())
     nx = ny = args.cpu_cells
     ppc, npx = args.ppc, max(1, args.cpu_cells // 32)

@@ -33,9 +33,11 @@ def build(native: bool = False, force: bool = False) -> Path:
     src = HERE / "picoracle.c"
     if out.exists() and not force and out.stat().st_mtime >= src.stat().st_mtime:
         return out
-    flags = ["-O3", "-march=native"] if native else ["-O2"]
-    cmd = ["gcc", "-shared", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-math-errno",
-           *flags, "-o", str(out), str(src), "-lm"]
+    # checker build: strict IEEE evaluation (no FMA contraction), portable ISA.
+    # baseline build: the reference's own optimisation flags (setup.py:13), FMA contraction allowed.
+    flags = ["-O3", "-march=native", "-ftree-vectorize", "-fno-trapping-math"] if native \
+        else ["-O2", "-ffp-contract=off"]
+    cmd = ["gcc", "-shared", "-fPIC", "-fopenmp", "-fno-math-errno", *flags, "-o", str(out), str(src), "-lm"]
     subprocess.run(cmd, check=True)
     return out
 

@@ -647,6 +647,14 @@ void orc_sync_currents_2d_patches(long npatches, double **arr, const int64_t *nb
         }
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
