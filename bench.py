@@ -195,6 +195,16 @@ def main():
     alive = d["nalive"][0]
     alg_bytes = BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * args.nx * args.ny
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if ev else float("nan")
+    # HBM traffic of one K1 launch: PMC counters cannot be read from inside this process; the value
+    # comes from the committed rocprofv3 --pmc passes of this same workload (profiles/, tools/prof_pmc.sh)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as fh:
+            tr = json.load(fh)
+        if tr["config"] == {"nx": args.nx, "ny": args.ny, "ppc": args.ppc}:
+            traffic = tr["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     n_total = n_local * comm.size
     out = {
         "metric": "particle-updates/sec", "value": n_total * args.steps / elapsed,
@@ -209,7 +219,7 @@ def main():
                    "part_eb_writeback": False},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": None},
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
     }
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
         try:
