@@ -9,7 +9,9 @@ import ctypes as C
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "liblambdapic_amd.so"
+import os as _os
+# LPA_LIB_PATH selects another build of the SAME library (profiling / ablation builds)
+LIB_PATH = Path(_os.environ.get("LPA_LIB_PATH", HERE / "liblambdapic_amd.so"))
 
 LPA_TILE_X = 8
 LPA_TILE_Y = 32

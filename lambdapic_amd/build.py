@@ -26,6 +26,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def build_variant(name: str, defines) -> Path:
+    """diagnostic build with extra -D flags into lambdapic_amd/csrc/build/<name>.so (not the product)"""
+    out = CSRC / "build" / f"liblambdapic_amd_{name}.so"
+    out.parent.mkdir(exist_ok=True)
+    cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], "-shared", *[str(CSRC / s) for s in SOURCES],
+           "-o", str(out)]
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
     headers = list(CSRC.glob("*.hpp")) + [HERE.parent / "include" / "lambdapic_amd.h"]
     newest_hdr = max(h.stat().st_mtime for h in headers)

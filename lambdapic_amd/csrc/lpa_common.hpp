@@ -89,12 +89,10 @@ __device__ __forceinline__ int torus(int c, int N) {
     return c;
 }
 
-// floor to int that never traps on NaN / huge values (garbage in, bounded garbage out)
-__device__ __forceinline__ int ifloor(double v) {
-    v = floor(v);
-    v = fmin(fmax(v, -1.0e9), 1.0e9);  // NaN -> -1e9 (fmax/fmin return the non-NaN operand)
-    return (int)v;
-}
+// floor to int: v_floor_f64 + v_cvt_i32_f64.  The hardware conversion saturates out-of-range values
+// and maps NaN to 0, so garbage in gives bounded garbage out; every index derived from it is clamped
+// (LDS path) or wrapped on the torus (global path) before use.
+__device__ __forceinline__ int ifloor(double v) { return (int)floor(v); }
 
 // TSC gather weights, core/pusher/unified/unified_pusher_2d.c:64-69
 __device__ __forceinline__ void tsc3(double d, double g[3]) {
@@ -134,7 +132,7 @@ __device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double
 struct AxisW {
     double S0[4], S1[4], DS[4];
     int base;       // node index of window cell 0
-    bool tail_zero; // dc == 0: the 4th window cell is outside the reference's loop
+    bool tail_zero; // dc == 0: the 4th window cell is outside the reference's loop (all its values are 0)
 };
 
 __device__ __forceinline__ void axis_window(AxisW &a, double r_old, double r_adv, double d) {

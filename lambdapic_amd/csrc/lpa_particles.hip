@@ -210,17 +210,31 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     __syncthreads();
 
     const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy;
+    double abl = 0.0;  // only used by the LPA_ABLATE_* diagnostic builds
     // wave-uniform trip count: every lane of a wave runs the same iterations (the deposit below uses
     // wave-wide DPP / permlane operations)
+    // software pipeline: the seven attribute loads of the NEXT iteration are issued before the current
+    // particle is processed, so their HBM latency hides under the VALU / LDS work of this one
+    double nx_ = 0.0, ny_ = 0.0, nux = 0.0, nuy = 0.0, nuz = 0.0, nig = 1.0, nw = 0.0;
+    {
+        const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
+        if (ip0 < end) {
+            nx_ = p.x[ip0]; ny_ = p.y[ip0]; nux = p.ux[ip0]; nuy = p.uy[ip0]; nuz = p.uz[ip0];
+            nig = p.ig[ip0]; nw = p.w[ip0];
+        }
+    }
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
         const int ip = it + lane;
         bool valid = ip < end;
-        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 0.0, ig = 1.0, w = 0.0;
-        if (valid) {
-            x = p.x[ip];
-            y = p.y[ip];
-            valid = !(isnan(x) || isnan(y));  // killed since the last sort (migration)
+        double x = nx_, y = ny_, ux = nux, uy = nuy, uz = nuz, ig = nig, w = nw;
+        {
+            const int ipn = ip + (int)blockDim.x;
+            if (ipn < end) {
+                nx_ = p.x[ipn]; ny_ = p.y[ipn]; nux = p.ux[ipn]; nuy = p.uy[ipn]; nuz = p.uz[ipn];
+                nig = p.ig[ipn]; nw = p.w[ipn];
+            }
         }
+        valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
         if (valid) {
             // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
             int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
@@ -235,7 +249,6 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         double vz = 0.0;
         int b0 = 0;
         if (valid) {
-            ux = p.ux[ip]; uy = p.uy[ip]; uz = p.uz[ip]; ig = p.ig[ip]; w = p.w[ip];
             x += k.cdt_half * ig * ux;
             y += k.cdt_half * ig * uy;
             double eb[6];
@@ -249,12 +262,18 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                 tsc3(iy2 - yo + 0.5, hy);
                 int lx1 = clampi(ix1 - rx0, 1, RWX - 2), lx2 = clampi(ix2 - rx0, 1, RWX - 2);
                 int ly1 = clampi(iy1 - ry0, 1, RWY - 2), ly2 = clampi(iy2 - ry0, 1, RWY - 2);
+#ifdef LPA_ABLATE_NO_GATHER  // diagnostic build: keep the weights, drop the 54 LDS reads
+                eb[0] = hx[0] * gy[1] + lx2; eb[1] = gx[1] * hy[2] + ly2; eb[2] = gx[2] * gy[0] + lx1;
+                eb[3] = gx[0] * hy[1] + ly1; eb[4] = hx[1] * gy[2]; eb[5] = hx[2] * hy[0];
+                abl += eb[0];
+#else
                 eb[0] = gather9_l(s_eb[0], lx2, ly1, hx, gy);
                 eb[1] = gather9_l(s_eb[1], lx1, ly2, gx, hy);
                 eb[2] = gather9_l(s_eb[2], lx1, ly1, gx, gy);
                 eb[3] = gather9_l(s_eb[3], lx1, ly2, gx, hy);
                 eb[4] = gather9_l(s_eb[4], lx2, ly1, hx, gy);
                 eb[5] = gather9_l(s_eb[5], lx2, ly2, hx, hy);
+#endif
             }
             if (WRITE_EB) {
 #pragma unroll
@@ -286,16 +305,26 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
 
         if (!WAVE_REDUCE) {
             // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
-            // ds_add_f64 below hits 32 different bank pairs.  Exact zeros (the window cells a particle
-            // that does not change cell never reaches) are skipped.
+            // ds_add_f64 below hits 32 different bank pairs.
             if (valid) {
                 esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                    [&](int kk, int ll, double djx, double djy, double djz, double drho) {
                                        int o = b0 + kk * RSJ + ll;
-                                       if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
-                                       if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
-                                       if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
-                                       if (drho != 0.0) atomicAdd(&s_j[3][o], drho);
+#ifdef LPA_ABLATE_NO_ATOMICS  // diagnostic build: keep the arithmetic, drop the LDS atomics
+                                       abl += djx + djy + djz + drho + o;
+#else
+                                       // window row 3 / column 3 carry exact zeros unless the particle
+                                       // changed cell along that axis: predicate on the crossing flags
+                                       // (one exec-mask region per run of cells) instead of testing 64
+                                       // values -- crossers are ~3 % of the lanes
+                                       bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
+                                       if (on) {
+                                           atomicAdd(&s_j[0][o], djx);
+                                           atomicAdd(&s_j[1][o], djy);
+                                           atomicAdd(&s_j[2][o], djz);
+                                           atomicAdd(&s_j[3][o], drho);
+                                       }
+#endif
                                    });
             }
             continue;
@@ -350,6 +379,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         }
     }
     __syncthreads();
+#if defined(LPA_ABLATE_NO_ATOMICS) || defined(LPA_ABLATE_NO_GATHER)
+    if (abl == 1.2345e-300) s_j[0][0] = abl;  // keeps the ablated arithmetic alive
+#endif
 
     // ---- flush the J tile: one FP64 global atomic per touched cell and component.  Consecutive
     //      threads walk consecutive y -> each wave instruction covers contiguous 8-B segments of a row
