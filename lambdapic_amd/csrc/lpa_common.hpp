@@ -102,17 +102,38 @@ __device__ __forceinline__ void tsc3(double d, double g[3]) {
     g[2] = 0.5 * (0.25 + d2 - d);
 }
 
+// 1/sqrt(a) and 1/a for finite a of order 1 (a = 1 + u^2 >= 1 here): hardware seed (v_rsq_f64 /
+// v_rcp_f64, ~23 bits) + two Newton steps in FMA form.  <= 1.5 ulp, against the <= 1 ulp of the
+// reference's 1.0 / sqrt(a); replaces the IEEE sqrt + divide sequences (~25 VALU instructions each).
+__device__ __forceinline__ double rsqrt_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    double h = 0.5 * y;
+    double e = fma(-a * y, h, 0.5);   // e = (1 - a y^2) / 2
+    y = fma(y, e, y);
+    h = 0.5 * y;
+    e = fma(-a * y, h, 0.5);
+    return fma(y, e, y);
+}
+
+__device__ __forceinline__ double rcp_nr(double a) {
+    double y = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    return fma(y, e, y);
+}
+
 // relativistic Boris rotation, core/pusher/unified/unified_pusher_2d.c:15-51
 __device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double &ig, double Ex,
                                       double Ey, double Ez, double Bx, double By, double Bz,
                                       double efactor, double bfactor) {
     double umx = ux + efactor * Ex, umy = uy + efactor * Ey, umz = uz + efactor * Ez;
-    double g = 1.0 / sqrt(1 + umx * umx + umy * umy + umz * umz);
+    double g = rsqrt_nr(1 + umx * umx + umy * umy + umz * umz);
     double Tx = bfactor * Bx * g, Ty = bfactor * By * g, Tz = bfactor * Bz * g;
     double upx = umx + umy * Tz - umz * Ty;
     double upy = umy + umz * Tx - umx * Tz;
     double upz = umz + umx * Ty - umy * Tx;
-    double Tf = 2.0 / (1 + Tx * Tx + Ty * Ty + Tz * Tz);
+    double Tf = 2.0 * rcp_nr(1 + Tx * Tx + Ty * Ty + Tz * Tz);
     double Sx = Tf * Tx, Sy = Tf * Ty, Sz = Tf * Tz;
     double px = umx + upy * Sz - upz * Sy;
     double py = umy + upz * Sx - upx * Sz;
@@ -120,7 +141,7 @@ __device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double
     ux = px + efactor * Ex;
     uy = py + efactor * Ey;
     uz = pz + efactor * Ez;
-    ig = 1.0 / sqrt(1 + ux * ux + uy * uy + uz * uz);
+    ig = rsqrt_nr(1 + ux * ux + uy * uy + uz * uz);
 }
 
 // One axis of the Esirkepov deposit on a 4-cell window (current/current_deposit.h:7-35,206-249).
@@ -135,8 +156,11 @@ struct AxisW {
     bool tail_zero; // dc == 0: the 4th window cell is outside the reference's loop (all its values are 0)
 };
 
-__device__ __forceinline__ void axis_window(AxisW &a, double r_old, double r_adv, double d) {
-    double o0 = r_old / d, o1 = r_adv / d;
+// `inv_d` = 1/d: the reference divides by d (current_deposit.h:201-204); multiplying by the reciprocal
+// differs by <= 1 ulp of the cell coordinate (<= 3e-13 cells at cell 1000) -- inside the stated
+// tolerances -- and saves four FP64 divisions (~45 VALU instructions) per particle.
+__device__ __forceinline__ void axis_window(AxisW &a, double r_old, double r_adv, double inv_d) {
+    double o0 = r_old * inv_d, o1 = r_adv * inv_d;
     int i0 = ifloor(o0 + 0.5), i1 = ifloor(o1 + 0.5);
     int dc = i1 - i0;
     double d0 = i0 - o0, d1 = i1 - o1;

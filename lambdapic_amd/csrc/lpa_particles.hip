@@ -87,8 +87,8 @@ __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, doub
                                                   double dt) {
     double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
     AxisW ax, ay;
-    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, g.dx);
-    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, g.dy);
+    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
+    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, 1.0 / g.dy);
     int rows[4], cols[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -284,8 +284,8 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             y += k.cdt_half * ig * uy;
             double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig;
             vz = uz * LPA_C * ig;
-            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, g.dx);
-            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, g.dy);
+            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
+            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
             int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
             b0 = bx * RSJ + by;
             double xs = x, ys = y;

@@ -63,9 +63,9 @@ __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, doub
                                                   double q, double dt) {
     double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
     AxisW ax, ay, az;
-    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, g.dx);
-    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, g.dy);
-    axis_window(az, z - vz * 0.5 * dt - g.z0, z + vz * 0.5 * dt - g.z0, g.dz);
+    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
+    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, 1.0 / g.dy);
+    axis_window(az, z - vz * 0.5 * dt - g.z0, z + vz * 0.5 * dt - g.z0, 1.0 / g.dz);
     const double one_third = 0.3333333333333333;  // core/utils/cutils.h:18
     double cd = (q / (g.dx * g.dy * g.dz)) * w;
     double fdx_ = (q / (g.dy * g.dz * dt)) * w;
