@@ -136,6 +136,36 @@ def step_split(patches, dt, species, hook=None):
     sync.sync_guard_fields_2d(fl, pl, E, n, nx, ny, ng)
 
 
+def step_3d_periodic(f, parts, dt, species, box_lo, box_hi):
+    """one 3-D step on ONE patch that is its own periodic neighbour (same stage order as `step`);
+    ``parts[ispec]`` are particle bags, ``box_lo/hi`` the particle box (-d/2, L - d/2) per axis."""
+    import oracle
+    from oracle import sync
+
+    E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+    oracle.update_efield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, E)
+    oracle.update_bfield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, B)
+    oracle.reset_current([f], 1)
+    for p, (q, m) in zip(parts, species):
+        oracle.unified_boris_pusher_cpu_3d([p], [f], 1, dt, q, m)
+    sync.periodic_current_fold(f)
+    for p in parts:   # Patches.sync_particles with a self neighbour: periodic shift of leavers
+        for a, lo, hi in zip(("x", "y", "z"), box_lo, box_hi):
+            v = getattr(p, a)
+            L = hi - lo
+            v[v > hi] -= L
+            v[v < lo] += L
+    oracle.update_bfield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, B)
+    oracle.update_efield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, E)
+
+
+def field_energy_3d(f) -> float:
+    s = (slice(0, f.nx), slice(0, f.ny), slice(0, f.nz))
+    e2 = f.ex[s] ** 2 + f.ey[s] ** 2 + f.ez[s] ** 2
+    b2 = f.bx[s] ** 2 + f.by[s] ** 2 + f.bz[s] ** 2
+    return float(np.sum(0.5 * EPSILON_0 * e2 + 0.5 / MU_0 * b2)) * f.dx * f.dy * f.dz
+
+
 def field_energy(patches) -> float:
     """sum over patch interiors of (eps0 E^2 + B^2/mu0)/2 * dx*dy
     (reference tests/test_numerical_heating.py:19-37)"""

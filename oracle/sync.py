@@ -151,3 +151,32 @@ def sync_particles_2d(patches, ispec, dx, dy, attrs=None):
         q.x[outside] = np.nan
         q.y[outside] = np.nan
     return npart_alive
+
+
+# -------------------------------------------------------------------------------------------------
+# one patch that is its own neighbour on every periodic axis (any dimension): what the sync
+# functions above reduce to for npatch = 1.  Used by the 3-D engine test; pinned to the reference
+# through the 2-D functions above (tests/test_oracle_golden.py::test_periodic_single_patch_twins).
+# -------------------------------------------------------------------------------------------------
+def periodic_guard_fill(f, attrs):
+    ng = f.n_guard
+    for a in attrs:
+        arr = getattr(f, a)
+        conv = np.roll(arr, ng, axis=tuple(range(arr.ndim)))
+        inner = conv[tuple(slice(ng, -ng) for _ in range(arr.ndim))]
+        arr[...] = np.roll(np.pad(inner, ng, mode="wrap"), -ng, axis=tuple(range(arr.ndim)))
+
+
+def periodic_current_fold(f):
+    ng = f.n_guard
+    for a in ("jx", "jy", "jz", "rho"):
+        arr = getattr(f, a)
+        nd = arr.ndim
+        conv = np.roll(arr, ng, axis=tuple(range(nd)))
+        n = [s - 2 * ng for s in conv.shape]
+        idx = np.ix_(*[(np.arange(s) - ng) % m for s, m in zip(conv.shape, n)])
+        out = np.zeros(n)
+        np.add.at(out, idx, conv)
+        conv[...] = 0.0
+        conv[tuple(slice(ng, -ng) for _ in range(nd))] = out
+        arr[...] = np.roll(conv, -ng, axis=tuple(range(nd)))

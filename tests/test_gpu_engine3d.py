@@ -1,0 +1,67 @@
+"""3-D resident step (FDTD 3-D, guard wrap / current fold in 3-D, fused 3-D push+deposit, periodic
+fold of positions) against the oracle's 3-D step on the same seeded plasma; two species (e- and a
+heavy positive one) so the deposit of both charges and the species loop are exercised.
+Tolerances as in 2-D: field energy 1e-10, charge / kinetic 1e-12, fields 1e-9 of the max."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import driver
+from helpers import assert_close
+from lambdapic_amd.engine3d import PicEngine3D
+from lambdapic_amd.fields import Fields3D
+from lambdapic_amd.particles import ParticlesBase
+
+pytestmark = pytest.mark.gpu
+C = 299792458.0
+
+
+def _species(rng, n, nx, ny, nz, dx, dy, dz, uth, w):
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx
+    p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    p.z[:] = rng.uniform(-0.5, nz - 0.5, n) * dz
+    for a in ("ux", "uy", "uz"):
+        getattr(p, a)[:] = rng.normal(size=n) * uth
+    p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+    p.w[:] = w
+    return p
+
+
+def test_3d_step_vs_oracle():
+    nx, ny, nz = 16, 12, 10
+    dx, dy, dz = 4e-8, 5e-8, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    rng = np.random.default_rng(21)
+    n = nx * ny * nz * 8
+    w = 1e27 * dx * dy * dz / 8
+    e = _species(rng, n, nx, ny, nz, dx, dy, dz, 0.3, w)        # hot: cell crossings, box wraps
+    ion = _species(rng, n, nx, ny, nz, dx, dy, dz, 0.001, w)
+    qe, me = -oracle.E_CHARGE, oracle.M_E
+    species = [(qe, me), (-qe, 1836.0 * me)]
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, 3)
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3)
+    eng.add_species(*species[0], e)
+    eng.add_species(*species[1], ion)
+    parts = [copy.deepcopy(e), copy.deepcopy(ion)]
+    lo = (-dx / 2, -dy / 2, -dz / 2)
+    hi = (nx * dx - dx / 2, ny * dy - dy / 2, nz * dz - dz / 2)
+    for it in range(12):
+        driver.step_3d_periodic(f, parts, dt, species, lo, hi)
+        eng.step(dt)
+        d = eng.diagnostics()
+        assert d["field_energy"] == pytest.approx(driver.field_energy_3d(f), rel=1e-10)
+        rho_sum = float(np.sum(f.rho[:nx, :ny, :nz])) * dx * dy * dz
+        assert abs(d["charge"] - rho_sum) <= 1e-12 * n * w * abs(qe)     # net charge ~ 0: absolute scale
+        for k, (q, m) in enumerate(species):
+            ke = float(np.sum(parts[k].w * (1 / parts[k].inv_gamma - 1))) * m * C ** 2
+            assert d["kinetic"][k] == pytest.approx(ke, rel=1e-12)
+            assert d["nalive"][k] == n
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+        assert_close(eng.download_field(a), getattr(f, a), 1e-9, what=a)
+    got = eng.download_species(0)
+    for a in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma"):
+        assert_close(got[a], getattr(parts[0], a), 1e-11, what=a)

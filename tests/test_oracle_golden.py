@@ -151,6 +151,27 @@ def test_g7_sync_fields_c_twin(golden):
             assert_close(getattr(p.fields, a), g[f"out{k}_{a}"], 1e-15, what=f"{k} {a}")
 
 
+def test_periodic_single_patch_twins():
+    """the N-D single-patch periodic fill / fold (used by the 3-D engine test) equal the
+    reference-pinned 2-D patch functions when the patch is its own neighbour"""
+    rng = np.random.default_rng(4)
+    P = make_patches_2d(12, 10, 1e-8, 1e-8, 1, 1)
+    Q = make_patches_2d(12, 10, 1e-8, 1e-8, 1, 1)
+    for a in P[0].fields.attrs:
+        v = rng.normal(size=P[0].fields.shape)
+        getattr(P[0].fields, a)[...] = v
+        getattr(Q[0].fields, a)[...] = v
+    E6 = ["ex", "ey", "ez", "bx", "by", "bz"]
+    sync.sync_guard_fields_2d([P[0].fields], list(P), E6, 1, 12, 10, 3)
+    sync.sync_currents_2d([P[0].fields], list(P), 1, 12, 10, 3)
+    sync.periodic_guard_fill(Q[0].fields, E6)
+    sync.periodic_current_fold(Q[0].fields)
+    for a in E6:
+        assert np.array_equal(getattr(P[0].fields, a), getattr(Q[0].fields, a)), a
+    for a in ["jx", "jy", "jz", "rho"]:
+        assert_close(getattr(Q[0].fields, a), getattr(P[0].fields, a), 1e-15, what=a)
+
+
 def test_g7_sync_particles(golden):
     g = golden("g7_sync_2d")
     P = _patches_from_g7(g)
