@@ -151,6 +151,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank path with ranks sharing GPUs (buffers staged "
+                         "through the host); the driver's runs use nccl (RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -160,11 +164,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: lambdapic_amd has no CPU path")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
     comm = SlabComm(None)
     assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
@@ -184,7 +191,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
