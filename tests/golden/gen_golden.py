@@ -376,6 +376,149 @@ def g8_trace(mx):
     np.savez_compressed(OUT / "g8_trace_2d.npz", **out)
 
 
+def load_ref_cpml():
+    """core/fields.py + core/boundary/cpml.py as plain Python (same numba binding as the FDTD)"""
+    load_ref_maxwell()                      # installs the numba / jit_spinner stand-ins
+    for name in ("lambdapic.core.boundary",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+
+    def load(mod, rel):
+        spec = importlib.util.spec_from_file_location(mod, REF / rel)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[mod] = m
+        spec.loader.exec_module(m)
+        return m
+
+    fields = load("lambdapic.core.fields", "core/fields.py")
+    cpml = load("lambdapic.core.boundary.cpml", "core/boundary/cpml.py")
+    return fields, cpml
+
+
+def load_ref_laser_kernel():
+    """only the boundary kernel _update_laser_bfields_2d of callback/laser.py (the module itself
+    imports the whole package); its source segment is executed here, never stored"""
+    import ast
+    src = (REF / "callback/laser.py").read_text()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_update_laser_bfields_2d")
+    fn.decorator_list = []
+    mod = ast.Module(body=[fn], type_ignores=[])
+    from scipy.constants import c, epsilon_0
+    ns = {"np": np, "NDArray": object, "prange": range, "c": c, "epsilon_0": epsilon_0}
+    exec(compile(ast.fix_missing_locations(mod), "laser_kernel", "exec"), ns)
+    return ns["_update_laser_bfields_2d"]
+
+
+def g9_cpml(mx):
+    """vacuum EM pulse in a 48x48 box, 3x3 patches of 16x16, PML (thickness 6) on all four sides:
+    the reference's PML classes + kappa-scaled updates on the edge patches, plain updates on the
+    centre patch, guard sync by the reference's C extension; 80 full Maxwell stages."""
+    RF, RC = load_ref_cpml()
+    sf = oracle.ref_module("patch", "sync_fields2d")
+    npx = npy = 3
+    nxp = nyp = 16
+    nx, ny, ng, th = npx * nxp, npy * nyp, 3, 6
+    dx, dy = 4e-8, 5e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    bc = {"xmin": "pml", "xmax": "pml", "ymin": "pml", "ymax": "pml"}
+    P = make_patches_2d(nx, ny, dx, dy, npx, npy, ng, boundary_conditions=bc)
+    for p in P:   # reference field bags (the PML classes isinstance-check them)
+        p.set_fields(RF.Fields2D(nxp, nyp, dx, dy, p.x0, p.y0, ng))
+        if p.ipatch_x == 0: p.pml_boundary.append(RC.PMLXmin(p.fields, thickness=th))
+        if p.ipatch_x == npx - 1: p.pml_boundary.append(RC.PMLXmax(p.fields, thickness=th))
+        if p.ipatch_y == 0: p.pml_boundary.append(RC.PMLYmin(p.fields, thickness=th))
+        if p.ipatch_y == npy - 1: p.pml_boundary.append(RC.PMLYmax(p.fields, thickness=th))
+    # initial condition: Gaussian blobs in ez, bz (both polarisations) + a weak random current
+    rng = np.random.default_rng(SEED + 9)
+    jglob = {a: rng.normal(size=(nx, ny)) * 1e13 for a in ("jx", "jy", "jz")}
+    for p in P:
+        f = p.fields
+        X, Y = f.xaxis[:nxp, :], f.yaxis[:, :nyp]
+        r2 = ((X - 0.45 * nx * dx) ** 2 + (Y - 0.55 * ny * dy) ** 2) / (4 * dx) ** 2
+        f.ez[:nxp, :nyp] = 1e12 * np.exp(-r2)
+        f.bz[:nxp, :nyp] = 2e3 * np.exp(-r2 * 1.3)
+        i0, j0 = p.ipatch_x * nxp, p.ipatch_y * nyp
+        for a in jglob:
+            getattr(f, a)[:nxp, :nyp] = jglob[a][i0:i0 + nxp, j0:j0 + nyp]
+    fl = [p.fields for p in P]
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, dt=dt, thickness=th, npx=npx, npy=npy, nsteps=80)
+    E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+    sf.sync_guard_fields_2d(fl, list(P), E + B, len(P), nxp, nyp, ng)
+
+    def glob(a):
+        G = np.zeros((nx, ny))
+        for p in P:
+            G[p.ipatch_x * nxp:(p.ipatch_x + 1) * nxp, p.ipatch_y * nyp:(p.ipatch_y + 1) * nyp] = \
+                getattr(p.fields, a)[:nxp, :nyp]
+        return G
+
+    for a in E + B + ["jx", "jy", "jz"]:
+        out["in_" + a] = glob(a)
+
+    def kappas(p):
+        ke_x = ke_y = kb_x = kb_y = None
+        first = p.pml_boundary[0]
+        ke_x, ke_y, kb_x, kb_y = first.kappa_ex, first.kappa_ey, first.kappa_bx, first.kappa_by
+        for pml in p.pml_boundary:        # core/maxwell/solver/solver.py:88-105
+            if isinstance(pml, RC.PMLX): ke_x, kb_x = pml.kappa_ex, pml.kappa_bx
+            elif isinstance(pml, RC.PMLY): ke_y, kb_y = pml.kappa_ey, pml.kappa_by
+        return ke_x, ke_y, kb_x, kb_y
+
+    def upd_e(h):
+        for p in P:
+            f = p.fields
+            if p.pml_boundary:
+                ke_x, ke_y, _, _ = kappas(p)
+                RC.update_efield_cpml_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, ke_x, ke_y,
+                                         dx, dy, h, nxp, nyp, ng)
+                for pml in p.pml_boundary:
+                    pml.advance_e_currents(h)
+            else:
+                mx.update_efield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, dx, dy, h, nxp, nyp, ng)
+
+    def upd_b(h):
+        for p in P:
+            f = p.fields
+            if p.pml_boundary:
+                _, _, kb_x, kb_y = kappas(p)
+                RC.update_bfield_cpml_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, kb_x, kb_y, dx, dy, h, nxp, nyp, ng)
+                for pml in p.pml_boundary:
+                    pml.advance_b_currents(h)
+            else:
+                mx.update_bfield_2d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, dx, dy, h, nxp, nyp, ng)
+
+    energy = []
+    for it in range(80):
+        upd_e(0.5 * dt); sf.sync_guard_fields_2d(fl, list(P), E, len(P), nxp, nyp, ng)
+        upd_b(0.5 * dt); sf.sync_guard_fields_2d(fl, list(P), B, len(P), nxp, nyp, ng)
+        if it == 2:   # the currents act for three steps, then vacuum
+            for f in fl:
+                f.jx[...] = 0; f.jy[...] = 0; f.jz[...] = 0
+        energy.append(sum(float(np.sum(0.5 * driver.EPSILON_0 * (f.ex[:nxp, :nyp] ** 2 + f.ey[:nxp, :nyp] ** 2 + f.ez[:nxp, :nyp] ** 2)
+                                        + 0.5 / driver.MU_0 * (f.bx[:nxp, :nyp] ** 2 + f.by[:nxp, :nyp] ** 2 + f.bz[:nxp, :nyp] ** 2))) for f in fl) * dx * dy)
+        if it in (9, 79):
+            for a in E + B:
+                out[f"step{it + 1}_{a}"] = glob(a)
+    out["trace_energy"] = np.array(energy)
+    np.savez_compressed(OUT / "g9_cpml_2d.npz", **out)
+
+
+def g10_laser(rng):
+    kern = load_ref_laser_kernel()
+    nx, ny, ng, dx, dy = 24, 20, 3, 4e-8, 5e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    f = Fields2D(nx, ny, dx, dy, 0.0, 0.0, ng)
+    for a in f.attrs[:9]:
+        getattr(f, a)[...] = rng.normal(size=f.shape) * (1e12 if a[0] == "e" else (1e4 if a[0] == "b" else 1e15))
+    ey_s, ez_s = rng.normal(size=ny + 2 * ng) * 1e12, rng.normal(size=ny + 2 * ng) * 1e12
+    out = dict(nx=nx, ny=ny, ng=ng, dx=dx, dy=dy, dt=dt, laserpos=8, iy_start=6, iy_end=ny - 6,
+               ey_source=ey_s, ez_source=ez_s)
+    out.update(snap(f, f.attrs[:9], "in_"))
+    kern(8, f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, dx, dy, dt, 6, ny - 6, ey_s, ez_s)
+    out.update(snap(f, ["bx", "by", "bz"], "out_"))
+    np.savez_compressed(OUT / "g10_laser_2d.npz", **out)
+
+
 def main():
     assert oracle.ref_available(), "run `make -C oracle ref` first"
     mx = load_ref_maxwell()
@@ -388,6 +531,8 @@ def main():
     g6_sort(rng)
     g7_sync(rng)
     g8_trace(mx)
+    g9_cpml(mx)
+    g10_laser(np.random.default_rng(SEED + 10))
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

@@ -245,3 +245,43 @@ def test_known_answers_charge_and_current():
     assert f.jx.sum() == pytest.approx(q * n * v[0], rel=1e-10)
     assert f.jy.sum() == pytest.approx(q * n * v[1], rel=1e-10)
     assert f.jz.sum() == pytest.approx(q * n * v[2], rel=1e-10)
+
+
+def test_g9_cpml_slab_vs_reference_patches(golden):
+    """the slab-level CPML restatement (one field bag, per-axis coefficient arrays) against the
+    reference's per-patch PML objects on 3x3 patches, 80 Maxwell stages with PML on all four
+    sides; interior fields agree to round-off (FMA-free on both sides: 1e-13 of the max)"""
+    from oracle import cpml
+    from lambdapic_amd.fields import Fields2D
+    g = golden("g9_cpml_2d")
+    nx, ny, ng = int(g["nx"]), int(g["ny"]), int(g["ng"])
+    dx, dy, dt = float(g["dx"]), float(g["dy"]), float(g["dt"])
+    f = Fields2D(nx, ny, dx, dy, 0.0, 0.0, ng)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
+        getattr(f, a)[:nx, :ny] = g["in_" + a]
+    pml = cpml.SlabPML2D(nx, ny, dx, dy, ("xmin", "xmax", "ymin", "ymax"), thickness=int(g["thickness"]))
+    I = (slice(0, nx), slice(0, ny))
+    en = []
+    for it in range(int(g["nsteps"])):
+        cpml.update_efield_cpml_2d(f, pml, 0.5 * dt)
+        cpml.update_bfield_cpml_2d(f, pml, 0.5 * dt)
+        if it == 2:
+            f.jx[...] = 0; f.jy[...] = 0; f.jz[...] = 0
+        en.append(float(np.sum(0.5 * oracle.EPSILON_0 * (f.ex[I] ** 2 + f.ey[I] ** 2 + f.ez[I] ** 2)
+                               + 0.5 / oracle.MU_0 * (f.bx[I] ** 2 + f.by[I] ** 2 + f.bz[I] ** 2))) * dx * dy)
+        if it + 1 in (10, 80):
+            for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+                assert_close(getattr(f, a)[I], g[f"step{it + 1}_{a}"], 1e-12,
+                             scale=np.abs(g[f"step10_{a}"]).max(), what=f"step {it + 1} {a}")
+    np.testing.assert_allclose(en, g["trace_energy"], rtol=1e-12)
+    assert en[-1] < 0.3 * en[0]           # the layer absorbs the outgoing pulse
+
+
+def test_g10_laser_injection_kernel(golden):
+    from oracle import cpml
+    g = golden("g10_laser_2d")
+    f = fields2d_from(g, "in_", 0.0, 0.0)
+    cpml.laser_inject_2d(f, int(g["laserpos"]), float(g["dt"]), int(g["iy_start"]), int(g["iy_end"]),
+                         g["ey_source"], g["ez_source"])
+    for a in ("bx", "by", "bz"):
+        assert_close(getattr(f, a), g["out_" + a], 1e-14, what=a)
