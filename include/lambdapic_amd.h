@@ -99,6 +99,34 @@ int lpa_fdtd_b_2d(const lpa_grid *g, double dt, void *stream);
 int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream);
 int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream);
 
+/* ---- CPML absorbing layers (core/boundary/cpml.py), slab form.
+ *      lpa_fdtd_*_cpml_2d : kappa-scaled Yee half steps (update_efield_cpml_2d / update_bfield_cpml_2d,
+ *                           cpml.py:343-377, driven by MaxwellSolver2D.update_efield/bfield,
+ *                           core/maxwell/solver/solver.py:154-190); kappa_*x [nx], kappa_*y [ny] are 1
+ *                           outside the layers, so one sweep covers the reference's mix of plain and
+ *                           PML patches.
+ *      lpa_cpml_psi_2d    : psi recursion + field correction of ONE layer (update_psi_{x,y}_and_{e,b}_2d,
+ *                           cpml.py:531-606): efield != 0 for the E form, axis 0/1 = layer normal,
+ *                           [start, stop) the layer's cells along it, bcoeff / ccoeff_d [n along axis]
+ *                           the coefficients of cpml.py:537-538 for this dt (host computed),
+ *                           psi_a / psi_b compact arrays [stop-start][ny] (axis 0) or [nx][stop-start]
+ *                           (axis 1): (psi_ey_x, psi_ez_x), (psi_ex_y, psi_ez_y), (psi_by_x, psi_bz_x),
+ *                           (psi_bx_y, psi_bz_y). */
+int lpa_fdtd_e_cpml_2d(const lpa_grid *g, double dt, double eps0, const double *kappa_ex,
+                       const double *kappa_ey, void *stream);
+int lpa_fdtd_b_cpml_2d(const lpa_grid *g, double dt, const double *kappa_bx, const double *kappa_by,
+                       void *stream);
+int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int start, int stop, double dt,
+                    const double *bcoeff, const double *ccoeff_d, double *psi_a, double *psi_b,
+                    void *stream);
+
+/* ---- laser injection through the x-min boundary (replaces _update_laser_bfields_2d,
+ *      callback/laser.py:17-46, called by Laser.__call__ at stage '_laser', :109-137):
+ *      ey_source / ez_source [ny] are the source fields on the boundary at the current time,
+ *      rows iy in [iy_start, iy_end) are driven. */
+int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
+                        int iy_end, const double *ey_source, const double *ez_source, void *stream);
+
 /* ---- zero jx jy jz rho including guards (replaces reset_current_cpu_2d/3d,
  *      core/current/cpu2d.c:19-72, cpu3d.c:185-240) */
 int lpa_reset_current(const lpa_grid *g, void *stream);
@@ -138,9 +166,15 @@ int lpa_halo_unpack_current(const lpa_grid *g, int side, const double *buf, void
  *      core/patch/sync_particles_2d.c:168-182) -- the fused form of the periodic migration. */
 typedef struct {
     double dt, q, m;
-    int32_t wrap;              /* bit 0: x, bit 1: y (bit 2: z) */
+    int32_t wrap;              /* bits 0..2: periodic fold of x, y, z into [lo, hi];
+                                  bits 4..6 (LPA_ABSORB_X << axis): kill (x = y = NaN) a particle that is
+                                  outside [alo, ahi] on that axis after the deposit -- the open / PML
+                                  edge rule of mark_out_of_bound_as_dead
+                                  (core/patch/sync_particles_2d.c:185-202, bounds core/patch/patch.py:105-148) */
     double lo[3], hi[3];       /* global particle box: lo = -d/2, hi = L - d/2 */
+    double alo[3], ahi[3];     /* absorption bounds (only read where the absorb bit is set) */
 } lpa_push_params;
+#define LPA_ABSORB_X 16
 
 int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                         int64_t first, int64_t count, void *stream);

@@ -19,6 +19,7 @@ LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1
 LPA_TILE_MARGIN = 1
 LPA_MIG_NATTR = 9
+LPA_ABSORB_X = 16
 
 
 class LpaError(RuntimeError):
@@ -47,7 +48,8 @@ class lpa_tiling(C.Structure):
 
 class lpa_push_params(C.Structure):
     _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32),
-                ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+                ("lo", C.c_double * 3), ("hi", C.c_double * 3),
+                ("alo", C.c_double * 3), ("ahi", C.c_double * 3)]
 
 
 _G, _P, _T, _PP = C.POINTER(lpa_grid), C.POINTER(lpa_particles), C.POINTER(lpa_tiling), C.POINTER(lpa_push_params)
@@ -61,6 +63,10 @@ SIGNATURES = {
     "lpa_fdtd_b_2d": (_i, [_G, _d, _vp]),
     "lpa_fdtd_e_3d": (_i, [_G, _d, _d, _vp]),
     "lpa_fdtd_b_3d": (_i, [_G, _d, _vp]),
+    "lpa_fdtd_e_cpml_2d": (_i, [_G, _d, _d, _vp, _vp, _vp]),
+    "lpa_fdtd_b_cpml_2d": (_i, [_G, _d, _vp, _vp, _vp]),
+    "lpa_cpml_psi_2d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "lpa_laser_inject_2d": (_i, [_G, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
     "lpa_reset_current": (_i, [_G, _vp]),
     "lpa_guard_wrap": (_i, [_G, _i, _i, _vp]),
     "lpa_current_fold": (_i, [_G, _i, _vp]),

@@ -116,6 +116,168 @@ extern "C" int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream) {
 }
 
 // =====================================================================================================
+// CPML absorbing layers (core/boundary/cpml.py).  The reference attaches PML objects to edge patches and
+// runs (a) a kappa-scaled Yee update on every patch that has one (cpml.py:343-377; kappa == 1 outside
+// the layer, so it equals the plain update there) and (b) the psi recursions on the layer's cells
+// (cpml.py:531-606).  On one slab per rank this is one kappa-scaled sweep with per-axis kappa arrays
+// over the whole slab + one small kernel per layer.  bcoeff / ccoeff_d (cpml.py:537-538) depend only on
+// the cell index along the layer normal and on dt: the host passes them as arrays.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_fdtd_e_cpml_2d(GridV g, double bfac, double jfac,
+                                                        const double *__restrict__ kx,
+                                                        const double *__restrict__ ky) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xm = c - g.NY, ym = c - 1;
+    double bfx = bfac / kx[i], bfy = bfac / ky[j];
+    double bzc = g.bz[c];
+    g.ex[c] += bfy * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c];
+    g.ey[c] += bfx * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    g.ez[c] += bfx * ((g.by[c] - g.by[xm]) / g.dx) - bfy * ((g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_2d(GridV g, double dt, const double *__restrict__ kx,
+                                                        const double *__restrict__ ky) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xp = c + g.NY, yp = c + 1;
+    double efx = dt / kx[i], efy = dt / ky[j];
+    double ezc = g.ez[c];
+    g.bx[c] -= efy * ((g.ez[yp] - ezc) / g.dy);
+    g.by[c] -= efx * (-(g.ez[xp] - ezc) / g.dx);
+    g.bz[c] -= efx * ((g.ey[xp] - g.ey[c]) / g.dx) - efy * ((g.ex[yp] - g.ex[c]) / g.dy);
+}
+
+// psi recursion of one layer.  AXIS 0: cells (ipos, t) with ipos in [start, stop), t over ny;
+// AXIS 1: cells (t, ipos) with t over nx.  psi is compact: [stop-start][ny] resp. [nx][stop-start].
+// EFIELD: psi_a/psi_b = (psi_ey_x, psi_ez_x) or (psi_ex_y, psi_ez_y); else the B twins.
+template <int AXIS, bool EFIELD>
+__global__ void __launch_bounds__(256) k_cpml_psi_2d(GridV g, int start, int stop, double fac,
+                                                     const double *__restrict__ bco,
+                                                     const double *__restrict__ cco, double *psi_a,
+                                                     double *psi_b) {
+    int nt = AXIS == 0 ? g.ny : g.nx, nl = stop - start;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int l = blockIdx.y;
+    if (t >= nt || l >= nl) return;
+    int ipos = start + l;
+    int i = AXIS == 0 ? ipos : t, j = AXIS == 0 ? t : ipos;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long step = AXIS == 0 ? g.NY : 1;
+    long ps = AXIS == 0 ? (long)l * g.ny + t : (long)t * nl + l;
+    double b = bco[ipos], cc = cco[ipos];
+    if (EFIELD) {
+        // x layer (cpml.py:531-548): psi_ey_x <- bz, psi_ez_x <- by; ey -= fac psi, ez += fac psi
+        // y layer (cpml.py:569-586): psi_ex_y <- bz, psi_ez_y <- bx; ex += fac psi, ez -= fac psi
+        const double *f1 = g.bz, *f2 = AXIS == 0 ? g.by : g.bx;
+        double pa = b * psi_a[ps] + cc * (f1[c] - f1[c - step]);
+        double pb = b * psi_b[ps] + cc * (f2[c] - f2[c - step]);
+        psi_a[ps] = pa;
+        psi_b[ps] = pb;
+        if (AXIS == 0) { g.ey[c] -= fac * pa; g.ez[c] += fac * pb; }
+        else { g.ex[c] += fac * pa; g.ez[c] -= fac * pb; }
+    } else {
+        // x layer (cpml.py:550-567): psi_by_x <- ez, psi_bz_x <- ey; by += fac psi, bz -= fac psi
+        // y layer (cpml.py:588-606): psi_bx_y <- ez, psi_bz_y <- ex; bx -= fac psi, bz += fac psi
+        const double *f1 = g.ez, *f2 = AXIS == 0 ? g.ey : g.ex;
+        double pa = b * psi_a[ps] + cc * (f1[c + step] - f1[c]);
+        double pb = b * psi_b[ps] + cc * (f2[c + step] - f2[c]);
+        psi_a[ps] = pa;
+        psi_b[ps] = pb;
+        if (AXIS == 0) { g.by[c] += fac * pa; g.bz[c] -= fac * pb; }
+        else { g.bx[c] -= fac * pa; g.bz[c] += fac * pb; }
+    }
+}
+
+extern "C" int lpa_fdtd_e_cpml_2d(const lpa_grid *g, double dt, double eps0, const double *kappa_ex,
+                                  const double *kappa_ey, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1) && eps0 > 0 && kappa_ex && kappa_ey, "lpa_fdtd_e_cpml_2d: bad args");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_cpml_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
+                       dt / eps0, kappa_ex, kappa_ey);
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_cpml_2d(const lpa_grid *g, double dt, const double *kappa_bx,
+                                  const double *kappa_by, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && kappa_bx && kappa_by, "lpa_fdtd_b_cpml_2d: bad args");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_cpml_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, kappa_bx, kappa_by);
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int start, int stop, double dt,
+                               const double *bcoeff, const double *ccoeff_d, double *psi_a, double *psi_b,
+                               void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && (axis == 0 || axis == 1) && bcoeff && ccoeff_d && psi_a && psi_b,
+                "lpa_cpml_psi_2d: bad args");
+    int n = axis == 0 ? g->nx : g->ny, nt = axis == 0 ? g->ny : g->nx;
+    // the E recursion reads node start-1 (the low guard when start == 0), the B one node stop
+    LPA_REQUIRE(start >= 0 && stop > start && stop <= n, "lpa_cpml_psi_2d: layer [%d,%d) outside [0,%d)",
+                start, stop, n);
+    GridV v = make_gridv(g, 2);
+    dim3 grid((nt + 255) / 256, stop - start);
+    hipStream_t st = (hipStream_t)stream;
+    double fac = efield ? dt * (LPA_C * LPA_C) : dt;
+    if (efield && axis == 0) hipLaunchKernelGGL((k_cpml_psi_2d<0, true>), grid, dim3(256), 0, st, v, start, stop, fac, bcoeff, ccoeff_d, psi_a, psi_b);
+    else if (efield) hipLaunchKernelGGL((k_cpml_psi_2d<1, true>), grid, dim3(256), 0, st, v, start, stop, fac, bcoeff, ccoeff_d, psi_a, psi_b);
+    else if (axis == 0) hipLaunchKernelGGL((k_cpml_psi_2d<0, false>), grid, dim3(256), 0, st, v, start, stop, fac, bcoeff, ccoeff_d, psi_a, psi_b);
+    else hipLaunchKernelGGL((k_cpml_psi_2d<1, false>), grid, dim3(256), 0, st, v, start, stop, fac, bcoeff, ccoeff_d, psi_a, psi_b);
+    LPA_CHECK_LAUNCH("lpa_cpml_psi_2d");
+    return LPA_OK;
+}
+
+// =====================================================================================================
+// laser injection at the x-min boundary (callback/laser.py:17-46): Mur-type condition on bz, by (and a
+// copy of bx) on the node row laserpos-1, driven by the source fields ey_source, ez_source [ny].
+// All right-hand sides are read from rows 0, -1 (low guard) and laserpos, never from row laserpos-1.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_laser_inject_2d(GridV g, int lp, double dt, double eps0,
+                                                         int iy0, int iy1,
+                                                         const double *__restrict__ eys,
+                                                         const double *__restrict__ ezs) {
+    int j = iy0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= iy1) return;
+    const double c = LPA_C;
+    long r0 = (long)g.ng * g.NY + (j + g.ng);          // row 0
+    long rm = r0 - g.NY;                                // row -1 (low guard)
+    long rl = (long)(lp + g.ng) * g.NY + (j + g.ng);    // row laserpos
+    long rt = rl - g.NY;                                // row laserpos - 1
+    double k = 1 / ((c * dt / g.dx + 1) * c);
+    double bxv = g.bx[r0];
+    double bzv = k * (+4 * eys[j] + 2 * (g.ey[r0] + c * 0.5 * (g.bz[r0] + g.bz[rm])) - 2 * g.ey[rl] +
+                      dt / eps0 * g.jy[rl] + (c * dt / g.dx - 1) * c * g.bz[rl]);
+    double byv = k * (-4 * ezs[j] - 2 * (g.ez[r0] - c * 0.5 * (g.by[r0] + g.by[rm])) + 2 * g.ez[rl] -
+                      (dt * (c * c)) * (g.bx[rl] - g.bx[rl - 1]) / g.dy - dt / eps0 * g.jz[rl] +
+                      (c * dt / g.dx - 1) * c * g.by[rl]);
+    g.bx[rt] = bxv;
+    g.bz[rt] = bzv;
+    g.by[rt] = byv;
+}
+
+extern "C" int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
+                                   int iy_end, const double *ey_source, const double *ez_source,
+                                   void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1) && ey_source && ez_source && eps0 > 0, "lpa_laser_inject_2d: bad args");
+    LPA_REQUIRE(laserpos >= 2 && laserpos < g->nx && iy_start >= 0 && iy_end <= g->ny,
+                "lpa_laser_inject_2d: laserpos / iy range outside the slab");
+    if (iy_end <= iy_start) return LPA_OK;
+    GridV v = make_gridv(g, 2);
+    hipLaunchKernelGGL(k_laser_inject_2d, dim3((iy_end - iy_start + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, v, laserpos, dt, eps0, iy_start, iy_end, ey_source, ez_source);
+    LPA_CHECK_LAUNCH("lpa_laser_inject_2d");
+    return LPA_OK;
+}
+
+// =====================================================================================================
 // current reset (core/current/cpu2d.c:19-72): memset of the four arrays including guards
 // =====================================================================================================
 extern "C" int lpa_reset_current(const lpa_grid *g, void *stream) {

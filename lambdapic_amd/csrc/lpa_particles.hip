@@ -20,7 +20,7 @@ struct PushK {
     double dt, q, m;
     double efactor, bfactor, cdt_half;
     int wrap;
-    double lo[3], hi[3];
+    double lo[3], hi[3], alo[3], ahi[3];
 };
 
 static PushK make_pushk(const lpa_push_params *pp) {
@@ -30,8 +30,22 @@ static PushK make_pushk(const lpa_push_params *pp) {
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
     k.cdt_half = LPA_C * 0.5 * pp->dt;
     k.wrap = pp->wrap;
-    for (int a = 0; a < 3; a++) { k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a]; }
+    for (int a = 0; a < 3; a++) {
+        k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
+        k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
+    }
     return k;
+}
+
+// periodic fold and / or absorption of the advanced position (what sync_particles does after the
+// deposit: core/patch/sync_particles_2d.c:168-202); an absorbed particle becomes a dead slot (NaN)
+__device__ __forceinline__ void finish_position_2d(double &x, double &y, const PushK &k) {
+    double L;
+    if (k.wrap & 1) { L = k.hi[0] - k.lo[0]; if (x > k.hi[0]) x -= L; if (x < k.lo[0]) x += L; }
+    if (k.wrap & 2) { L = k.hi[1] - k.lo[1]; if (y > k.hi[1]) y -= L; if (y < k.lo[1]) y += L; }
+    bool dead = ((k.wrap & LPA_ABSORB_X) && (x < k.alo[0] || x > k.ahi[0])) ||
+                ((k.wrap & (LPA_ABSORB_X << 1)) && (y < k.alo[1] || y > k.ahi[1]));
+    if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; }
 }
 
 // periodic fold of a coordinate into [lo, hi] (sync_particles_2d.c:168-182 with a self neighbour)
@@ -122,8 +136,7 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     x += k.cdt_half * ig * ux;
     y += k.cdt_half * ig * uy;
     deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt);
-    if (k.wrap & 1) x = fold_coord(x, k.lo[0], k.hi[0]);
-    if (k.wrap & 2) y = fold_coord(y, k.lo[1], k.hi[1]);
+    finish_position_2d(x, y, k);
     p.x[ip] = x; p.y[ip] = y;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
@@ -289,8 +302,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
-            if (k.wrap & 1) xs = fold_coord(x, k.lo[0], k.hi[0]);
-            if (k.wrap & 2) ys = fold_coord(y, k.lo[1], k.hi[1]);
+            finish_position_2d(xs, ys, k);
             p.x[ip] = xs; p.y[ip] = ys;
             p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
         } else {
@@ -535,8 +547,10 @@ __global__ void __launch_bounds__(256) k_wrap_positions_2d(PartV p, PushK k) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= p.n) return;
     if (p.dead && p.dead[ip]) return;
-    if (k.wrap & 1) { double x = p.x[ip]; if (!isnan(x)) p.x[ip] = fold_coord(x, k.lo[0], k.hi[0]); }
-    if (k.wrap & 2) { double y = p.y[ip]; if (!isnan(y)) p.y[ip] = fold_coord(y, k.lo[1], k.hi[1]); }
+    double x = p.x[ip], y = p.y[ip];
+    if (isnan(x) || isnan(y)) return;
+    finish_position_2d(x, y, k);
+    p.x[ip] = x; p.y[ip] = y;
 }
 
 extern "C" int lpa_wrap_positions_2d(const lpa_particles *p, const lpa_push_params *pp, void *stream) {

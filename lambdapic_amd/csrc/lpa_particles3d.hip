@@ -8,7 +8,7 @@
 struct PushK3 {
     double dt, q, efactor, bfactor, cdt_half;
     int wrap;
-    double lo[3], hi[3];
+    double lo[3], hi[3], alo[3], ahi[3];
 };
 
 struct GIdx3 { long r[3]; int c[3]; int d[3]; };
@@ -154,6 +154,14 @@ __global__ void __launch_bounds__(256) k_push_deposit_global_3d(GridV g, PartV p
     if (k.wrap & 1) x = fold3(x, k.lo[0], k.hi[0]);
     if (k.wrap & 2) y = fold3(y, k.lo[1], k.hi[1]);
     if (k.wrap & 4) z = fold3(z, k.lo[2], k.hi[2]);
+    {
+        bool dead = false;
+        double c3[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            dead = dead || ((k.wrap & (LPA_ABSORB_X << a)) && (c3[a] < k.alo[a] || c3[a] > k.ahi[a]));
+        if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; z = x; }
+    }
     p.x[ip] = x; p.y[ip] = y; p.z[ip] = z;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
@@ -171,7 +179,10 @@ extern "C" int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, co
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
     k.cdt_half = LPA_C * 0.5 * pp->dt;
     k.wrap = pp->wrap;
-    for (int a = 0; a < 3; a++) { k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a]; }
+    for (int a = 0; a < 3; a++) {
+        k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
+        k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
+    }
     long nb = (count + 255) / 256;
     hipLaunchKernelGGL(k_push_deposit_global_3d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
                        make_gridv(g, 3), make_partv(p), k, (long)first, (long)count);

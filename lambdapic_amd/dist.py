@@ -23,8 +23,17 @@ class SlabComm:
         else:
             self.group, self.rank, self.size = None, 0, 1
         self.periodic = periodic
-        self.left = (self.rank - 1) % self.size
-        self.right = (self.rank + 1) % self.size
+        # ring (periodic x) or chain (open / PML x edges: the end ranks have one neighbour)
+        self.left = (self.rank - 1) % self.size if (periodic or self.rank > 0) else -1
+        self.right = (self.rank + 1) % self.size if (periodic or self.rank < self.size - 1) else -1
+
+    @property
+    def has_left(self):
+        return self.size > 1 and self.left >= 0
+
+    @property
+    def has_right(self):
+        return self.size > 1 and self.right >= 0
 
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
         """send_lo -> left neighbour, send_hi -> right neighbour; recv_lo <- left, recv_hi <- right.
@@ -37,8 +46,9 @@ class SlabComm:
         one GPU in a test) device tensors are staged through host memory.
         """
         if self.size == 1:
-            recv_lo.copy_(send_hi)   # my own high edge is my low guard's periodic source
-            recv_hi.copy_(send_lo)
+            if self.periodic:
+                recv_lo.copy_(send_hi)   # my own high edge is my low guard's periodic source
+                recv_hi.copy_(send_lo)
             return []
         staged = send_lo.is_cuda and dist.get_backend(self.group) == "gloo"
         if staged:
@@ -46,19 +56,23 @@ class SlabComm:
             r_lo, r_hi = torch.empty_like(s_lo), torch.empty_like(s_hi)
         else:
             s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
-        ops = [
-            dist.P2POp(dist.isend, s_hi, self.right, self.group, tag=1),
-            dist.P2POp(dist.isend, s_lo, self.left, self.group, tag=0),
-            dist.P2POp(dist.irecv, r_lo, self.left, self.group, tag=1),
-            dist.P2POp(dist.irecv, r_hi, self.right, self.group, tag=0),
-        ]
-        reqs = dist.batch_isend_irecv(ops)
+        ops = []
+        if self.has_right:
+            ops.append(dist.P2POp(dist.isend, s_hi, self.right, self.group, tag=1))
+        if self.has_left:
+            ops.append(dist.P2POp(dist.isend, s_lo, self.left, self.group, tag=0))
+            ops.append(dist.P2POp(dist.irecv, r_lo, self.left, self.group, tag=1))
+        if self.has_right:
+            ops.append(dist.P2POp(dist.irecv, r_hi, self.right, self.group, tag=0))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
         if wait or staged:
             for r in reqs:
                 r.wait()
             if staged:
-                recv_lo.copy_(r_lo)
-                recv_hi.copy_(r_hi)
+                if self.has_left:
+                    recv_lo.copy_(r_lo)
+                if self.has_right:
+                    recv_hi.copy_(r_hi)
         return reqs
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
@@ -86,5 +100,8 @@ def exchange_faces(comm: SlabComm, pack, unpack, bufs):
     pack(0, bufs["s_lo"])
     pack(1, bufs["s_hi"])
     comm.exchange(bufs["s_lo"], bufs["s_hi"], bufs["r_lo"], bufs["r_hi"])
-    unpack(0, bufs["r_lo"])
-    unpack(1, bufs["r_hi"])
+    single = comm.size == 1 and comm.periodic
+    if comm.has_left or single:      # nothing arrives through an open (PML) face
+        unpack(0, bufs["r_lo"])
+    if comm.has_right or single:
+        unpack(1, bufs["r_hi"])

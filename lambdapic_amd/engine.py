@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib, constants
@@ -29,20 +30,88 @@ from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr
 from .dist import SlabComm, exchange_faces
 
 
+class DevicePML2D:
+    """CPML coefficients and psi arrays of one rank's slab (reference: per-patch ``PML`` objects,
+    `core/boundary/cpml.py:23-340`; slab mapping as in oracle/cpml.py).  Host builds the per-axis
+    kappa / sigma / a profiles; bcoeff / ccoeff_d (`cpml.py:537-538`) are cached per dt."""
+
+    def __init__(self, nx, ny, dx, dy, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7):
+        self.nx, self.ny, self.dx, self.dy, self.t = nx, ny, dx, dy, int(thickness)
+        self.sides, self.device = set(sides), device
+        m, ma = 3, 1
+        smax = sigma_max * constants.C_LIGHT * 0.8 * (m + 1.0) / dx      # cpml.py:60 (dx for every axis)
+        self.host = {}
+        for ax, n in (("x", nx), ("y", ny)):
+            for fld in ("e", "b"):
+                self.host[fld + ax] = dict(kappa=np.ones(n), sigma=np.zeros(n), a=np.zeros(n))
+
+            def fill(fld, pos, sl, ax=ax):
+                c = self.host[fld + ax]
+                c["kappa"][sl] = 1 + (kappa_max - 1) * pos ** m           # cpml.py:119-125
+                c["sigma"][sl] = smax * pos ** m
+                c["a"][sl] = a_max * (1 - pos) ** ma
+
+            ar = np.arange(self.t, dtype=float)
+            if ax + "min" in self.sides:                                   # cpml.py:233-250,271-287
+                fill("e", 1.0 - ar / self.t, np.s_[:self.t])
+                fill("b", 1.0 - (ar + 0.5) / self.t, np.s_[:self.t])
+            if ax + "max" in self.sides:                                   # cpml.py:253-269,289-305
+                fill("e", 1.0 - ar[::-1] / self.t, np.s_[n - self.t:n])
+                fill("b", 1.0 - (ar + 0.5)[::-1] / self.t, np.s_[n - self.t - 1:n - 1])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.kappa = {k: dev(v["kappa"]) for k, v in self.host.items()}
+        # layers: (efield?, axis, start, stop, psi_a, psi_b); x layers first, then y (cpml.py order of
+        # pml_boundary: simulation.py:455-463)
+        self.layers = []
+        for fld in ("e", "b"):
+            for axis, ax, n, nt in ((0, "x", nx, ny), (1, "y", ny, nx)):
+                rng = []
+                if ax + "min" in self.sides:
+                    rng.append((0, self.t))
+                if ax + "max" in self.sides:
+                    rng.append((n - self.t, n) if fld == "e" else (n - self.t - 1, n - 1))
+                for s0, s1 in rng:
+                    z = lambda: torch.zeros((s1 - s0) * nt, dtype=torch.float64, device=device)
+                    self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
+                                            psi_a=z(), psi_b=z()))
+        self._coef = {}
+
+    def coef(self, key, dt, d):
+        k = (key, dt)
+        if k not in self._coef:
+            c = self.host[key]
+            kap, sig, a = c["kappa"], c["sigma"], c["a"]
+            b = np.exp(-(sig / kap + a) * dt)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cc = (b - 1) * sig / kap / (sig + kap * a) / d
+            cc = np.where(np.isfinite(cc), cc, 0.0)
+            mk = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
+            self._coef[k] = (mk(b), mk(cc))
+        return self._coef[k]
+
+
 class PicEngine2D:
     def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
                  x0=0.0, y0=0.0, sort_interval=8, block_particles=8192, migrate_capacity=32768,
-                 periodic_x=True, periodic_y=True, order=_lib.LPA_ORDER_STRIPED):
+                 boundary_conditions=None, cpml_thickness=6, order=_lib.LPA_ORDER_STRIPED):
         """``nx`` is the LOCAL number of cells along x (this rank's slab); the global box has
         ``nx * comm.size`` cells and this slab starts at ``x0 + rank*nx*dx``."""
         self.L = lib()
-        self.comm = comm or SlabComm(None)
+        bc = dict(boundary_conditions or {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")})
+        for axis in "xy":
+            pair = (bc[axis + "min"], bc[axis + "max"])
+            if any(v not in ("periodic", "pml") for v in pair) or (("periodic" in pair) and pair[0] != pair[1]):
+                raise ValueError(f"boundary conditions of {axis}: both 'periodic' or each 'pml', got {pair}")
+        self.bc = bc
+        self.periodic_x, self.periodic_y = bc["xmin"] == "periodic", bc["ymin"] == "periodic"
+        self.comm = comm or SlabComm(None, periodic=self.periodic_x)
+        if self.comm.periodic != self.periodic_x:
+            raise ValueError("SlabComm(periodic=...) must match the x boundary condition")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LpaError("PicEngine2D needs a GPU device; there is no CPU path")
         self.nx, self.ny, self.dx, self.dy, self.ng = int(nx), int(ny), float(dx), float(dy), int(n_guard)
-        if not (periodic_x and periodic_y):
-            raise NotImplementedError("only periodic boundaries in this round (CPML: SURVEY 8f-1)")
+        self.cpml_thickness = int(cpml_thickness)
         self.x0_global, self.y0 = float(x0), float(y0)
         self.x0 = self.x0_global + self.comm.rank * self.nx * self.dx
         self.Lx, self.Ly = self.nx * self.comm.size * self.dx, self.ny * self.dy
@@ -52,8 +121,30 @@ class PicEngine2D:
         self.block_particles = int(block_particles)
         self.migrate_capacity = int(migrate_capacity)
         self.order = int(order)   # LPA_ORDER_STRIPED (conflict-free LDS atomics) or LPA_ORDER_CELL_MAJOR
-        # axes handled by local periodic wrap: y always; x only when this rank owns the whole box
-        self.local_axes = 2 | (1 if self.comm.size == 1 else 0)
+        # axes handled by a local periodic wrap: y if periodic; x only when periodic AND this rank owns
+        # the whole box
+        self.local_axes = (2 if self.periodic_y else 0) | (1 if (self.periodic_x and self.comm.size == 1) else 0)
+        # CPML layers owned by this rank: x faces only on the end ranks
+        sides = [s for s in ("ymin", "ymax") if bc[s] == "pml"]
+        if bc["xmin"] == "pml" and self.comm.rank == 0:
+            sides.append("xmin")
+        if bc["xmax"] == "pml" and self.comm.rank == self.comm.size - 1:
+            sides.append("xmax")
+        self.pml = DevicePML2D(self.nx, self.ny, self.dx, self.dy, sides, self.cpml_thickness,
+                               self.device) if sides else None
+        # particle absorption at open (PML) faces: the owner's bounds are pulled in by the layer
+        # thickness (core/patch/patch.py:105-148) and a particle beyond them has no neighbour to go to
+        self.absorb = 0
+        self.alo, self.ahi = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
+        t = self.cpml_thickness
+        if not self.periodic_x:
+            self.absorb |= _lib.LPA_ABSORB_X
+            self.alo[0] = self.x0_global + t * self.dx - self.dx / 2
+            self.ahi[0] = self.x0_global + (self.nx * self.comm.size - 1 - t) * self.dx + self.dx / 2
+        if not self.periodic_y:
+            self.absorb |= _lib.LPA_ABSORB_X << 1
+            self.alo[1] = self.y0 + t * self.dy - self.dy / 2
+            self.ahi[1] = self.y0 + (self.ny - 1 - t) * self.dy + self.dy / 2
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._ws = {}
         self._halo = None
@@ -79,10 +170,47 @@ class PicEngine2D:
 
     # ---- Maxwell (MaxwellSolver2D.update_efield/bfield, core/maxwell/solver/solver.py:143-190) ----
     def update_efield(self, dt):
-        check(self.L.lpa_fdtd_e_2d(self._g(), dt, self.eps0, self.stream), "lpa_fdtd_e_2d")
+        if self.pml is None:
+            check(self.L.lpa_fdtd_e_2d(self._g(), dt, self.eps0, self.stream), "lpa_fdtd_e_2d")
+            return
+        p, st = self.pml, self.stream
+        check(self.L.lpa_fdtd_e_cpml_2d(self._g(), dt, self.eps0, p.kappa["ex"].data_ptr(),
+                                        p.kappa["ey"].data_ptr(), st), "lpa_fdtd_e_cpml_2d")
+        self._psi(True, dt)
 
     def update_bfield(self, dt):
-        check(self.L.lpa_fdtd_b_2d(self._g(), dt, self.stream), "lpa_fdtd_b_2d")
+        if self.pml is None:
+            check(self.L.lpa_fdtd_b_2d(self._g(), dt, self.stream), "lpa_fdtd_b_2d")
+            return
+        p, st = self.pml, self.stream
+        check(self.L.lpa_fdtd_b_cpml_2d(self._g(), dt, p.kappa["bx"].data_ptr(), p.kappa["by"].data_ptr(), st),
+              "lpa_fdtd_b_cpml_2d")
+        self._psi(False, dt)
+
+    def _psi(self, efield, dt):
+        for ly in self.pml.layers:
+            if ly["e"] != efield:
+                continue
+            b, cc = self.pml.coef(ly["key"], dt, self.dx if ly["axis"] == 0 else self.dy)
+            check(self.L.lpa_cpml_psi_2d(self._g(), int(efield), ly["axis"], ly["start"], ly["stop"], dt,
+                                         b.data_ptr(), cc.data_ptr(), ly["psi_a"].data_ptr(),
+                                         ly["psi_b"].data_ptr(), self.stream), "lpa_cpml_psi_2d")
+
+    # ---- laser injection (Laser.__call__ at stage '_laser', callback/laser.py:109-137) -------------
+    def laser_inject(self, ey_source, ez_source, dt):
+        """``ey_source, ez_source``: host or device arrays [ny] of the source fields on the x-min
+        boundary at the current time.  Only the rank that owns the x-min layer injects."""
+        if self.pml is None or "xmin" not in self.pml.sides:
+            return
+        t = self.cpml_thickness
+        iy0 = t if self.bc["ymin"] == "pml" else 0
+        iy1 = self.ny - t if self.bc["ymax"] == "pml" else self.ny
+        to = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(
+            self.device, torch.float64)
+        ey, ez = to(ey_source), to(ez_source)
+        check(self.L.lpa_laser_inject_2d(self._g(), t + 2, dt, self.eps0, iy0, iy1, ey.data_ptr(), ez.data_ptr(),
+                                         self.stream), "lpa_laser_inject_2d")
+        self._keep = (ey, ez)   # keep the buffers alive until the stream has consumed them
 
     # ---- guard cells (Patches.sync_guard_fields + MPIManager.sync_guard_fields_start/_wait) --------
     def _halo_bufs(self):
@@ -181,7 +309,9 @@ class PicEngine2D:
     def _push_params(self, sp, dt):
         pp = _lib.lpa_push_params()
         pp.dt, pp.q, pp.m = dt, sp.q, sp.m
-        pp.wrap = self.local_axes
+        pp.wrap = self.local_axes | self.absorb
+        for a in range(3):
+            pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
         pp.lo[0], pp.hi[0] = self.x0_global - self.dx / 2, self.x0_global + self.Lx - self.dx / 2
         pp.lo[1], pp.hi[1] = self.y0 - self.dy / 2, self.y0 + self.Ly - self.dy / 2
         pp.lo[2], pp.hi[2] = 0.0, 0.0
@@ -266,12 +396,16 @@ class PicEngine2D:
         xhi = self.x0 + (self.nx - 1) * self.dx + self.dx / 2
         check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
                                         cap, st), "lpa_migrate_pack_x")
+        if not self.comm.has_left:
+            m["r_lo"][:1].zero_()    # open face: nothing arrives (count = 0)
+        if not self.comm.has_right:
+            m["r_hi"][:1].zero_()
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         cur = ws["counters"][1:2].data_ptr()
         # arrivals through my low face come from the left neighbour; at the global low edge they
         # crossed the periodic boundary: x > xmax_global -> x - Lx (sync_particles_2d.c:168-182)
-        shift_lo = -self.Lx if self.comm.rank == 0 else 0.0
-        shift_hi = self.Lx if self.comm.rank == self.comm.size - 1 else 0.0
+        shift_lo = -self.Lx if (self.comm.rank == 0 and self.periodic_x) else 0.0
+        shift_hi = self.Lx if (self.comm.rank == self.comm.size - 1 and self.periodic_x) else 0.0
         check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_lo"].data_ptr(), cap,
                                         shift_lo, st), "unpack lo")
         check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_hi"].data_ptr(), cap,

@@ -180,14 +180,14 @@ class Simulation:
     _PUSHER_STAGES = {"_push_position_1", "_interpolator", "_qed", "_push_momentum", "_push_position_2"}
 
     def __init__(self, nx, ny, dx, dy, npatch_x=1, npatch_y=1, nsteps=None, sim_time=None, dt_cfl=0.95,
-                 n_guard=3, boundary_conditions=None, random_seed=None, device="cuda:0", comm=None,
-                 sort_interval=16, capacity_factor=1.5):
-        bc = boundary_conditions or {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")}
-        if any(v != "periodic" for v in bc.values()):
-            raise NotImplementedError("only periodic boundaries: CPML is the first 'next' row (SURVEY 8f-1)")
+                 n_guard=3, boundary_conditions=None, cpml_thickness=6, random_seed=None, device="cuda:0",
+                 comm=None, sort_interval=16, capacity_factor=1.5):
+        # reference default: PML on all four sides (simulation.py:157-162)
+        bc = dict(boundary_conditions or {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")})
         if dt_cfl > 1.0:
             raise ValueError("dt_cfl must be <= 1")
-        self.comm = comm or SlabComm(None)
+        self.cpml_thickness = int(cpml_thickness)
+        self.comm = comm or SlabComm(None, periodic=bc["xmin"] == "periodic")
         self.nx, self.ny, self.dx, self.dy = int(nx), int(ny), float(dx), float(dy)
         if self.nx % self.comm.size or (self.nx // self.comm.size) % npatch_x or self.ny % npatch_y:
             raise ValueError("nx must split evenly over ranks and patches")
@@ -214,9 +214,10 @@ class Simulation:
         nx_loc = self.nx // self.comm.size
         self.nx_per_patch, self.ny_per_patch = nx_loc // self.npatch_x, self.ny // self.npatch_y
         self.engine = PicEngine2D(nx_loc, self.ny, self.dx, self.dy, self.n_guard, self.device, self.comm,
-                                  sort_interval=self.sort_interval)
+                                  sort_interval=self.sort_interval, boundary_conditions=self.boundary_conditions,
+                                  cpml_thickness=self.cpml_thickness)
         mirrors = make_patches_2d(nx_loc, self.ny, self.dx, self.dy, self.npatch_x, self.npatch_y, self.n_guard,
-                                  nspecies=len(self.species))
+                                  boundary_conditions=self.boundary_conditions, nspecies=len(self.species))
         for p in mirrors:                       # patch origins in global coordinates
             p.x0 += self.engine.x0
             p.fields.x0 = p.x0
@@ -304,10 +305,13 @@ class Simulation:
         cbs = self._triggered(table.get(stage, []))
         if not cbs:
             return
-        self.download()
+        host_cbs = [cb for cb in cbs if not getattr(cb, "device_native", False)]
+        if host_cbs:
+            self.download()
         for cb in cbs:
             cb(self)
-        self.upload()
+        if host_cbs:
+            self.upload()
 
     def sync_currents(self):
         if not self.current_synced:
@@ -335,7 +339,8 @@ class Simulation:
         if nsteps is None:
             nsteps = int(sim_time / self.dt) if sim_time is not None else \
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
-        self.engine.write_part_eb = bool(table)     # callbacks may read ex_part..bz_part
+        # host callbacks may read ex_part..bz_part
+        self.engine.write_part_eb = any(not getattr(cb, "device_native", False) for cb in callbacks or [])
         self._run_stage(table, "init")
         unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]

@@ -19,7 +19,8 @@ C = 299792458.0
 
 def _sim(nx=64, ny=64, npx=2, npy=2, ppc=16, seed=3, **kw):
     dx = dy = LAMBDA / 20
-    sim = Simulation(nx, ny, dx, dy, npatch_x=npx, npatch_y=npy, random_seed=seed, **kw)
+    bc = {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")}
+    sim = Simulation(nx, ny, dx, dy, npatch_x=npx, npatch_y=npy, random_seed=seed, boundary_conditions=bc, **kw)
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / LAMBDA) ** 2 / constants.E_CHARGE ** 2
     sim.add_species(Species("electron", charge=-1, mass=1, density=nc, ppc=ppc, momentum_sigma=0.0442))
     return sim, nc
