@@ -224,12 +224,16 @@ class Simulation:
             p.fields.xaxis += self.engine.x0
         mirrors.xmin_global, mirrors.xmax_global = -self.dx / 2, self.Lx - self.dx / 2
         self.patches = DevicePatches(self, mirrors)
-        rng = np.random.default_rng(None if self.random_seed is None else self.random_seed + self.comm.rank)
         for s in self.species:
             n_tot = 0
             for p in mirrors:
                 q = p.particles[s.ispec]
-                n_tot += self._fill(p, q, s, rng)
+                # one generator per (species, patch origin): the same particles whatever the number
+                # of ranks (the reference spawns one generator per rank, simulation.py:700-716, so ITS
+                # loading depends on the decomposition; identical physics, different noise)
+                seed = None if self.random_seed is None else \
+                    [self.random_seed, s.ispec, int(round(p.x0 / self.dx)), int(round(p.y0 / self.dy))]
+                n_tot += self._fill(p, q, s, np.random.default_rng(seed))
             self.engine.add_species(s.q, s.m, capacity=int(n_tot * self.capacity_factor) + 65536, with_eb=True)
             self.engine.species[s.ispec].upload([p.particles[s.ispec] for p in mirrors])
         self.maxwell = MaxwellSolver2D(self)

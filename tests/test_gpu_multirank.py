@@ -110,3 +110,71 @@ def test_slabs_match_single_rank(single, world):
     for a in f1:
         scale = np.abs(f1[a]).max()
         assert np.abs(fn[a] - f1[a]).max() <= 1e-9 * scale, a
+
+
+# ---- laser-target like case (BASELINE config C3 in small): PML on all sides, laser from x-min, plasma
+# ---- slab with two species, chain of x-slabs (open ends) ------------------------------------------
+def _run_laser_target(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.laser import SimpleLaser2D
+    from lambdapic_amd.simulation import Simulation, Species
+    lam = 0.8e-6
+    nx, ny = 192, 64
+    dx = dy = lam / 16
+    bc = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")}
+    comm = SlabComm(None, periodic=False, single=(world == 1))
+    # npatch_x = 4 / world: the mirrors' patch origins (= loading seeds) do not depend on the world size
+    sim = Simulation(nx, ny, dx, dy, npatch_x=4 // world, boundary_conditions=bc, cpml_thickness=6, comm=comm,
+                     sort_interval=5)
+    nc = 1.742e27
+    dens = lambda x, y: np.where((x > 100 * dx) & (x < 130 * dx) & (y > 10 * dy) & (y < 54 * dy), 2 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=0.02))
+    sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=4, momentum_sigma=0.0))
+    sim.random_seed = 1234
+    sim.initialize()
+    laser = SimpleLaser2D(a0=2.0, w0=2.5e-6, ctau=2.0e-6, l0=lam)
+    trace = []
+    for it in range(110):
+        sim.run(1, callbacks=[laser])
+        if it % 10 == 9:
+            d = sim.engine.diagnostics()
+            trace.append([d["field_energy"], d["charge"], sum(d["kinetic"]), sum(d["nalive"])])
+    g = sim.engine.grid
+    nxl = nx // world
+    fields = {a: g.view(a)[3:3 + nxl, 3:3 + ny].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch_lt(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_laser_target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trace = sum(r[1] for r in res)
+    fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+    return trace, fields
+
+
+def test_laser_target_chain_matches_single_rank():
+    t1, f1 = _launch_lt(1)
+    t2, f2 = _launch_lt(2)
+    assert t1[-1, 0] > 0 and t1[-1, 2] > t1[0, 2]             # the laser heats the target
+    assert np.array_equal(t2[:, 3], t1[:, 3])
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
+    for a in f1:
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
