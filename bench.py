@@ -49,8 +49,7 @@ def build_engine(args, comm, device):
     n = nx * ny * ppc
     eng = PicEngine2D(nx, ny, dx, dy, n_guard=3, device=device, comm=comm,
                       sort_interval=args.sort_interval, block_particles=args.block_particles)
-    area = 2 * eng.migrate_capacity * max(args.sort_interval, 1) if comm.size > 1 else 0
-    eng.add_species(q, m, capacity=n + area + 4096)
+    eng.add_species(q, m, capacity=n + 4096)
     s = eng.species[0].cset
     gen = torch.Generator(device=device).manual_seed(20260722 + comm.rank)
     chunk = 1 << 24

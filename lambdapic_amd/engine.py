@@ -161,8 +161,14 @@ class PicEngine2D:
     def stream(self):
         return current_stream_ptr(self.device)
 
+    def arrival_area(self) -> int:
+        """slots reserved behind the sorted particles for arrivals from the neighbour slabs between
+        two sorts (0 on a single rank)"""
+        return self.migrate_capacity * 2 * max(self.sort_interval, 1) if self.comm.size > 1 else 0
+
     def add_species(self, q, m, capacity, with_eb=False) -> int:
-        self.species.append(DeviceParticles(capacity, self.device, q, m, with_eb))
+        """``capacity`` = live particles this rank must be able to hold; the arrival area is added"""
+        self.species.append(DeviceParticles(int(capacity) + self.arrival_area(), self.device, q, m, with_eb))
         return len(self.species) - 1
 
     def _g(self):
@@ -261,7 +267,7 @@ class PicEngine2D:
         key = id(sp)
         if key not in self._ws:
             nbytes = self.L.lpa_sort_workspace_bytes(self._g(), sp.capacity)
-            area = self.migrate_capacity * 2 * max(self.sort_interval, 1) if self.comm.size > 1 else 0
+            area = self.arrival_area()
             self._ws[key] = {
                 "sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
                 "overflow": torch.empty(sp.capacity, dtype=torch.int32, device=self.device),

@@ -58,7 +58,7 @@ def _run(rank, world, port, q):
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
     mine = (x >= lo) & (x < hi)
     n = int(mine.sum())
-    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=3 * n + 8 * 4096 * 5)
+    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=3 * n)
     s = eng.species[0].cset
     for name, arr in (("x", x), ("y", y), ("ux", u[0]), ("uy", u[1]), ("uz", u[2]), ("inv_gamma", ig), ("w", w)):
         s.arr(name)[:n] = torch.from_numpy(arr[mine]).cuda()
@@ -85,7 +85,7 @@ def _launch(world):
     procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -159,7 +159,7 @@ def _launch_lt(world):
     procs = [ctx.Process(target=_run_laser_target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
