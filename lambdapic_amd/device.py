@@ -141,6 +141,20 @@ class DeviceParticles:
             self.sets[1 - self.cur] = ParticleSet(self.capacity, self.device, self.with_eb)
         return self.sets[1 - self.cur]
 
+    def reserve(self, capacity):
+        """grow the store to at least ``capacity`` slots (the reference's ParticlesBase.extend,
+        core/particles.py:141-168); existing slots keep their order"""
+        if capacity <= self.capacity:
+            return False
+        new = ParticleSet(int(capacity), self.device, self.with_eb)
+        old = self.cset
+        new.data[:, : self.n].copy_(old.data[:, : self.n])
+        new.id[: self.n].copy_(old.id[: self.n])
+        self.sets = [new, None]
+        self.cur = 0
+        self.capacity = int(capacity)
+        return True
+
     def upload(self, host_particles_list):
         """concatenate the live particles of the host mirrors into the device store"""
         names = self.cset.names           # core attributes (+ ex_part..bz_part when carried)

@@ -417,6 +417,78 @@ class PicEngine2D:
         check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_hi"].data_ptr(), cap,
                                         shift_hi, st), "unpack hi")
 
+    # ---- moving window (MovingWindow callback, callback/utils.py:471-648) ---------------------------
+    def remove_x_pml(self):
+        """the reference drops the x layers when the window starts moving (callback/utils.py:547-553)"""
+        if self.pml is None:
+            return
+        old = self.pml
+        sides = [s_ for s_ in old.sides if s_[0] != "x"]
+        if len(sides) == len(old.sides):
+            return
+        new = DevicePML2D(self.nx, self.ny, self.dx, self.dy, sides, self.cpml_thickness, self.device) if sides else None
+        if new is not None:      # the y layers keep their psi history
+            keep = {(l["e"], l["axis"], l["start"]): l for l in old.layers}
+            for l in new.layers:
+                o = keep.get((l["e"], l["axis"], l["start"]))
+                if o is not None:
+                    l["psi_a"], l["psi_b"] = o["psi_a"], o["psi_b"]
+        self.pml = new
+        # open x edges without a layer: the owner bounds are the slab's own (patch.py:105-148)
+        self.alo[0] = self.x0_global - self.dx / 2
+        self.ahi[0] = self.x0_global + (self.nx * self.comm.size - 1) * self.dx + self.dx / 2
+
+    def shift_window(self, ncells):
+        """move the slab ``ncells`` to the right: what relabelling the leftmost patch column to the
+        right end does (callback/utils.py:594-620,576-585): surviving cells keep their values (the
+        new low guard holds the cells that just left, like the reference's stale guard), the new
+        columns start from zero fields and zero psi, particles left of the window are dropped."""
+        if self.comm.size != 1:
+            raise NotImplementedError("moving window on a slab decomposition (ring rotation) is not built yet")
+        n, g = int(ncells), self.grid
+        keep = g.ng + g.nx - n
+        g.buf[:, :keep] = g.buf[:, n:n + keep].clone()
+        g.buf[:, keep:] = 0.0
+        if self.pml is not None:
+            for l in self.pml.layers:
+                if l["axis"] == 1:                      # y layers: psi is [nx][thickness]
+                    nl = l["stop"] - l["start"]
+                    for k in ("psi_a", "psi_b"):
+                        v = l[k].view(self.nx, nl)
+                        v[: self.nx - n] = v[n:].clone()
+                        v[self.nx - n:] = 0.0
+        shift = n * self.dx
+        self.x0_global += shift
+        self.x0 += shift
+        g.x0 += shift
+        g.c.x0 = g.x0
+        self.alo[0] += shift
+        self.ahi[0] += shift
+        for sp in self.species:
+            x = sp.cset.arr("x")[: sp.n]
+            x[x < self.x0 - self.dx / 2] = float("nan")
+
+    def append_particles(self, ispec, host):
+        """append host particles (dict of arrays: x y ux uy uz inv_gamma w [_id]) behind the stored
+        ones as loose particles and force a re-sort"""
+        sp = self.species[ispec]
+        k = int(host["x"].size)
+        if k == 0:
+            return
+        if sp.n + k + self.arrival_area() > sp.capacity:
+            # the tiling of the old set dies with it: the forced re-sort below rebuilds it
+            sp.reserve(int(1.5 * (sp.n + k)) + self.arrival_area())
+            self._ws.pop(id(sp), None)
+            sp.n_sorted, sp.tiling = 0, None
+        st = sp.cset
+        for a in st.names:
+            if a in host:
+                st.arr(a)[sp.n:sp.n + k].copy_(torch.from_numpy(np.ascontiguousarray(host[a])))
+        if "_id" in host:
+            st.id[sp.n:sp.n + k].copy_(torch.from_numpy(np.ascontiguousarray(host["_id"]).view(np.int64)))
+        sp.n += k
+        sp.steps_since_sort = 1 << 30
+
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
     def step(self, dt, tiled=True):
         E, B = ("ex", "ey", "ez"), ("bx", "by", "bz")

@@ -169,6 +169,45 @@ class DevicePatches:
             self.sim.engine.sync_particles(i)
 
 
+class MovingWindow:
+    """Mirror of the reference's ``MovingWindow`` callback (`callback/utils.py:471-648`): stage
+    ``start``; once ``sim.time >= start_time`` (default Lx / c) the x layers are removed and the
+    window advances by ``velocity * dt`` per step; every time a whole patch width has accumulated
+    the leftmost patch column is recycled to the right end (fields and psi zeroed, its particles
+    replaced by a fresh loading of the species' density profiles)."""
+    stage = "start"
+    interval = 1
+    device_native = True
+
+    def __init__(self, velocity, start_time=None, inject_particles=True, stop_inject_time=None):
+        self.velocity, self.start_time = velocity, start_time
+        self.inject_particles, self.stop_inject_time = inject_particles, stop_inject_time
+        self.total_shift = self.patch_this_shift = None
+        self.num_shifts = 0
+
+    def __call__(self, sim):
+        patch_Lx = sim.nx_per_patch * sim.dx
+        if self.start_time is None:
+            self.start_time = sim.Lx / constants.C_LIGHT
+        if self.total_shift is None:
+            self.total_shift = self.patch_this_shift = patch_Lx
+        if sim.time < self.start_time:
+            return
+        if self.num_shifts == 0:
+            sim.engine.remove_x_pml()
+        v = self.velocity(sim.time) if callable(self.velocity) else self.velocity
+        self.total_shift += v * sim.dt
+        self.patch_this_shift += v * sim.dt
+        self.num_shifts += 1
+        if self.patch_this_shift <= -patch_Lx:
+            raise NotImplementedError("backward moving window")
+        if self.patch_this_shift < patch_Lx:
+            return
+        self.patch_this_shift -= patch_Lx
+        sim.shift_window_right(self.inject_particles and
+                               (self.stop_inject_time is None or sim.time < self.stop_inject_time))
+
+
 class Simulation:
     """2-D periodic simulation driver with the reference's constructor vocabulary
     (`simulation/simulation.py:118-168`) and stage list (`:170-184`)."""
@@ -265,6 +304,36 @@ class Simulation:
                 getattr(q, a)[:] = rng.normal(0.0, s.momentum_sigma, n)
             q.inv_gamma[:] = 1.0 / np.sqrt(1 + q.ux ** 2 + q.uy ** 2 + q.uz ** 2)
         return n
+
+    def shift_window_right(self, inject):
+        """recycle the leftmost patch column (`callback/utils.py:594-620`) on the device slab"""
+        eng, n = self.engine, self.nx_per_patch
+        eng.shift_window(n)
+        self.window_shifts = getattr(self, "window_shifts", 0) + 1
+        for p in self.patches:              # the mirrors follow the window
+            p.x0 += n * self.dx
+            p.fields.x0 = p.x0
+            p.fields.xaxis += n * self.dx
+            p.xaxis = p.xaxis + n * self.dx
+        self.patches._m.xmin_global += n * self.dx
+        self.patches._m.xmax_global += n * self.dx
+        if not inject:
+            return
+        from .patch import Patch2D
+        from .particles import ParticlesBase
+        x_new = eng.x0 + (eng.nx - n) * self.dx
+        for s in self.species:
+            for j in range(self.npatch_y):
+                tmp = Patch2D(0, 0, 0, j, x_new, j * self.ny_per_patch * self.dy, n, self.ny_per_patch,
+                              self.dx, self.dy)
+                q = ParticlesBase(ipatch=j, rank=self.comm.rank)
+                # same seed rule as initialize(): the loading of a column is a function of its origin,
+                # so a moving window reproduces what a long static box would have held there
+                seed = None if self.random_seed is None else \
+                    [self.random_seed, s.ispec, int(round(tmp.x0 / self.dx)), int(round(tmp.y0 / self.dy))]
+                if self._fill(tmp, q, s, np.random.default_rng(seed)):
+                    eng.append_particles(s.ispec, {a: getattr(q, a) for a in
+                                                   ("x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id")})
 
     # ---- host mirrors <-> device --------------------------------------------------------------------
     def download(self):
