@@ -1,7 +1,8 @@
 """Laser injection callbacks (stage ``_laser``), host side.
 
-Mirror of the reference's ``SimpleLaser2D`` (`callback/laser.py:272-391`): same constructor
-parameters, same source-field formulas; the boundary update itself runs on the device
+Mirrors of the reference's ``SimpleLaser2D`` (`callback/laser.py:272-391`), ``GaussianLaser2D``
+(`callback/laser.py:397-555`, Laguerre-Gaussian modes included) and of ``laser1 + laser2``
+(`callback/laser.py:139-151,240-270`): same constructor parameters, same source-field formulas; the boundary update itself runs on the device
 (``PicEngine2D.laser_inject`` -> ``lpa_laser_inject_2d``, the GPU twin of
 ``_update_laser_bfields_2d``, `callback/laser.py:17-46`).  Being device native, the callback does not
 trigger the host-mirror refresh that ordinary callbacks get.
@@ -15,11 +16,83 @@ from . import constants
 C = constants.C_LIGHT
 
 
-class SimpleLaser2D:
+class Laser2D:
+    """common part (`callback/laser.py:79-137,154-192`): stage, stop time, the x-min layer check and
+    the hand-over of the source rows to the device kernel"""
     stage = "_laser"
     interval = 1
     device_native = True      # touches device state through the engine; no mirror download/upload
+    side = "xmin"
+    y0 = None
+    tstop = np.inf
+    disabled = False
 
+    def boundary_y(self, sim):
+        """f.yaxis - dy/2 - y0 on the interior nodes (`callback/laser.py:166-172`; ``y0 or Ly/2``
+        as there: y0 = 0 means the box centre)"""
+        eng = sim.engine
+        return eng.y0 + np.arange(eng.ny) * eng.dy - eng.dy / 2 - (self.y0 or sim.Ly / 2)
+
+    def source_fields(self, sim, y):
+        """(ey_source, ez_source) on the boundary nodes ``y`` (centred on the beam axis) at
+        ``sim.time``, or (None, None) once the pulse is over"""
+        raise NotImplementedError
+
+    def __call__(self, sim):
+        if self.disabled:
+            return
+        if C * sim.time >= self.tstop:          # callback/laser.py:113-117
+            self.disabled = True
+            return
+        eng = sim.engine
+        # the reference disables a laser whose x-min layer is missing (never there, or removed
+        # when a MovingWindow started): callback/laser.py:119-128
+        if eng.bc["xmin"] != "pml" or (eng.comm.rank == 0 and (eng.pml is None or "xmin" not in eng.pml.sides)):
+            self.disabled = True
+            return
+        ey, ez = self.source_fields(sim, self.boundary_y(sim))
+        if ey is not None:
+            eng.laser_inject(ey, ez, sim.dt)
+
+    def __add__(self, other):
+        if not isinstance(other, Laser2D):
+            raise TypeError(f"Cannot add Laser with {type(other)}")
+        if self.side != other.side:
+            raise TypeError(f"Cannot add lasers from different sides: {self.side} and {other.side}")
+        return CombinedLaser2D(self, other)
+
+
+def _polarise(amp, phase, pol_angle, ellipticity):
+    """major/minor axis decomposition shared by both profiles (`callback/laser.py:372-383`)"""
+    norm = np.sqrt(1 + ellipticity ** 2)
+    major, minor = 1.0 / norm, ellipticity / norm
+    cp, sp = np.cos(pol_angle), np.sin(pol_angle)
+    return (amp * (major * cp * np.sin(phase) - minor * sp * np.cos(phase)),
+            amp * (major * sp * np.sin(phase) + minor * cp * np.cos(phase)))
+
+
+class CombinedLaser2D(Laser2D):
+    """sum of two sources (`callback/laser.py:240-270`)"""
+
+    def __init__(self, laser1, laser2):
+        self.laser1, self.laser2 = laser1, laser2
+        self.side = laser1.side
+        self.tstop = max(laser1.tstop, laser2.tstop)
+
+    def boundary_y(self, sim):
+        return None
+
+    def source_fields(self, sim, y):
+        a = self.laser1.source_fields(sim, self.laser1.boundary_y(sim))
+        b = self.laser2.source_fields(sim, self.laser2.boundary_y(sim))
+        if a[0] is None:
+            return b
+        if b[0] is None:
+            return a
+        return a[0] + b[0], a[1] + b[1]
+
+
+class SimpleLaser2D(Laser2D):
     def __init__(self, a0, w0, ctau, y0=None, angle_y=0.0, tstop=None, pol_angle=0.0, ellipticity=0.0,
                  cep=0.0, l0=0.8e-6, side="xmin"):
         if any(p <= 0 for p in (a0, l0, w0, ctau)):
@@ -37,36 +110,78 @@ class SimpleLaser2D:
         self.E0 = a0 * constants.M_E * C * self.omega0 / constants.E_CHARGE
         self.k0 = self.omega0 / C
         self.ky = self.k0 * np.sin(angle_y)
-        self.disabled = False
 
-    def source_fields(self, time, y):
-        """ey_source, ez_source on the boundary nodes ``y`` (already centred on the beam axis) at
-        ``time`` -- `callback/laser.py:351-386`"""
+    def source_fields(self, sim, y):
+        """`callback/laser.py:351-386`"""
+        time = sim.time
+        if C * time >= self.tstop:
+            return None, None
         r_rot = np.sqrt((y / np.cos(self.angle_y)) ** 2)
         transverse_phase = -(self.ky * y)
         t_rot = C * time - y * np.sin(self.angle_y)
         tprof = np.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
         amp = self.E0 * np.exp(-r_rot ** 2 / self.w0 ** 2) * tprof
         phase = self.omega0 * time + self.cep + transverse_phase
-        norm = np.sqrt(1 + self.ellipticity ** 2)
-        major, minor = 1.0 / norm, self.ellipticity / norm
-        cp, sp = np.cos(self.pol_angle), np.sin(self.pol_angle)
-        ey = amp * (major * cp * np.sin(phase) - minor * sp * np.cos(phase)) * np.cos(self.angle_y)
-        ez = amp * (major * sp * np.sin(phase) + minor * cp * np.cos(phase))
-        return ey, ez
+        ey, ez = _polarise(amp, phase, self.pol_angle, self.ellipticity)
+        return ey * np.cos(self.angle_y), ez
 
-    def __call__(self, sim):
-        if self.disabled:
-            return
-        if C * sim.time >= self.tstop:          # callback/laser.py:113-117
-            self.disabled = True
-            return
-        eng = sim.engine
-        if eng.bc["xmin"] != "pml":             # the reference disables a laser without an x-min PML
-            self.disabled = True
-            return
-        y0 = self.y0 if self.y0 is not None else sim.Ly / 2
-        # boundary coordinates: f.yaxis - dy/2 - y0 (callback/laser.py:166-172), interior nodes
-        y = eng.y0 + np.arange(eng.ny) * eng.dy - eng.dy / 2 - y0
-        ey, ez = self.source_fields(sim.time, y)
-        eng.laser_inject(ey, ez, sim.dt)
+
+class GaussianLaser2D(Laser2D):
+    """Gaussian beam evaluated at the injection plane: waist evolution, wavefront curvature, Gouy
+    phase, Gaussian envelope centred ``x0`` behind the boundary, optional Laguerre-Gaussian (l, p)
+    mode (`callback/laser.py:397-555`)"""
+
+    def __init__(self, a0, l0, w0, ctau, x0=None, y0=None, z0=None, tstop=None, pol_angle=0.0, ellipticity=0.0,
+                 cep=0.0, focus_position=0.0, side="xmin", l=0, p=0):
+        if any(par <= 0 for par in (a0, l0, w0, ctau)):
+            raise ValueError("All parameters (a0, l0, w0, ctau) must be positive")
+        if side != "xmin":
+            raise ValueError("Invalid side: only 'xmin' is implemented.")
+        if abs(ellipticity) > 1:
+            raise ValueError("Ellipticity must be in range [-1, 1]")
+        if not isinstance(p, int) or p < 0:
+            raise ValueError("Number of radial nodes p must be a non-negative integer")
+        if not isinstance(l, int):
+            raise ValueError("Azimuthal index l must be an integer")
+        self.a0, self.l0, self.w0, self.ctau, self.y0, self.z0 = a0, l0, w0, ctau, y0, z0
+        self.omega0 = 2 * np.pi * C / l0
+        self.k0 = self.omega0 / C
+        self.x0 = 3 * ctau if x0 is None else x0
+        self.tstop = 6 * ctau if tstop is None else C * tstop
+        self.E0 = a0 * constants.M_E * C * self.omega0 / constants.E_CHARGE
+        self.pol_angle, self.ellipticity, self.cep = pol_angle, ellipticity, cep
+        self.focus_position = focus_position
+        self.zR = np.pi * w0 ** 2 / l0
+        self.l, self.p = l, p
+        self._is_lg = l != 0 or p > 0
+        if self._is_lg:
+            from scipy.special import factorial, genlaguerre
+            # normalised so that the fundamental mode has unit norm
+            self.lg_norm = np.sqrt(2 * factorial(p) / (np.pi * factorial(p + abs(l)))) / np.sqrt(2 / np.pi)
+            self.laguerre = genlaguerre(p, abs(l))
+
+    def beam_params(self, z):
+        z = z - self.focus_position
+        w = self.w0 * np.sqrt(1 + (z / self.zR) ** 2)
+        R = z * (1 + (self.zR / z) ** 2) if abs(z) > 1e-10 else np.inf
+        return w, R, np.arctan(z / self.zR)
+
+    def source_fields(self, sim, y):
+        time = sim.time
+        if C * time >= self.tstop:
+            return None, None
+        tprof = np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2)
+        x_rel = sim.cpml_thickness * sim.dx
+        w, R, psi = self.beam_params(x_rel)
+        r = np.abs(y)
+        if self._is_lg:
+            phi = np.arctan2(0.0, y)             # 2-D: the azimuth is 0 or pi
+            u = np.sqrt(2) * r / w
+            amp_lg = self.lg_norm * u ** abs(self.l) * self.laguerre(u ** 2)
+            phase_lg = self.l * phi
+        else:
+            amp_lg, phase_lg = 1.0, 0.0
+        amp = self.E0 * (self.w0 / w) * np.exp(-r ** 2 / w ** 2) * amp_lg * tprof
+        phase = (self.omega0 * time + self.cep - self.k0 * x_rel - self.k0 * r ** 2 / (2 * R)
+                 - (2 * self.p + abs(self.l) + 1) * psi - phase_lg)
+        return _polarise(amp, phase, self.pol_angle, self.ellipticity)

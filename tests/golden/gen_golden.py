@@ -519,7 +519,62 @@ def g10_laser(rng):
     np.savez_compressed(OUT / "g10_laser_2d.npz", **out)
 
 
+def load_ref_laser_classes():
+    """the laser profile classes of callback/laser.py (class statements only; the module itself
+    imports the whole package and mpi4py); executed here with duck-typed sim / patch objects"""
+    import ast
+    from numpy.typing import NDArray
+    from scipy.constants import c, e, epsilon_0, m_e, pi
+    from scipy.special import factorial, genlaguerre
+    tree = ast.parse((REF / "callback/laser.py").read_text())
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef)]
+    ns = {"np": np, "NDArray": NDArray, "c": c, "e": e, "m_e": m_e, "pi": pi, "epsilon_0": epsilon_0,
+          "factorial": factorial, "genlaguerre": genlaguerre, "Optional": object}
+    for name in ("Simulation", "Simulation2D", "Simulation3D", "Patch", "Patch2D", "Patch3D", "Fields"):
+        ns[name] = object
+    exec(compile(ast.fix_missing_locations(ast.Module(body=body, type_ignores=[])), "laser_classes", "exec"), ns)
+    return ns
+
+
+def g11_laser_profiles():
+    """source rows (ey_source, ez_source) of SimpleLaser2D, GaussianLaser2D (plain, LG, defocused,
+    elliptical) and of a sum of two lasers at several times"""
+    ns = load_ref_laser_classes()
+    ny, ng, dx, dy, t = 96, 3, 5e-8, 6e-8, 6
+    Ly = ny * dy
+    yaxis = ((np.arange(ny + 2 * ng) - ng) * dy)            # fields.yaxis incl. guards, origin 0
+    yaxis = np.roll(yaxis, -ng)[None, :]                     # wrapped layout: interior first
+    patch = types.SimpleNamespace(fields=types.SimpleNamespace(yaxis=yaxis))
+    cases = {
+        "simple": ("SimpleLaser2D", dict(a0=2.0, w0=1.2e-6, ctau=1.5e-6, pol_angle=0.3, ellipticity=0.4, cep=0.7)),
+        "simple_oblique": ("SimpleLaser2D", dict(a0=1.0, w0=1.0e-6, ctau=2.0e-6, angle_y=0.35, y0=2.0e-6)),
+        "gauss": ("GaussianLaser2D", dict(a0=1.5, l0=0.8e-6, w0=1.5e-6, ctau=1.0e-6, focus_position=8e-6)),
+        "gauss_ellip": ("GaussianLaser2D", dict(a0=1.0, l0=1.0e-6, w0=2.0e-6, ctau=1.2e-6, pol_angle=1.1,
+                                                ellipticity=-1.0, cep=0.5, y0=3.1e-6)),
+        "gauss_lg": ("GaussianLaser2D", dict(a0=1.0, l0=0.8e-6, w0=1.0e-6, ctau=1.0e-6, focus_position=-3e-6,
+                                             l=1, p=2)),
+    }
+    out = dict(ny=ny, ng=ng, dx=dx, dy=dy, thickness=t, Ly=Ly, yaxis=yaxis[0])
+    times = np.array([0.2e-15, 3.3e-15, 7.7e-15, 12.1e-15])
+    out["times"] = times
+    import json
+    out["cases"] = np.array(json.dumps(cases))
+    lasers = {k: ns[cls](**kw) for k, (cls, kw) in cases.items()}
+    lasers["sum"] = lasers["simple"] + lasers["gauss"]
+    for name, las in lasers.items():
+        for it, tm in enumerate(times):
+            sim = types.SimpleNamespace(time=float(tm), Ly=Ly, dy=dy, dx=dx, cpml_thickness=t)
+            ey, ez = las._calculate_bound_fields(sim, patch)
+            if ey is None:                      # pulse over: stored as empty rows
+                ey = ez = np.zeros(0)
+            out[f"{name}_t{it}_ey"], out[f"{name}_t{it}_ez"] = ey, ez
+    np.savez_compressed(OUT / "g11_laser_profiles.npz", **out)
+
+
 def main():
+    if "--only-g11" in sys.argv:
+        g11_laser_profiles()
+        return
     assert oracle.ref_available(), "run `make -C oracle ref` first"
     mx = load_ref_maxwell()
     rng = np.random.default_rng(SEED)
@@ -533,6 +588,7 @@ def main():
     g8_trace(mx)
     g9_cpml(mx)
     g10_laser(np.random.default_rng(SEED + 10))
+    g11_laser_profiles()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

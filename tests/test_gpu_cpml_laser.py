@@ -167,3 +167,30 @@ def test_moving_window_matches_long_static_box(plasma):
         ow, os_ = np.lexsort((lw["y"][iw], lw["x"][iw])), np.lexsort((ls["y"][isx], ls["x"][isx]))
         np.testing.assert_allclose(lw["x"][iw][ow], ls["x"][isx][os_], rtol=0, atol=1e-9 * w.dx)
         np.testing.assert_allclose(lw["ux"][iw][ow], ls["ux"][isx][os_], rtol=0, atol=1e-9)
+
+
+def test_gaussian_laser_and_sum_inject_on_device():
+    """GaussianLaser2D focused at the boundary: the injected peak is a0 m c w0 / e (profiles are pinned
+    row by row in tests/test_laser_profiles.py); two lasers added inject the sum of their rows"""
+    from lambdapic_amd.laser import GaussianLaser2D
+    lam = 0.8e-6
+    nx, ny = 256, 160
+    dx = dy = lam / 16
+    E0 = constants.M_E * C * (2 * np.pi * C / lam) / constants.E_CHARGE
+
+    def run(make):
+        sim = Simulation(nx, ny, dx, dy, boundary_conditions=PML, cpml_thickness=6)
+        sim.run(int(7.5e-6 / C / sim.dt), callbacks=[make()])
+        return sim.engine.grid.view("ey").clone(), sim.engine.grid.view("ez").clone()
+
+    g1 = lambda: GaussianLaser2D(a0=0.8, l0=lam, w0=2.0e-6, ctau=1.2e-6, focus_position=6 * dx)
+    # same ctau -> same stop time: once a laser is over its boundary rows are no longer rewritten, which
+    # would differ between a single run and the sum
+    g2 = lambda: GaussianLaser2D(a0=0.3, l0=lam, w0=1.5e-6, ctau=1.2e-6, pol_angle=np.pi / 2, y0=5e-6)
+    ey1, ez1 = run(g1)
+    assert ey1.abs().max().item() == pytest.approx(0.8 * E0, rel=0.05) and ez1.abs().max().item() < 1e-6 * E0
+    ey2, ez2 = run(g2)
+    ey12, ez12 = run(lambda: g1() + g2())
+    # vacuum Maxwell is linear: the sum of the runs is the run of the sum
+    assert (ey12 - ey1 - ey2).abs().max().item() < 1e-12 * E0
+    assert (ez12 - ez1 - ez2).abs().max().item() < 1e-12 * E0
