@@ -241,12 +241,17 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     // wave-wide DPP / permlane operations)
     // software pipeline: the seven attribute loads of the NEXT iteration are issued before the current
     // particle is processed, so their HBM latency hides under the VALU / LDS work of this one
+    // particle attributes are addressed as uniform base + 32-bit byte offset (the sorted range is far
+    // below 2^29 particles): one VALU instruction per access instead of a 64-bit address each
+    auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
+    auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
     double nx_ = 0.0, ny_ = 0.0, nux = 0.0, nuy = 0.0, nuz = 0.0, nig = 1.0, nw = 0.0;
     {
         const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
         if (ip0 < end) {
-            nx_ = p.x[ip0]; ny_ = p.y[ip0]; nux = p.ux[ip0]; nuy = p.uy[ip0]; nuz = p.uz[ip0];
-            nig = p.ig[ip0]; nw = p.w[ip0];
+            const uint32_t o = (uint32_t)ip0 * 8u;
+            nx_ = ld(p.x, o); ny_ = ld(p.y, o); nux = ld(p.ux, o); nuy = ld(p.uy, o); nuz = ld(p.uz, o);
+            nig = ld(p.ig, o); nw = ld(p.w, o);
         }
     }
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
@@ -256,16 +261,26 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         {
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {
-                nx_ = p.x[ipn]; ny_ = p.y[ipn]; nux = p.ux[ipn]; nuy = p.uy[ipn]; nuz = p.uz[ipn];
-                nig = p.ig[ipn]; nw = p.w[ipn];
+                const uint32_t o = (uint32_t)ipn * 8u;
+                nx_ = ld(p.x, o); ny_ = ld(p.y, o); nux = ld(p.ux, o); nuy = ld(p.uy, o); nuz = ld(p.uz, o);
+                nig = ld(p.ig, o); nw = ld(p.w, o);
             }
         }
         valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
+        // first half push and the nearest node (ix1, iy1) of the mid-step position.  The LDS path is
+        // valid iff that node lies within the tile + margin: the gather then reads nodes ix1-2..ix1+1
+        // and the deposit window (mid-step cell and the cell one step of < 1 cell further, +-1 ulp of
+        // wobble in either) stays within ix1-3..ix1+3, all inside the HALO = margin + 3 nodes staged
+        // around the tile.  Everything else goes to the overflow list untouched (nothing stored yet).
+        double xo = 0.0, yo = 0.0;
+        int ix1 = 0, iy1 = 0;
         if (valid) {
-            // start cell (nearest node); the LDS path is valid iff it lies within the tile + margin
-            int is = ifloor((x - g.x0) * inv_dx + 0.5), js = ifloor((y - g.y0) * inv_dy + 0.5);
-            if (is < tx0 - LPA_TILE_MARGIN || is >= tx0 + TX + LPA_TILE_MARGIN ||
-                js < ty0 - LPA_TILE_MARGIN || js >= ty0 + TY + LPA_TILE_MARGIN) {
+            x += k.cdt_half * ig * ux;
+            y += k.cdt_half * ig * uy;
+            xo = (x - g.x0) * inv_dx; yo = (y - g.y0) * inv_dy;
+            ix1 = ifloor(xo + 0.5); iy1 = ifloor(yo + 0.5);
+            if ((unsigned)(ix1 - (tx0 - LPA_TILE_MARGIN)) >= (unsigned)(TX + 2 * LPA_TILE_MARGIN) ||
+                (unsigned)(iy1 - (ty0 - LPA_TILE_MARGIN)) >= (unsigned)(TY + 2 * LPA_TILE_MARGIN)) {
                 uint32_t slot = atomicAdd(overflow_count, 1u);
                 overflow[slot] = (uint32_t)ip;
                 valid = false;
@@ -275,19 +290,16 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         double vz = 0.0;
         int b0 = 0;
         if (valid) {
-            x += k.cdt_half * ig * ux;
-            y += k.cdt_half * ig * uy;
             double eb[6];
             {
-                double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy;
-                int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo), iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
+                int ix2 = ifloor(xo), iy2 = ifloor(yo);
                 double gx[3], hx[3], gy[3], hy[3];
                 tsc3(ix1 - xo, gx);
                 tsc3(ix2 - xo + 0.5, hx);
                 tsc3(iy1 - yo, gy);
                 tsc3(iy2 - yo + 0.5, hy);
-                int lx1 = clampi(ix1 - rx0, 1, RWX - 2), lx2 = clampi(ix2 - rx0, 1, RWX - 2);
-                int ly1 = clampi(iy1 - ry0, 1, RWY - 2), ly2 = clampi(iy2 - ry0, 1, RWY - 2);
+                // in range by the margin test (ix2 is ix1 or ix1 - 1)
+                int lx1 = ix1 - rx0, lx2 = ix2 - rx0, ly1 = iy1 - ry0, ly2 = iy2 - ry0;
 #ifdef LPA_ABLATE_NO_GATHER  // diagnostic build: keep the weights, drop the 54 LDS reads
                 eb[0] = hx[0] * gy[1] + lx2; eb[1] = gx[1] * hy[2] + ly2; eb[2] = gx[2] * gy[0] + lx1;
                 eb[3] = gx[0] * hy[1] + ly1; eb[4] = hx[1] * gy[2]; eb[5] = hx[2] * hy[0];
@@ -316,8 +328,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
             finish_position_2d(xs, ys, k);
-            p.x[ip] = xs; p.y[ip] = ys;
-            p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+            const uint32_t o = (uint32_t)ip * 8u;
+            st(p.x, o, xs); st(p.y, o, ys);
+            st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -343,6 +356,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                        // (one exec-mask region per run of cells) instead of testing 64
                                        // values -- crossers are ~3 % of the lanes
                                        bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
+#ifdef LPA_ABLATE_NO_TAIL  // diagnostic build: drop window row 3 / column 3 (wrong for cell crossers)
+                                       on = kk < 3 && ll < 3;
+#endif
                                        if (on) {
                                            atomicAdd(&s_j[0][o], djx);
                                            atomicAdd(&s_j[1][o], djy);

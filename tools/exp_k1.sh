@@ -1,0 +1,11 @@
+#!/bin/bash
+# K1 experiment timings for compile-time variants: tools/exp_k1.sh "name:DEF1 DEF2" ...
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT"
+for v in "$@"; do
+  name=${v%%:*}; defs=${v#*:}
+  lib=$(python3 -c "from lambdapic_amd.build import build_variant; print(build_variant('$name', '$defs'.split()))" 2>/dev/null) || exit 1
+  LPA_LIB_PATH=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 20 --warmup 4 2>/dev/null | tail -1 | \
+    python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'ms_per_step', round(d['ms_per_step'],3))"
+done
