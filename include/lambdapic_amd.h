@@ -75,7 +75,9 @@ typedef struct {
 
 #define LPA_TILE_X 8       /* cells per tile along x                                            */
 #define LPA_TILE_Y 32      /* cells per tile along y (the fastest axis): one half-wave = one row */
-#define LPA_TILE_MARGIN 1  /* cells a particle may sit outside its tile and stay on the LDS path */
+#ifndef LPA_TILE_MARGIN
+#define LPA_TILE_MARGIN 2  /* cells a particle may sit outside its tile and stay on the LDS path */
+#endif
 /* order of the particles inside a tile:
  *   CELL_MAJOR : all particles of cell 0, then of cell 1, ... -- the lanes of a wave share a cell;
  *                the tiled kernel sums their deposit windows across the wave in registers

@@ -17,7 +17,7 @@ LPA_TILE_X = 8
 LPA_TILE_Y = 32
 LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1
-LPA_TILE_MARGIN = 1
+LPA_TILE_MARGIN = 2
 LPA_MIG_NATTR = 9
 LPA_ABSORB_X = 16
 

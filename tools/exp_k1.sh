@@ -1,11 +1,12 @@
 #!/bin/bash
-# K1 experiment timings for compile-time variants: tools/exp_k1.sh "name:DEF1 DEF2" ...
+# K1 experiment timings for compile-time variants: tools/exp_k1.sh "name:DEF1 DEF2[:bench flags]" ...
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 for v in "$@"; do
-  name=${v%%:*}; defs=${v#*:}
+  name=${v%%:*}; rest=${v#*:}; defs=${rest%%:*}; flags=""
+  case "$rest" in *:*) flags=${rest#*:};; esac
   lib=$(python3 -c "from lambdapic_amd.build import build_variant; print(build_variant('$name', '$defs'.split()))" 2>/dev/null) || exit 1
-  LPA_LIB_PATH=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 20 --warmup 4 2>/dev/null | tail -1 | \
-    python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'ms_per_step', round(d['ms_per_step'],3))"
+  LPA_LIB_PATH=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 40 --warmup 8 $flags 2>/dev/null | tail -1 | \
+    python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', '$flags', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'ms_per_step', round(d['ms_per_step'],3))"
 done
