@@ -53,7 +53,7 @@ class SlabComm:
         staged = send_lo.is_cuda and dist.get_backend(self.group) == "gloo"
         if staged:
             s_lo, s_hi = send_lo.cpu(), send_hi.cpu()
-            r_lo, r_hi = torch.empty_like(s_lo), torch.empty_like(s_hi)
+            r_lo, r_hi = torch.empty_like(recv_lo, device="cpu"), torch.empty_like(recv_hi, device="cpu")
         else:
             s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
         ops = []

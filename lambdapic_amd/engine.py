@@ -439,24 +439,40 @@ class PicEngine2D:
         self.ahi[0] = self.x0_global + (self.nx * self.comm.size - 1) * self.dx + self.dx / 2
 
     def shift_window(self, ncells):
-        """move the slab ``ncells`` to the right: what relabelling the leftmost patch column to the
-        right end does (callback/utils.py:594-620,576-585): surviving cells keep their values (the
-        new low guard holds the cells that just left, like the reference's stale guard), the new
-        columns start from zero fields and zero psi, particles left of the window are dropped."""
-        if self.comm.size != 1:
-            raise NotImplementedError("moving window on a slab decomposition (ring rotation) is not built yet")
+        """move every slab ``ncells`` to the right: what relabelling the leftmost patch column to the
+        right end does (callback/utils.py:594-620,576-585).  Surviving cells keep their values (the
+        new low guard holds the cells that just left, like the reference's stale guard); on a slab
+        chain the columns (and y-layer psi rows) that leave through a low face travel to the left
+        neighbour, whose tail and high guard they become (a rotation of the neighbour ring
+        by one patch width); the last rank's new columns start from zero fields and zero psi.
+        Particles left of the new lower bound follow their columns; on rank 0 they are dropped."""
         n, g = int(ncells), self.grid
+        if not 0 < n <= g.nx - g.ng:
+            raise _lib.LpaError("window shift must be between 1 and nx - n_guard cells")
         keep = g.ng + g.nx - n
+        ylayers = [l for l in self.pml.layers if l["axis"] == 1] if self.pml is not None else []
+        # ---- what leaves through the low face: interior columns [0, n + ng) and psi rows [0, n)
+        parts = [g.buf[:, g.ng:g.ng + n + g.ng].reshape(-1)]
+        for l in ylayers:
+            nl = l["stop"] - l["start"]
+            for k in ("psi_a", "psi_b"):
+                parts.append(l[k].view(self.nx, nl)[:n].reshape(-1))
+        send = torch.cat(parts)
+        recv = torch.zeros_like(send)          # stays zero on the last rank: fresh columns
+        if self.comm.size > 1:
+            one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+            self.comm.exchange(send, one(), one(), recv)
+        nf = 10 * (n + g.ng) * g.NY
         g.buf[:, :keep] = g.buf[:, n:n + keep].clone()
-        g.buf[:, keep:] = 0.0
-        if self.pml is not None:
-            for l in self.pml.layers:
-                if l["axis"] == 1:                      # y layers: psi is [nx][thickness]
-                    nl = l["stop"] - l["start"]
-                    for k in ("psi_a", "psi_b"):
-                        v = l[k].view(self.nx, nl)
-                        v[: self.nx - n] = v[n:].clone()
-                        v[self.nx - n:] = 0.0
+        g.buf[:, keep:] = recv[:nf].view(10, n + g.ng, g.NY)
+        off = nf
+        for l in ylayers:
+            nl = l["stop"] - l["start"]
+            for k in ("psi_a", "psi_b"):
+                v = l[k].view(self.nx, nl)
+                v[: self.nx - n] = v[n:].clone()
+                v[self.nx - n:] = recv[off:off + n * nl].view(n, nl)
+                off += n * nl
         shift = n * self.dx
         self.x0_global += shift
         self.x0 += shift
@@ -464,9 +480,45 @@ class PicEngine2D:
         g.c.x0 = g.x0
         self.alo[0] += shift
         self.ahi[0] += shift
+        # ---- particles that are now left of the slab
+        xlo = self.x0 - self.dx / 2
         for sp in self.species:
-            x = sp.cset.arr("x")[: sp.n]
-            x[x < self.x0 - self.dx / 2] = float("nan")
+            st = sp.cset
+            x = st.arr("x")[: sp.n]
+            if self.comm.size == 1:
+                x[x < xlo] = float("nan")
+                continue
+            idx = (x < xlo).nonzero().squeeze(1)          # host sync: a window shift is a rare event
+            cnt = torch.tensor([float(idx.numel())], dtype=torch.float64, device=self.device)
+            got = torch.zeros_like(cnt)
+            self.comm.exchange(cnt, torch.zeros_like(cnt), torch.zeros_like(cnt), got)
+            rows = len(st.names) + 1                      # attributes + id (bit pattern)
+            out = torch.empty((rows, idx.numel()), dtype=torch.float64, device=self.device)
+            out[:-1] = st.data[:, idx]
+            out[-1] = st.id[idx].view(torch.float64)
+            x[idx] = float("nan")
+            k = int(got.item()) if self.comm.has_right else 0
+            inc = torch.empty((rows, k), dtype=torch.float64, device=self.device)
+            dummy = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+            # zero-length messages are legal but pointless: pad to one column
+            s_ = out.reshape(-1) if out.numel() else dummy()
+            r_ = inc.reshape(-1) if inc.numel() else dummy()
+            self.comm.exchange(s_, dummy(), dummy(), r_)
+            if k:
+                self._append_device(sp, inc[:-1], inc[-1].view(torch.int64))
+
+    def _append_device(self, sp, data_rows, ids):
+        k = int(data_rows.shape[1])
+        if sp.n + k + self.arrival_area() > sp.capacity:
+            # the tiling of the old set dies with it: the forced re-sort rebuilds it
+            sp.reserve(int(1.5 * (sp.n + k)) + self.arrival_area())
+            self._ws.pop(id(sp), None)
+            sp.n_sorted, sp.tiling = 0, None
+        st = sp.cset
+        st.data[:, sp.n:sp.n + k] = data_rows
+        st.id[sp.n:sp.n + k] = ids
+        sp.n += k
+        sp.steps_since_sort = 1 << 30
 
     def append_particles(self, ispec, host):
         """append host particles (dict of arrays: x y ux uy uz inv_gamma w [_id]) behind the stored
@@ -475,19 +527,14 @@ class PicEngine2D:
         k = int(host["x"].size)
         if k == 0:
             return
-        if sp.n + k + self.arrival_area() > sp.capacity:
-            # the tiling of the old set dies with it: the forced re-sort below rebuilds it
-            sp.reserve(int(1.5 * (sp.n + k)) + self.arrival_area())
-            self._ws.pop(id(sp), None)
-            sp.n_sorted, sp.tiling = 0, None
         st = sp.cset
-        for a in st.names:
+        rows = torch.zeros((len(st.names), k), dtype=torch.float64)
+        for i, a in enumerate(st.names):
             if a in host:
-                st.arr(a)[sp.n:sp.n + k].copy_(torch.from_numpy(np.ascontiguousarray(host[a])))
-        if "_id" in host:
-            st.id[sp.n:sp.n + k].copy_(torch.from_numpy(np.ascontiguousarray(host["_id"]).view(np.int64)))
-        sp.n += k
-        sp.steps_since_sort = 1 << 30
+                rows[i] = torch.from_numpy(np.ascontiguousarray(host[a], dtype=np.float64))
+        ids = torch.from_numpy(np.ascontiguousarray(host["_id"]).view(np.int64)) if "_id" in host \
+            else torch.zeros(k, dtype=torch.int64)
+        self._append_device(sp, rows.to(self.device), ids.to(self.device))
 
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
     def step(self, dt, tiled=True):

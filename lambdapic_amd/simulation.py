@@ -317,8 +317,8 @@ class Simulation:
             p.xaxis = p.xaxis + n * self.dx
         self.patches._m.xmin_global += n * self.dx
         self.patches._m.xmax_global += n * self.dx
-        if not inject:
-            return
+        if not inject or self.comm.rank != self.comm.size - 1:
+            return                      # only the last slab's tail is new ground
         from .patch import Patch2D
         from .particles import ParticlesBase
         x_new = eng.x0 + (eng.nx - n) * self.dx

@@ -178,3 +178,71 @@ def test_laser_target_chain_matches_single_rank():
     for a in f1:
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
+
+
+# ---- moving window on a slab chain: the columns that leave a slab's low face become the left
+# ---- neighbour's tail (rotation of the neighbour ring by one patch width) ----------------
+def _run_window(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd import constants
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.laser import SimpleLaser2D
+    from lambdapic_amd.simulation import MovingWindow, Simulation, Species
+    lam = 0.8e-6
+    nx, ny = 256, 64
+    dx = dy = lam / 16
+    bc = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")}
+    comm = SlabComm(None, periodic=False, single=(world == 1))
+    sim = Simulation(nx, ny, dx, dy, npatch_x=8 // world, boundary_conditions=bc, cpml_thickness=6, comm=comm,
+                     sort_interval=5, random_seed=5)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
+    dens = lambda x, y: np.where((x > 150 * dx) & (abs(y - ny * dy / 2) < 20 * dy), 0.05 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=0.01))
+    laser = SimpleLaser2D(a0=1.5, w0=1.2e-6, ctau=1.5e-6, l0=lam)
+    mw = MovingWindow(velocity=C, start_time=0.6 * nx * dx / C)
+    trace = []
+    for it in range(520):
+        sim.run(1, callbacks=[laser, mw])
+        if it % 40 == 39:
+            d = sim.engine.diagnostics()
+            trace.append([d["field_energy"], d["charge"], sum(d["kinetic"]), sum(d["nalive"])])
+    g = sim.engine.grid
+    nxl = nx // world
+    fields = {a: g.view(a)[3:3 + nxl, 3:3 + ny].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    fields["_x0"] = np.full((1, ny), sim.engine.x0_global / dx)
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch_window(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_window, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trace = sum(r[1] for r in res)
+    fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+    return trace, fields
+
+
+def test_moving_window_chain_matches_single_rank():
+    t1, f1 = _launch_window(1)
+    t2, f2 = _launch_window(2)
+    assert f1["_x0"][0, 0] >= 4 * 32 and np.array_equal(f1["_x0"][0], f2["_x0"][0])   # both shifted alike
+    assert t1[-1, 3] > 1000                                        # plasma was injected and kept
+    assert np.array_equal(t2[:, 3], t1[:, 3])
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
