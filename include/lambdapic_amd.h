@@ -71,6 +71,8 @@ typedef struct {
     const int32_t *blk_begin;  /* [max_blocks] first particle of each work block                 */
     const int32_t *blk_end;    /* [max_blocks] one past the last particle                        */
     const int32_t *n_blocks;   /* [1] number of valid work blocks                                */
+    int32_t tiles_z;           /* 3-D tilings (lpa_sort_tiles_3d): tiles along z; 0 for 2-D      */
+    int32_t reserved_;
 } lpa_tiling;
 
 #define LPA_TILE_X 8       /* cells per tile along x                                            */
@@ -78,6 +80,12 @@ typedef struct {
 #ifndef LPA_TILE_MARGIN
 #define LPA_TILE_MARGIN 2  /* cells a particle may sit outside its tile and stay on the LDS path */
 #endif
+/* 3-D tiles: 4 x 4 x 16 cells (z is the fastest axis): 256 cells like the 2-D tile; a 16-lane group
+ * of a wave = 16 consecutive z-cells of one (x, y) column */
+#define LPA_TILE3_X 4
+#define LPA_TILE3_Y 4
+#define LPA_TILE3_Z 16
+#define LPA_TILE3_MARGIN 1
 /* order of the particles inside a tile:
  *   CELL_MAJOR : all particles of cell 0, then of cell 1, ... -- the lanes of a wave share a cell;
  *                the tiled kernel sums their deposit windows across the wave in registers
@@ -188,6 +196,16 @@ int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *p, const lp
                              void *stream);
 int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                         int64_t first, int64_t count, void *stream);
+/* 3-D twins of the tiled / list forms (replace unified_boris_pusher_cpu_3d,
+ * core/pusher/unified/unified_pusher_3d.c:219-436): J / rho of a 4 x 4 x 16-cell tile and its halo are
+ * accumulated in LDS, E / B are gathered from global memory; particles whose deposit window leaves the
+ * staged region go to `overflow` */
+int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles *p,
+                              const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
+                              uint32_t *overflow_count, void *stream);
+int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                             const uint32_t *list, const uint32_t *list_count, int64_t max_count,
+                             void *stream);
 
 /* ---- split kernels of the callback-in-pusher-stage path
  *      interpolation_patches_2d (core/interpolation/cpu2d.c:71-136), boris_push_patches
@@ -210,6 +228,11 @@ int lpa_wrap_positions_2d(const lpa_particles *p, const lpa_push_params *pp, voi
  *      of live particles is written to the workspace header (lpa_sort_live_count). */
 int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                      void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                      int32_t order, lpa_tiling *out, void *stream);
+/* 3-D twin (replaces sort_particles_patches_3d, core/sort/cpu3d.c): tiles of LPA_TILE3_X x LPA_TILE3_Y x
+ * LPA_TILE3_Z cells; the workspace size comes from lpa_sort_workspace_bytes with the 3-D grid */
+int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
                       int32_t order, lpa_tiling *out, void *stream);
 /* number of live particles after the last sort (device pointer inside the workspace) */

@@ -18,6 +18,7 @@ LPA_TILE_Y = 32
 LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1
 LPA_TILE_MARGIN = 2
+LPA_TILE3_X, LPA_TILE3_Y, LPA_TILE3_Z, LPA_TILE3_MARGIN = 4, 4, 16, 1
 LPA_MIG_NATTR = 9
 LPA_ABSORB_X = 16
 
@@ -43,7 +44,8 @@ class lpa_tiling(C.Structure):
     _fields_ = [("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("n_sorted", C.c_int64),
                 ("max_blocks", C.c_int32), ("order", C.c_int32),
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
-                ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p)]
+                ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
+                ("tiles_z", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class lpa_push_params(C.Structure):
@@ -78,6 +80,8 @@ SIGNATURES = {
     "lpa_push_deposit_tiled_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
     "lpa_push_deposit_list_2d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
     "lpa_push_deposit_3d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
+    "lpa_push_deposit_tiled_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
+    "lpa_push_deposit_list_3d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
     "lpa_interpolate_2d": (_i, [_G, _P, _vp]),
     "lpa_boris": (_i, [_P, _d, _d, _d, _vp]),
     "lpa_push_position_2d": (_i, [_P, _d, _vp]),
@@ -85,6 +89,7 @@ SIGNATURES = {
     "lpa_wrap_positions_2d": (_i, [_P, _PP, _vp]),
     "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
+    "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),

@@ -58,27 +58,18 @@ __device__ __forceinline__ void gather_global_3d(const GridV &g, double xo, doub
     gidx3(a, ix2, iy2, iz1, g); eb[5] = gather27_g(g.bz, a, hx, hy, gz);
 }
 
-__device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, double y, double z,
-                                                  double ux, double uy, double uz, double ig, double w,
-                                                  double q, double dt) {
-    double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
-    AxisW ax, ay, az;
-    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
-    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, 1.0 / g.dy);
-    axis_window(az, z - vz * 0.5 * dt - g.z0, z + vz * 0.5 * dt - g.z0, 1.0 / g.dz);
+// 3-D Esirkepov deposit of one particle on the 4x4x4 window (factored form of
+// current_deposit_3d_fast, current/current_deposit.h:293-321); `sink(i, j, k, djx, djy, djz, drho)`
+// adds the contributions of window cell (i, j, k).
+template <class Sink>
+__device__ __forceinline__ void esirkepov_3d(const AxisW &ax, const AxisW &ay, const AxisW &az, double w,
+                                             double q, double dx, double dy, double dz, double dt,
+                                             Sink &&sink) {
     const double one_third = 0.3333333333333333;  // core/utils/cutils.h:18
-    double cd = (q / (g.dx * g.dy * g.dz)) * w;
-    double fdx_ = (q / (g.dy * g.dz * dt)) * w;
-    double fdy_ = (q / (g.dx * g.dz * dt)) * w;
-    double fdz_ = (q / (g.dx * g.dy * dt)) * w;
-    long rows[4];
-    int cols[4], deps[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        rows[k] = (long)torus(ax.base + k + g.ng, g.NX) * g.NY * g.NZ;
-        cols[k] = torus(ay.base + k + g.ng, g.NY) * g.NZ;
-        deps[k] = torus(az.base + k + g.ng, g.NZ);
-    }
+    double cd = (q / (dx * dy * dz)) * w;
+    double fdx_ = (q / (dy * dz * dt)) * w;
+    double fdy_ = (q / (dx * dz * dt)) * w;
+    double fdz_ = (q / (dx * dy * dt)) * w;
     double jx_run[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -107,18 +98,37 @@ __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, doub
                 jy_run[k] -= fdy * tjy;
                 jz_run -= fdz_ * az.DS[k] * tz_ij;
                 bool zz = az.tail_zero && k == 3;
-                long idx = rows[i] + cols[j] + deps[k];
-                double djx = xz ? 0.0 : jx_run[k][j];
-                double djy = yz ? 0.0 : jy_run[k];
-                double djz = zz ? 0.0 : jz_run;
-                double dr = cd * ax.S1[i] * ay.S1[j] * az.S1[k];
-                if (djx != 0.0) atomicAdd(&g.jx[idx], djx);
-                if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
-                if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
-                if (dr != 0.0) atomicAdd(&g.rho[idx], dr);
+                sink(i, j, k, xz ? 0.0 : jx_run[k][j], yz ? 0.0 : jy_run[k], zz ? 0.0 : jz_run,
+                     cd * ax.S1[i] * ay.S1[j] * az.S1[k]);
             }
         }
     }
+}
+
+__device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, double y, double z,
+                                                  double ux, double uy, double uz, double ig, double w,
+                                                  double q, double dt) {
+    double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+    AxisW ax, ay, az;
+    axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
+    axis_window(ay, y - vy * 0.5 * dt - g.y0, y + vy * 0.5 * dt - g.y0, 1.0 / g.dy);
+    axis_window(az, z - vz * 0.5 * dt - g.z0, z + vz * 0.5 * dt - g.z0, 1.0 / g.dz);
+    long rows[4];
+    int cols[4], deps[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        rows[k] = (long)torus(ax.base + k + g.ng, g.NX) * g.NY * g.NZ;
+        cols[k] = torus(ay.base + k + g.ng, g.NY) * g.NZ;
+        deps[k] = torus(az.base + k + g.ng, g.NZ);
+    }
+    esirkepov_3d(ax, ay, az, w, q, g.dx, g.dy, g.dz, dt,
+                 [&](int i, int j, int k, double djx, double djy, double djz, double dr) {
+                     long idx = rows[i] + cols[j] + deps[k];
+                     if (djx != 0.0) atomicAdd(&g.jx[idx], djx);
+                     if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
+                     if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
+                     if (dr != 0.0) atomicAdd(&g.rho[idx], dr);
+                 });
 }
 
 __device__ __forceinline__ double fold3(double v, double lo, double hi) {
@@ -128,11 +138,21 @@ __device__ __forceinline__ double fold3(double v, double lo, double hi) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_push_deposit_global_3d(GridV g, PartV p, PushK3 k, long first,
-                                                                long count) {
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    long ip = first + t;
+// periodic fold and / or absorption of the advanced position (sync_particles_3d with a self neighbour)
+__device__ __forceinline__ void finish_position_3d(double &x, double &y, double &z, const PushK3 &k) {
+    if (k.wrap & 1) x = fold3(x, k.lo[0], k.hi[0]);
+    if (k.wrap & 2) y = fold3(y, k.lo[1], k.hi[1]);
+    if (k.wrap & 4) z = fold3(z, k.lo[2], k.hi[2]);
+    bool dead = false;
+    double c3[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        dead = dead || ((k.wrap & (LPA_ABSORB_X << a)) && (c3[a] < k.alo[a] || c3[a] > k.ahi[a]));
+    if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; z = x; }
+}
+
+// the whole per-particle update on global memory
+__device__ __forceinline__ void update_global_3d(const GridV &g, const PartV &p, const PushK3 &k, long ip) {
     double x = p.x[ip], y = p.y[ip], z = p.z[ip];
     if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y) || isnan(z)) return;
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig = p.ig[ip], w = p.w[ip];
@@ -151,28 +171,155 @@ __global__ void __launch_bounds__(256) k_push_deposit_global_3d(GridV g, PartV p
     y += k.cdt_half * ig * uy;
     z += k.cdt_half * ig * uz;
     deposit_global_3d(g, x, y, z, ux, uy, uz, ig, w, k.q, k.dt);
-    if (k.wrap & 1) x = fold3(x, k.lo[0], k.hi[0]);
-    if (k.wrap & 2) y = fold3(y, k.lo[1], k.hi[1]);
-    if (k.wrap & 4) z = fold3(z, k.lo[2], k.hi[2]);
-    {
-        bool dead = false;
-        double c3[3] = {x, y, z};
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-            dead = dead || ((k.wrap & (LPA_ABSORB_X << a)) && (c3[a] < k.alo[a] || c3[a] > k.ahi[a]));
-        if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; z = x; }
-    }
+    finish_position_3d(x, y, z, k);
     p.x[ip] = x; p.y[ip] = y; p.z[ip] = z;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
 
-extern "C" int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
-                                   int64_t first, int64_t count, void *stream) {
-    LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "lpa_push_deposit_3d: bad grid");
-    LPA_REQUIRE(lpa_part_ok(p, 3), "lpa_push_deposit_3d: bad particle store");
-    LPA_REQUIRE(pp && pp->dt > 0 && pp->m > 0, "lpa_push_deposit_3d: dt and m must be > 0");
-    LPA_REQUIRE(first >= 0 && count >= 0 && first + count <= p->n, "lpa_push_deposit_3d: bad range");
-    if (count == 0) return LPA_OK;
+__global__ void __launch_bounds__(256) k_push_deposit_global_3d(GridV g, PartV p, PushK3 k, long first,
+                                                                long count) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    update_global_3d(g, p, k, first + t);
+}
+
+__global__ void __launch_bounds__(256) k_push_deposit_list_3d(GridV g, PartV p, PushK3 k,
+                                                              const uint32_t *__restrict__ list,
+                                                              const uint32_t *__restrict__ list_count) {
+    long n = *list_count;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        update_global_3d(g, p, k, list[t]);
+}
+
+// =====================================================================================================
+// K1-tiled, 3-D.  Tiles of 4 x 4 x 16 cells (256 cells, z fastest), STRIPED order: a 16-lane group of a
+// wave sits in 16 consecutive z-cells of one (x, y) column, and the LDS services a 64-bit atomic in
+// 16-lane groups -- conflict free whatever the row strides.  J / rho of the tile + 3 nodes on every side
+// (margin 1 + the 2 nodes a deposit window reaches beyond the mid-step node) live in LDS:
+// 4 x 10 x 10 x 22 f64 = 70 KB, two 512-thread workgroups per CU.  E and B are gathered from global
+// memory through L1/L2 (a 6-component FP64 image with its halo does not fit beside J): 162 cached loads
+// per particle, tile-sorted so neighbouring lanes share lines.
+// =====================================================================================================
+constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
+constexpr int H3 = LPA_TILE3_MARGIN + 2;
+constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10 x 10 x 22
+constexpr int R3N = R3X * R3Y * R3Z;                                       // 2200
+constexpr int K13_THREADS = 512;
+
+__global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
+    GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
+    const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
+    uint32_t *overflow, uint32_t *overflow_count) {
+    __shared__ double s_j[4][R3N];
+    if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
+    const int tile = blk_tile[blockIdx.x];
+    const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
+    const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y, tx_ = tile / (tiles_z * tiles_y);
+    const int t0[3] = {tx_ * T3X, ty_ * T3Y, tz_ * T3Z};          // first node of the tile
+    const int r0[3] = {t0[0] - H3, t0[1] - H3, t0[2] - H3};       // first node of the LDS region
+    const int lane = threadIdx.x & 63;
+    for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_j[c][t] = 0.0;
+    }
+    __syncthreads();
+
+    const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy, inv_dz = 1.0 / g.dz;
+    auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
+    auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
+    // software pipeline: the eight attribute loads of the next iteration are in flight during this one
+    double nx_ = 0.0, ny_ = 0.0, nz_ = 0.0, nux = 0.0, nuy = 0.0, nuz = 0.0, nig = 1.0, nw = 0.0;
+    {
+        const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
+        if (ip0 < end) {
+            const uint32_t o = (uint32_t)ip0 * 8u;
+            nx_ = ld(p.x, o); ny_ = ld(p.y, o); nz_ = ld(p.z, o); nux = ld(p.ux, o); nuy = ld(p.uy, o);
+            nuz = ld(p.uz, o); nig = ld(p.ig, o); nw = ld(p.w, o);
+        }
+    }
+    for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
+        const int ip = it + lane;
+        bool valid = ip < end;
+        double x = nx_, y = ny_, z = nz_, ux = nux, uy = nuy, uz = nuz, ig = nig, w = nw;
+        {
+            const int ipn = ip + (int)blockDim.x;
+            if (ipn < end) {
+                const uint32_t o = (uint32_t)ipn * 8u;
+                nx_ = ld(p.x, o); ny_ = ld(p.y, o); nz_ = ld(p.z, o); nux = ld(p.ux, o); nuy = ld(p.uy, o);
+                nuz = ld(p.uz, o); nig = ld(p.ig, o); nw = ld(p.w, o);
+            }
+        }
+        valid = valid && !(isnan(x) || isnan(y) || isnan(z));
+        if (!valid) continue;
+        x += k.cdt_half * ig * ux;
+        y += k.cdt_half * ig * uy;
+        z += k.cdt_half * ig * uz;
+        double eb[6];
+        gather_global_3d(g, (x - g.x0) * inv_dx, (y - g.y0) * inv_dy, (z - g.z0) * inv_dz, eb);
+        boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
+        x += k.cdt_half * ig * ux;
+        y += k.cdt_half * ig * uy;
+        z += k.cdt_half * ig * uz;
+        double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+        AxisW ax, ay, az;
+        axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, inv_dx);
+        axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, inv_dy);
+        axis_window(az, z - vz * 0.5 * k.dt - g.z0, z + vz * 0.5 * k.dt - g.z0, inv_dz);
+        // the LDS path is valid iff the whole 4 x 4 x 4 window lies inside the staged region; anything
+        // else (drifted further than the margin since the sort, non-finite input) goes to the overflow
+        // list untouched -- nothing has been stored or deposited yet
+        const int bx = ax.base - r0[0], by = ay.base - r0[1], bz = az.base - r0[2];
+        if ((unsigned)bx > (unsigned)(R3X - 4) || (unsigned)by > (unsigned)(R3Y - 4) ||
+            (unsigned)bz > (unsigned)(R3Z - 4)) {
+            uint32_t slot = atomicAdd(overflow_count, 1u);
+            overflow[slot] = (uint32_t)ip;
+            continue;
+        }
+        if (p.eb[0]) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+        }
+        {
+            double xs = x, ys = y, zs = z;
+            finish_position_3d(xs, ys, zs, k);
+            const uint32_t o = (uint32_t)ip * 8u;
+            st(p.x, o, xs); st(p.y, o, ys); st(p.z, o, zs);
+            st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
+        }
+        const int b0 = (bx * R3Y + by) * R3Z + bz;
+        esirkepov_3d(ax, ay, az, w, k.q, g.dx, g.dy, g.dz, k.dt,
+                     [&](int i, int j, int kk, double djx, double djy, double djz, double dr) {
+                         // window plane 3 of an axis carries exact zeros unless the particle changed
+                         // cell along that axis (see the 2-D kernel)
+                         bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) &&
+                                   (kk < 3 || !az.tail_zero);
+                         if (on) {
+                             int o = b0 + (i * R3Y + j) * R3Z + kk;
+                             atomicAdd(&s_j[0][o], djx);
+                             atomicAdd(&s_j[1][o], djy);
+                             atomicAdd(&s_j[2][o], djz);
+                             atomicAdd(&s_j[3][o], dr);
+                         }
+                     });
+    }
+    __syncthreads();
+    // flush: one FP64 global atomic per touched node and component, on the torus
+    {
+        double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
+        for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
+            int lz = t % R3Z, ly = (t / R3Z) % R3Y, lx = t / (R3Z * R3Y);
+            long gi = ((long)torus(r0[0] + lx + g.ng, g.NX) * g.NY + torus(r0[1] + ly + g.ng, g.NY)) * g.NZ +
+                      torus(r0[2] + lz + g.ng, g.NZ);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = s_j[c][t];
+                if (v != 0.0) atomicAdd(&dst[c][gi], v);
+            }
+        }
+    }
+}
+
+static PushK3 make_pushk3(const lpa_push_params *pp) {
     PushK3 k;
     k.dt = pp->dt; k.q = pp->q;
     k.efactor = pp->q * pp->dt / (2 * pp->m * LPA_C);
@@ -183,9 +330,58 @@ extern "C" int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, co
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
         k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
     }
+    return k;
+}
+
+static int check_push3(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const char *name) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "%s: bad grid", name);
+    LPA_REQUIRE(lpa_part_ok(p, 3), "%s: bad particle store", name);
+    LPA_REQUIRE(pp && pp->dt > 0 && pp->m > 0, "%s: dt and m must be > 0", name);
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *p,
+                                        const lpa_push_params *pp, const uint32_t *list,
+                                        const uint32_t *list_count, int64_t max_count, void *stream) {
+    if (int e = check_push3(g, p, pp, "lpa_push_deposit_list_3d")) return e;
+    LPA_REQUIRE(list && list_count && max_count >= 0, "lpa_push_deposit_list_3d: bad list");
+    if (max_count == 0 || p->n == 0) return LPA_OK;
+    long nb = (max_count + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_push_deposit_list_3d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       make_gridv(g, 3), make_partv(p), make_pushk3(pp), list, list_count);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_list_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles *p,
+                                         const lpa_push_params *pp, const lpa_tiling *t,
+                                         uint32_t *overflow, uint32_t *overflow_count, void *stream) {
+    if (int e = check_push3(g, p, pp, "lpa_push_deposit_tiled_3d")) return e;
+    LPA_REQUIRE(t && t->blk_tile && t->blk_begin && t->blk_end && t->n_blocks && t->max_blocks > 0 &&
+                    overflow && overflow_count,
+                "lpa_push_deposit_tiled_3d: bad tiling");
+    LPA_REQUIRE(t->tiles_x == (g->nx + T3X - 1) / T3X && t->tiles_y == (g->ny + T3Y - 1) / T3Y &&
+                    t->tiles_z == (g->nz + T3Z - 1) / T3Z,
+                "lpa_push_deposit_tiled_3d: tiling does not match the grid");
+    LPA_REQUIRE(p->is_dead == nullptr,
+                "lpa_push_deposit_tiled_3d: tile-binned stores carry no is_dead array (dead = NaN x)");
+    if (t->n_sorted == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_push_deposit_tiled_3d, dim3(t->max_blocks), dim3(K13_THREADS), 0, (hipStream_t)stream,
+                       make_gridv(g, 3), make_partv(p), make_pushk3(pp), t->blk_tile, t->blk_begin, t->blk_end,
+                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
+                                   int64_t first, int64_t count, void *stream) {
+    if (int e = check_push3(g, p, pp, "lpa_push_deposit_3d")) return e;
+    LPA_REQUIRE(first >= 0 && count >= 0 && first + count <= p->n, "lpa_push_deposit_3d: bad range");
+    if (count == 0) return LPA_OK;
     long nb = (count + 255) / 256;
     hipLaunchKernelGGL(k_push_deposit_global_3d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       make_gridv(g, 3), make_partv(p), k, (long)first, (long)count);
+                       make_gridv(g, 3), make_partv(p), make_pushk3(pp), (long)first, (long)count);
     LPA_CHECK_LAUNCH("lpa_push_deposit_3d");
     return LPA_OK;
 }

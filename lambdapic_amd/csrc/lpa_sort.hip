@@ -46,9 +46,18 @@ struct SortWs {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
+static_assert(T3X * T3Y * T3Z == TCELLS, "3-D tiles hold 256 cells like the 2-D ones");
+
+// tiles of the grid: 2-D (nz <= 1) or 3-D
+static int tile_count(const lpa_grid *g) {
+    if (g->nz > 1)
+        return ((g->nx + T3X - 1) / T3X) * ((g->ny + T3Y - 1) / T3Y) * ((g->nz + T3Z - 1) / T3Z);
+    return ((g->nx + TX - 1) / TX) * ((g->ny + TY - 1) / TY);
+}
+
 static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
-    int tx = (g->nx + TX - 1) / TX, ty = (g->ny + TY - 1) / TY;
-    int nt = tx * ty;
+    int nt = tile_count(g);
     int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return base ? base + o : nullptr; };
@@ -70,7 +79,7 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
 }
 
 extern "C" int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity) {
-    if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;
+    if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;  // nz > 1 selects the 3-D tiles
     // sized for the smallest block size accepted by lpa_sort_tiles_2d
     return ws_layout(g, capacity, 1024, nullptr, nullptr);
 }
@@ -80,6 +89,26 @@ extern "C" const int32_t *lpa_sort_live_count(void *workspace) {
 }
 
 constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;
+
+// rank inside the cell: lanes that share a cell elect a leader that reserves the whole group with one
+// atomic; after 4 rounds the remaining lanes reserve their slots individually
+__device__ __forceinline__ uint32_t cell_rank(bool live, uint32_t ck, int32_t *cell_cnt) {
+    uint32_t r = 0;
+    unsigned long long todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; round < 4 && todo; round++) {
+        int leader = __ffsll((long long)todo) - 1;
+        uint32_t lk = __shfl(ck, leader, 64);
+        unsigned long long grp = __ballot(live && ck == lk) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = (uint32_t)atomicAdd(&cell_cnt[lk], (int32_t)__popcll(grp));
+        base = __shfl(base, leader, 64);
+        if ((grp >> lane) & 1ull) r = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+        todo &= ~grp;
+    }
+    if ((todo >> lane) & 1ull) r = (uint32_t)atomicAdd(&cell_cnt[ck], 1);
+    return r;
+}
 
 __global__ void __launch_bounds__(256) k_cell_count(PartV p, double x0, double y0, double inv_dx,
                                                     double inv_dy, int nx, int ny, int tiles_y,
@@ -100,23 +129,35 @@ __global__ void __launch_bounds__(256) k_cell_count(PartV p, double x0, double y
             ck = (uint32_t)(tile * TCELLS + (is % TX) * TY + (js % TY));
         }
     }
-    // rank inside the cell.  Lanes that share a cell elect a leader that reserves the whole group
-    // with one atomic (cell-major input: 1-3 rounds); after 4 rounds (striped or unsorted input:
-    // every lane in a different cell) the remaining lanes reserve their slots individually.
-    uint32_t r = 0;
-    unsigned long long todo = __ballot(live);
-    const int lane = threadIdx.x & 63;
-    for (int round = 0; round < 4 && todo; round++) {
-        int leader = __ffsll((long long)todo) - 1;
-        uint32_t lk = __shfl(ck, leader, 64);
-        unsigned long long grp = __ballot(live && ck == lk) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = (uint32_t)atomicAdd(&cell_cnt[lk], (int32_t)__popcll(grp));
-        base = __shfl(base, leader, 64);
-        if ((grp >> lane) & 1ull) r = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
-        todo &= ~grp;
+    uint32_t r = cell_rank(live, ck, cell_cnt);
+    if (ip < p.n) {
+        key[ip] = ck;
+        rank[ip] = r;
     }
-    if ((todo >> lane) & 1ull) r = (uint32_t)atomicAdd(&cell_cnt[ck], 1);
+}
+
+// 3-D key: tile-major, inside the tile (lx * 4 + ly) * 16 + lz (z fastest, like the grid)
+__global__ void __launch_bounds__(256) k_cell_count_3d(PartV p, double x0, double y0, double z0,
+                                                       double inv_dx, double inv_dy, double inv_dz, int nx,
+                                                       int ny, int nz, int tiles_y, int tiles_z,
+                                                       int32_t *cell_cnt, uint32_t *key, uint32_t *rank) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    uint32_t ck = KEY_DEAD;
+    if (ip < p.n) {
+        double x = p.x[ip], y = p.y[ip], z = p.z[ip];
+        live = !((p.dead && p.dead[ip]) || isnan(x) || isnan(y) || isnan(z));
+        if (live) {
+            int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5),
+                ks = ifloor((z - z0) * inv_dz + 0.5);
+            is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
+            js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
+            ks = ks < 0 ? 0 : (ks >= nz ? nz - 1 : ks);
+            int tile = ((is / T3X) * tiles_y + js / T3Y) * tiles_z + ks / T3Z;
+            ck = (uint32_t)(tile * TCELLS + ((is % T3X) * T3Y + (js % T3Y)) * T3Z + (ks % T3Z));
+        }
+    }
+    uint32_t r = cell_rank(live, ck, cell_cnt);
     if (ip < p.n) {
         key[ip] = ck;
         rank[ip] = r;
@@ -275,35 +316,47 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
     }
 }
 
-extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
-                                 void *workspace, int64_t workspace_bytes, int32_t block_particles,
-                                 int32_t order, lpa_tiling *out, void *stream) {
-    LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0, "lpa_sort_tiles_2d: bad grid");
-    LPA_REQUIRE(lpa_part_ok(src, 2) && lpa_part_ok(dst, 2) && workspace && out,
-                "lpa_sort_tiles_2d: bad particle stores / workspace");
-    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED, "lpa_sort_tiles_2d: bad order");
-    LPA_REQUIRE(src->n < (1ll << 31) - 1, "lpa_sort_tiles_2d: more than 2^31 particles in one store");
-    LPA_REQUIRE(dst->n >= src->n, "lpa_sort_tiles_2d: dst capacity (dst->n) smaller than src->n");
-    LPA_REQUIRE(block_particles >= 1024, "lpa_sort_tiles_2d: block_particles must be >= 1024");
-    LPA_REQUIRE(dst->x != src->x, "lpa_sort_tiles_2d: the sort is out of place");
+static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_particles *src,
+                      const lpa_particles *dst, void *workspace, int64_t workspace_bytes,
+                      int32_t block_particles, int32_t order, lpa_tiling *out, void *stream) {
+    LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && (dim == 2 || (g->nz > 1 && g->dz > 0)),
+                "%s: bad grid", name);
+    LPA_REQUIRE(lpa_part_ok(src, dim) && lpa_part_ok(dst, dim) && workspace && out,
+                "%s: bad particle stores / workspace", name);
+    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED, "%s: bad order", name);
+    LPA_REQUIRE(src->n < (1ll << 31) - 1, "%s: more than 2^31 particles in one store", name);
+    LPA_REQUIRE(dst->n >= src->n, "%s: dst capacity (dst->n) smaller than src->n", name);
+    LPA_REQUIRE(block_particles >= 1024, "%s: block_particles must be >= 1024", name);
+    LPA_REQUIRE(dst->x != src->x, "%s: the sort is out of place", name);
+    lpa_grid gg = *g;
+    if (dim == 2) gg.nz = 1;
     SortWs w;
-    int64_t need = ws_layout(g, src->n, block_particles, (char *)workspace, &w);
+    int64_t need = ws_layout(&gg, src->n, block_particles, (char *)workspace, &w);
     if (need > workspace_bytes) {
-        lpa_set_error("lpa_sort_tiles_2d: workspace %lld B < %lld B", (long long)workspace_bytes,
-                      (long long)need);
+        lpa_set_error("%s: workspace %lld B < %lld B", name, (long long)workspace_bytes, (long long)need);
         return LPA_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int tiles_x = (g->nx + TX - 1) / TX, tiles_y = (g->ny + TY - 1) / TY;
+    int tiles_x, tiles_y, tiles_z = 0;
+    if (dim == 2) {
+        tiles_x = (g->nx + TX - 1) / TX; tiles_y = (g->ny + TY - 1) / TY;
+    } else {
+        tiles_x = (g->nx + T3X - 1) / T3X; tiles_y = (g->ny + T3Y - 1) / T3Y; tiles_z = (g->nz + T3Z - 1) / T3Z;
+    }
     if (hipMemsetAsync(w.cell_cnt, 0, sizeof(int32_t) * (size_t)w.ntiles * TCELLS, st) != hipSuccess) {
-        lpa_set_error("lpa_sort_tiles_2d: memset failed");
+        lpa_set_error("%s: memset failed", name);
         return LPA_ERR_HIP;
     }
     PartV sv = make_partv(src), dv = make_partv(dst);
     if (src->n > 0) {
         unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
-                           1.0 / g->dy, g->nx, g->ny, tiles_y, w.cell_cnt, w.key, w.rank);
+        if (dim == 2)
+            hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
+                               1.0 / g->dy, g->nx, g->ny, tiles_y, w.cell_cnt, w.key, w.rank);
+        else
+            hipLaunchKernelGGL(k_cell_count_3d, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, g->z0,
+                               1.0 / g->dx, 1.0 / g->dy, 1.0 / g->dz, g->nx, g->ny, g->nz, tiles_y, tiles_z,
+                               w.cell_cnt, w.key, w.rank);
         LPA_CHECK_LAUNCH("k_cell_count");
     }
     hipLaunchKernelGGL(k_tile_sum, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_cnt);
@@ -325,6 +378,8 @@ extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, co
     }
     out->tiles_x = tiles_x;
     out->tiles_y = tiles_y;
+    out->tiles_z = tiles_z;
+    out->reserved_ = 0;
     out->n_sorted = src->n;  // upper bound known on the host; the exact count is hdr->n_live
     out->max_blocks = w.max_blocks;
     out->order = order;
@@ -334,6 +389,20 @@ extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, co
     out->blk_end = w.blk_end;
     out->n_blocks = &w.hdr->n_blocks;
     return LPA_OK;
+}
+
+extern "C" int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                                 void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                                 int32_t order, lpa_tiling *out, void *stream) {
+    return sort_tiles(2, "lpa_sort_tiles_2d", g, src, dst, workspace, workspace_bytes, block_particles, order,
+                      out, stream);
+}
+
+extern "C" int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                                 void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                                 int32_t order, lpa_tiling *out, void *stream) {
+    return sort_tiles(3, "lpa_sort_tiles_3d", g, src, dst, workspace, workspace_bytes, block_particles, order,
+                      out, stream);
 }
 
 // =====================================================================================================

@@ -1,7 +1,9 @@
 """PicEngine3D -- device-resident 3-D step on one GPU (periodic box), same stage order as
-``PicEngine2D``.  This round the 3-D particle kernel is the global-memory form
-(``lpa_push_deposit_3d``: 27-point gather, 4x4x4 Esirkepov window, FP64 global atomics); the 3-D
-LDS-tiled kernel and the 3-D slab exchange are the next rows.
+``PicEngine2D``.  Particles are binned into 4 x 4 x 16-cell tiles (``lpa_sort_tiles_3d``) and pushed by the
+LDS-tiled kernel (``lpa_push_deposit_tiled_3d``: J / rho of the tile accumulated in LDS, E / B
+gathered from global memory) + the overflow list; grids whose extents are not multiples of the tile
+use the global-memory form (``lpa_push_deposit_3d``).  The 3-D slab exchange is the next row
+(DESIGN.md section 7).
 
 Replaces, per step: ``update_efield/bfield_patches_3d`` (`core/maxwell/cpu.py:115-158`),
 ``sync_guard_fields_3d`` / ``sync_currents_3d`` with a self neighbour (`core/patch/sync_fields3d.c`),
@@ -24,8 +26,14 @@ ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
 
 
 class PicEngine3D:
-    def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0"):
+    def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
+                 block_particles=4096):
         self.L = lib()
+        fits = nx % _lib.LPA_TILE3_X == 0 and ny % _lib.LPA_TILE3_Y == 0 and nz % _lib.LPA_TILE3_Z == 0
+        if tiled and not fits:
+            raise ValueError("tiled 3-D path needs nx, ny multiples of 4 and nz a multiple of 16")
+        self.tiled = fits if tiled is None else bool(tiled)
+        self.sort_interval, self.block_particles = int(sort_interval), int(block_particles)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LpaError("PicEngine3D needs a GPU device; there is no CPU path")
@@ -70,11 +78,48 @@ class PicEngine3D:
         for k in range(6):
             p.part_eb[k] = None
         p.id, p.is_dead = None, None
-        self.species.append({"q": float(q), "m": float(m), "data": data, "c": p, "n": n})
+        self.species.append({"q": float(q), "m": float(m), "data": data, "c": p, "n": n, "alt": None,
+                             "tiling": None, "since": 0, "ws": None})
         return len(self.species) - 1
 
+    @staticmethod
+    def _cstruct(data, n):
+        p = _lib.lpa_particles()
+        p.n = int(n)
+        for k, a in enumerate(ATTRS3):
+            setattr(p, a, data[k].data_ptr())
+        for k in range(6):
+            p.part_eb[k] = None
+        p.id, p.is_dead = None, None
+        return p
+
+    def sort(self, i):
+        """tile-bin species ``i`` (replaces sort_particles_patches_3d, core/sort/cpu3d.c); one host
+        sync for the live count"""
+        sp = self.species[i]
+        cap = sp["data"].shape[1]
+        if sp["alt"] is None:
+            sp["alt"] = torch.empty_like(sp["data"])
+            nbytes = self.L.lpa_sort_workspace_bytes(self._g(), cap)
+            sp["ws"] = {"sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
+                        "overflow": torch.empty(max(cap, 1), dtype=torch.int32, device=self.device),
+                        "count": torch.zeros(1, dtype=torch.int32, device=self.device),
+                        "tiling": _lib.lpa_tiling()}
+        ws = sp["ws"]
+        src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
+        check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
+                                       ws["sort"].numel(), self.block_particles, _lib.LPA_ORDER_STRIPED,
+                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
+        n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
+        sp["data"], sp["alt"] = sp["alt"], sp["data"]
+        sp["n"] = n_live
+        sp["c"] = self._cstruct(sp["data"], n_live)
+        ws["tiling"].n_sorted = n_live
+        sp["tiling"] = ws["tiling"]
+        sp["since"] = 0
+
     def download_species(self, i):
-        d = self.species[i]["data"].cpu().numpy()
+        d = self.species[i]["data"][:, : self.species[i]["n"]].cpu().numpy()
         return {a: d[k] for k, a in enumerate(ATTRS3)}
 
     def _g(self):
@@ -92,7 +137,19 @@ class PicEngine3D:
             pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], 7
             for a in range(3):
                 pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.n[a] * self.d[a] - self.d[a] / 2
-            check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
+            if not self.tiled:
+                check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
+                continue
+            if sp["tiling"] is None or sp["since"] >= self.sort_interval:
+                self.sort(self.species.index(sp))
+            ws = sp["ws"]
+            ws["count"].zero_()
+            check(L.lpa_push_deposit_tiled_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
+                                              ws["overflow"].data_ptr(), ws["count"].data_ptr(), st),
+                  "lpa_push_deposit_tiled_3d")
+            check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ws["overflow"].data_ptr(),
+                                             ws["count"].data_ptr(), sp["n"], st), "lpa_push_deposit_list_3d")
+            sp["since"] += 1
         check(L.lpa_current_fold(g, 7, st), "lpa_current_fold")
         check(L.lpa_fdtd_b_3d(g, 0.5 * dt, st), "lpa_fdtd_b_3d")
         check(L.lpa_guard_wrap(g, 2, 7, st), "lpa_guard_wrap")

@@ -65,3 +65,47 @@ def test_3d_step_vs_oracle():
     got = eng.download_species(0)
     for a in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma"):
         assert_close(got[a], getattr(parts[0], a), 1e-11, what=a)
+
+
+@pytest.mark.parametrize("uth,sort_interval", [(0.3, 4), (0.02, 3)])
+def test_3d_tiled_step_vs_oracle(uth, sort_interval):
+    """the tile-sorted path: lpa_sort_tiles_3d (4 x 4 x 16-cell tiles) + LDS-tiled kernel + overflow list
+    against the oracle's 3-D step.  Hot case: particles drift beyond the tile margin between sorts
+    (overflow list) and wrap around the box; cold case: everything stays on the LDS path."""
+    nx, ny, nz = 12, 8, 32
+    dx, dy, dz = 4e-8, 5e-8, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    rng = np.random.default_rng(5)
+    n = nx * ny * nz * 6
+    w = 1e27 * dx * dy * dz / 6
+    e = _species(rng, n, nx, ny, nz, dx, dy, dz, uth, w)
+    ion = _species(rng, n, nx, ny, nz, dx, dy, dz, 0.001, w)
+    qe, me = -oracle.E_CHARGE, oracle.M_E
+    species = [(qe, me), (-qe, 1836.0 * me)]
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, 3)
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=True, sort_interval=sort_interval, block_particles=1024)
+    assert eng.tiled
+    eng.add_species(*species[0], e)
+    eng.add_species(*species[1], ion)
+    parts = [copy.deepcopy(e), copy.deepcopy(ion)]
+    lo = (-dx / 2, -dy / 2, -dz / 2)
+    hi = (nx * dx - dx / 2, ny * dy - dy / 2, nz * dz - dz / 2)
+    seen_overflow = 0
+    for it in range(10):
+        driver.step_3d_periodic(f, parts, dt, species, lo, hi)
+        eng.step(dt)
+        seen_overflow = max(seen_overflow, int(eng.species[0]["ws"]["count"].item()))
+        d = eng.diagnostics()
+        assert d["field_energy"] == pytest.approx(driver.field_energy_3d(f), rel=1e-10)
+        for k, (q, m) in enumerate(species):
+            ke = float(np.sum(parts[k].w * (1 / parts[k].inv_gamma - 1))) * m * C ** 2
+            assert d["kinetic"][k] == pytest.approx(ke, rel=1e-12)
+            assert d["nalive"][k] == n
+    # cold: only particles that wrapped around the periodic box since the last sort leave the LDS path
+    assert (seen_overflow > 0.01 * n) == (uth > 0.1)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+        assert_close(eng.download_field(a), getattr(f, a), 1e-9, what=a)
+    got = eng.download_species(0)
+    og, oo = np.argsort(got["x"]), np.argsort(parts[0].x)         # the sort permuted the store
+    for a in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma"):
+        assert_close(got[a][og], getattr(parts[0], a)[oo], 1e-11, what=a)

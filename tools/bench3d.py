@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """3-D measurement (not the headline bench): one GPU's share of BASELINE config C5 -- a 64x256x256-cell
-periodic slab (512x256x256 / 8 GPUs), 8 ppc thermal plasma -- through PicEngine3D (global-memory
-fused kernel).  Prints one JSON line with particle-updates/s and the algorithmic HBM rate
+periodic slab (512x256x256 / 8 GPUs), 8 ppc thermal plasma -- through PicEngine3D (tile sort + LDS-tiled
+kernel, or --global for the global-memory kernel).  Prints one JSON line with particle-updates/s and the algorithmic HBM rate
 (121 B per 3-D particle-update)."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -13,12 +13,15 @@ from lambdapic_amd.engine3d import PicEngine3D, ATTRS3
 ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=64); ap.add_argument("--ny", type=int, default=256)
 ap.add_argument("--nz", type=int, default=256); ap.add_argument("--ppc", type=int, default=8)
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
+ap.add_argument("--global", dest="glob", action="store_true"); ap.add_argument("--sort-interval", type=int, default=10)
+ap.add_argument("--block-particles", type=int, default=4096)
 a = ap.parse_args()
 lam = 0.8e-6
 dx, dy, dz = lam / 20, lam / 10, lam / 10                 # example/laser-target-3d.py:26-31
 dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
-eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3)
+eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3, tiled=not a.glob, sort_interval=a.sort_interval,
+                  block_particles=a.block_particles)
 n = a.nx * a.ny * a.nz * a.ppc
 dev = eng.device
 g = torch.Generator(device=dev).manual_seed(1)
@@ -36,7 +39,8 @@ data[7] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE 
 p = _lib.lpa_particles(); p.n = n
 for k, name in enumerate(ATTRS3):
     setattr(p, name, data[k].data_ptr())
-eng.species.append({"q": -constants.E_CHARGE, "m": constants.M_E, "data": data, "c": p, "n": n})
+eng.species.append({"q": -constants.E_CHARGE, "m": constants.M_E, "data": data, "c": p, "n": n, "alt": None,
+                    "tiling": None, "since": 0, "ws": None})
 for _ in range(a.warmup):
     eng.step(dt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -44,7 +48,9 @@ for _ in range(a.steps):
     eng.step(dt)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = eng.diagnostics()
-print(json.dumps({"metric": "particle-updates/sec (3-D, global-memory kernel)", "value": n * a.steps / el,
+ov = int(eng.species[0]["ws"]["count"].item()) if eng.species[0]["ws"] else None
+print(json.dumps({"metric": "particle-updates/sec (3-D, %s kernel)" % ("global-memory" if a.glob else "LDS-tiled"),
+                  "overflow_last_step": ov, "sort_interval": a.sort_interval, "value": n * a.steps / el,
                   "ms_per_step": 1e3 * el / a.steps, "particles": n, "cells": [a.nx, a.ny, a.nz],
                   "algorithmic_GBps": (121.0 * n) * a.steps / el / 1e9, "alive": d["nalive"][0],
                   "charge_rel_err": abs(d["charge"] / (n * float(data[7][0]) * -constants.E_CHARGE) - 1)}))
