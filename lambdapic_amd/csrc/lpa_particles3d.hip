@@ -194,23 +194,49 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_3d(GridV g, PartV p, 
 // =====================================================================================================
 // K1-tiled, 3-D.  Tiles of 4 x 4 x 16 cells (256 cells, z fastest), STRIPED order: a 16-lane group of a
 // wave sits in 16 consecutive z-cells of one (x, y) column, and the LDS services a 64-bit atomic in
-// 16-lane groups -- conflict free whatever the row strides.  J / rho of the tile + 3 nodes on every side
-// (margin 1 + the 2 nodes a deposit window reaches beyond the mid-step node) live in LDS:
-// 4 x 10 x 10 x 22 f64 = 70 KB, two 512-thread workgroups per CU.  E and B are gathered from global
-// memory through L1/L2 (a 6-component FP64 image with its halo does not fit beside J): 162 cached loads
-// per particle, tile-sorted so neighbouring lanes share lines.
+// 16-lane groups -- conflict free whatever the row strides.  One 512-thread workgroup per CU owns
+// 152 KB of LDS: J / rho of the tile + 3 nodes on every side (margin 1 + the 2 nodes a deposit window
+// reaches beyond the mid-step node): 4 x 10 x 10 x 22 f64 = 70 KB, and E / B on the nodes the gather can
+// touch (mid-step node - 2 ... + 1 with the node within tile +- 1): 6 x 9 x 9 x 21 f64 = 82 KB.
+// (Gathering E / B from global memory instead -- 162 cached 8-byte loads per particle -- was bound by
+// the address rate of the texture path: 11.8 ms per step on C5's slab against 13.2 ms total.)
 // =====================================================================================================
 constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
 constexpr int H3 = LPA_TILE3_MARGIN + 2;
 constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10 x 10 x 22
 constexpr int R3N = R3X * R3Y * R3Z;                                       // 2200
+constexpr int G3L = LPA_TILE3_MARGIN + 2, G3H = LPA_TILE3_MARGIN + 1;      // gather reach below / above the tile
+constexpr int E3X = T3X + G3L + G3H, E3Y = T3Y + G3L + G3H, E3Z = T3Z + G3L + G3H;  // 9 x 9 x 21
+constexpr int E3N = E3X * E3Y * E3Z;                                       // 1701
 constexpr int K13_THREADS = 512;
+
+typedef const volatile __attribute__((address_space(3))) double *lds_ptr3;
+
+// 27-point gather from the LDS image of one component; (lx, ly, lz) = local index of the stencil
+// centre; evaluation order of interp_field_fast_3d (unified_pusher_3d.c:111-143): z outermost
+__device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, int lz, const double fx[3],
+                                             const double fy[3], const double fz[3]) {
+    lds_ptr3 c = (lds_ptr3)(f + (lx * E3Y + ly) * E3Z + lz);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double pl = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int o = (j - 1) * E3Z + (k - 1);
+            pl += fy[j] * (fx[0] * c[o - E3Y * E3Z] + fx[1] * c[o] + fx[2] * c[o + E3Y * E3Z]);
+        }
+        acc += fz[k] * pl;
+    }
+    return acc;
+}
 
 __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
     uint32_t *overflow, uint32_t *overflow_count) {
     __shared__ double s_j[4][R3N];
+    __shared__ double s_eb[6][E3N];
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
@@ -221,6 +247,17 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 4; c++) s_j[c][t] = 0.0;
+    }
+    const int e0[3] = {t0[0] - G3L, t0[1] - G3L, t0[2] - G3L};    // first node of the E/B image
+    {
+        const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
+        for (int t = threadIdx.x; t < E3N; t += blockDim.x) {
+            int lz = t % E3Z, ly = (t / E3Z) % E3Y, lx = t / (E3Z * E3Y);
+            long gi = ((long)torus(e0[0] + lx + g.ng, g.NX) * g.NY + torus(e0[1] + ly + g.ng, g.NY)) * g.NZ +
+                      torus(e0[2] + lz + g.ng, g.NZ);
+#pragma unroll
+            for (int c = 0; c < 6; c++) s_eb[c][t] = src[c][gi];
+        }
     }
     __syncthreads();
 
@@ -255,7 +292,39 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         y += k.cdt_half * ig * uy;
         z += k.cdt_half * ig * uz;
         double eb[6];
-        gather_global_3d(g, (x - g.x0) * inv_dx, (y - g.y0) * inv_dy, (z - g.z0) * inv_dz, eb);
+        {
+            double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy, zo = (z - g.z0) * inv_dz;
+            int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo);
+            int iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
+            int iz1 = ifloor(zo + 0.5), iz2 = ifloor(zo);
+            // LDS gather iff the mid-step node lies within tile +- margin (stencil: node - 2 ... + 1)
+            if ((unsigned)(ix1 - (t0[0] - LPA_TILE3_MARGIN)) >= (unsigned)(T3X + 2 * LPA_TILE3_MARGIN) ||
+                (unsigned)(iy1 - (t0[1] - LPA_TILE3_MARGIN)) >= (unsigned)(T3Y + 2 * LPA_TILE3_MARGIN) ||
+                (unsigned)(iz1 - (t0[2] - LPA_TILE3_MARGIN)) >= (unsigned)(T3Z + 2 * LPA_TILE3_MARGIN)) {
+                uint32_t slot = atomicAdd(overflow_count, 1u);
+                overflow[slot] = (uint32_t)ip;
+                continue;
+            }
+            double gx[3], hx[3], gy[3], hy[3], gz[3], hz[3];
+            tsc3(ix1 - xo, gx); tsc3(ix2 - xo + 0.5, hx);
+            tsc3(iy1 - yo, gy); tsc3(iy2 - yo + 0.5, hy);
+            tsc3(iz1 - zo, gz); tsc3(iz2 - zo + 0.5, hz);
+            const int lx1 = ix1 - e0[0], lx2 = ix2 - e0[0], ly1 = iy1 - e0[1], ly2 = iy2 - e0[1],
+                      lz1 = iz1 - e0[2], lz2 = iz2 - e0[2];
+            // stagger table: unified_pusher_3d.c:190-195
+            eb[0] = gather27_l(s_eb[0], lx2, ly1, lz1, hx, gy, gz);
+            __builtin_amdgcn_sched_barrier(0);
+            eb[1] = gather27_l(s_eb[1], lx1, ly2, lz1, gx, hy, gz);
+            __builtin_amdgcn_sched_barrier(0);
+            eb[2] = gather27_l(s_eb[2], lx1, ly1, lz2, gx, gy, hz);
+            __builtin_amdgcn_sched_barrier(0);
+            eb[3] = gather27_l(s_eb[3], lx1, ly2, lz2, gx, hy, hz);
+            __builtin_amdgcn_sched_barrier(0);
+            eb[4] = gather27_l(s_eb[4], lx2, ly1, lz2, hx, gy, hz);
+            __builtin_amdgcn_sched_barrier(0);
+            eb[5] = gather27_l(s_eb[5], lx2, ly2, lz1, hx, hy, gz);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
         x += k.cdt_half * ig * ux;
         y += k.cdt_half * ig * uy;
