@@ -1,15 +1,17 @@
-"""PicEngine3D -- device-resident 3-D step on one GPU (periodic box), same stage order as
+"""PicEngine3D -- device-resident 3-D step of one x-slab of a periodic box, same stage order as
 ``PicEngine2D``.  Particles are binned into 4 x 4 x 16-cell tiles (``lpa_sort_tiles_3d``) and pushed by the
-LDS-tiled kernel (``lpa_push_deposit_tiled_3d``: J / rho of the tile accumulated in LDS, E / B
-gathered from global memory) + the overflow list; grids whose extents are not multiples of the tile
-use the global-memory form (``lpa_push_deposit_3d``).  The 3-D slab exchange is the next row
-(DESIGN.md section 7).
+LDS-tiled kernel (``lpa_push_deposit_tiled_3d``: E / B and J / rho of the tile staged in LDS) + the
+overflow list; grids whose extents are not multiples of the tile use the global-memory form
+(``lpa_push_deposit_3d``).  With more than one rank the box is cut into x-slabs (x is the slowest
+index, so a face is ``ng`` contiguous y-z planes): guard planes, current folds and leaving particles
+travel to the two ring neighbours exactly as in 2-D (``dist.exchange_faces``); y and z wrap locally.
 
 Replaces, per step: ``update_efield/bfield_patches_3d`` (`core/maxwell/cpu.py:115-158`),
-``sync_guard_fields_3d`` / ``sync_currents_3d`` with a self neighbour (`core/patch/sync_fields3d.c`),
-``reset_current_cpu_3d`` (`core/current/cpu3d.c:185-240`), ``unified_boris_pusher_cpu_3d``
-(`core/pusher/unified/unified_pusher_3d.c:219-436`) and the periodic part of
-``sync_particles_3d`` (`core/patch/sync_particles_3d.c`).
+``sync_guard_fields_3d`` / ``sync_currents_3d`` (`core/patch/sync_fields3d.c`, MPI twins
+`core/mpi/sync_fields3d.c`), ``reset_current_cpu_3d`` (`core/current/cpu3d.c:185-240`),
+``unified_boris_pusher_cpu_3d`` (`core/pusher/unified/unified_pusher_3d.c:219-436`),
+``sort_particles_patches_3d`` (`core/sort/cpu3d.c`) and ``sync_particles_3d``
+(`core/patch/sync_particles_3d.c`, `core/mpi/sync_particles_3d.c`) for periodic boxes.
 """
 from __future__ import annotations
 
@@ -19,7 +21,8 @@ import numpy as np
 import torch
 
 from . import _lib, constants
-from ._lib import check, lib
+from ._lib import LPA_MIG_NATTR, check, lib
+from .dist import SlabComm, exchange_faces
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 
 ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
@@ -27,13 +30,18 @@ ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
 
 class PicEngine3D:
     def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
-                 block_particles=4096):
+                 block_particles=4096, comm=None, migrate_capacity=32768):
+        """``nx`` = cells of THIS rank's slab along x; the box is ``nx * comm.size`` cells long"""
         self.L = lib()
         fits = nx % _lib.LPA_TILE3_X == 0 and ny % _lib.LPA_TILE3_Y == 0 and nz % _lib.LPA_TILE3_Z == 0
         if tiled and not fits:
             raise ValueError("tiled 3-D path needs nx, ny multiples of 4 and nz a multiple of 16")
         self.tiled = fits if tiled is None else bool(tiled)
         self.sort_interval, self.block_particles = int(sort_interval), int(block_particles)
+        self.comm = comm or SlabComm(None, periodic=True, single=True)
+        if self.comm.size > 1 and not self.tiled:
+            raise ValueError("a slab decomposition needs the tile-sorted store (arrival area)")
+        self.migrate_capacity = int(migrate_capacity)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LpaError("PicEngine3D needs a GPU device; there is no CPU path")
@@ -41,17 +49,23 @@ class PicEngine3D:
         self.d = (float(dx), float(dy), float(dz))
         self.ng = int(n_guard)
         N = tuple(v + 2 * self.ng for v in self.n)
+        self.N = N
         self.buf = torch.zeros((10,) + N, dtype=torch.float64, device=self.device)
+        self.x0 = self.comm.rank * self.n[0] * self.d[0]
+        self.Lbox = (self.n[0] * self.comm.size * self.d[0], self.n[1] * self.d[1], self.n[2] * self.d[2])
         g = _lib.lpa_grid()
         g.nx, g.ny, g.nz, g.ng = *self.n, self.ng
         g.dx, g.dy, g.dz = self.d
-        g.x0 = g.y0 = g.z0 = 0.0
+        g.x0, g.y0, g.z0 = self.x0, 0.0, 0.0
         for k, name in enumerate(FIELD_ATTRS):
             setattr(g, name, self.buf[k].data_ptr())
         self.c = g
+        # axes wrapped locally: y and z always, x only when this rank owns the whole box
+        self.local_axes = 6 | (1 if self.comm.size == 1 else 0)
         self.species = []
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._halo = None
 
     @property
     def stream(self):
@@ -66,20 +80,25 @@ class PicEngine3D:
     def download_field(self, name):
         return np.ascontiguousarray(from_device_layout(self.view(name).cpu().numpy(), self.ng))
 
-    def add_species(self, q, m, host_particles):
-        """upload the live particles of one host bag (ParticlesBase-like with z)"""
+    # ---- particle store -------------------------------------------------------------------------------
+    def arrival_area(self):
+        return self.migrate_capacity * 2 * max(self.sort_interval, 1) if self.comm.size > 1 else 0
+
+    def add_species(self, q, m, host_particles, capacity=None):
+        """upload the live particles of one host bag (ParticlesBase-like with z); ``capacity`` = live
+        particles this rank must be able to hold (the arrival area is added)"""
         live = ~host_particles.is_dead
         n = int(live.sum())
-        data = torch.from_numpy(np.stack([getattr(host_particles, a)[live] for a in ATTRS3])).to(self.device)
-        p = _lib.lpa_particles()
-        p.n = n
-        for k, a in enumerate(ATTRS3):
-            setattr(p, a, data[k].data_ptr())
-        for k in range(6):
-            p.part_eb[k] = None
-        p.id, p.is_dead = None, None
-        self.species.append({"q": float(q), "m": float(m), "data": data, "c": p, "n": n, "alt": None,
-                             "tiling": None, "since": 0, "ws": None})
+        cap = max(int(capacity or n), n) + self.arrival_area()
+        data = torch.full((len(ATTRS3), max(cap, 1)), float("nan"), dtype=torch.float64, device=self.device)
+        if n:
+            data[:, :n] = torch.from_numpy(np.stack([getattr(host_particles, a)[live] for a in ATTRS3])).to(self.device)
+        return self.add_species_device(q, m, data, n)
+
+    def add_species_device(self, q, m, data, n):
+        """``data``: device tensor [8][capacity] in ATTRS3 order, the first ``n`` columns in use"""
+        self.species.append({"q": float(q), "m": float(m), "data": data, "c": self._cstruct(data, n), "n": int(n),
+                             "n_sorted": 0, "alt": None, "tiling": None, "since": 0, "ws": None})
         return len(self.species) - 1
 
     @staticmethod
@@ -93,70 +112,156 @@ class PicEngine3D:
         p.id, p.is_dead = None, None
         return p
 
-    def sort(self, i):
-        """tile-bin species ``i`` (replaces sort_particles_patches_3d, core/sort/cpu3d.c); one host
-        sync for the live count"""
-        sp = self.species[i]
-        cap = sp["data"].shape[1]
-        if sp["alt"] is None:
-            sp["alt"] = torch.empty_like(sp["data"])
-            nbytes = self.L.lpa_sort_workspace_bytes(self._g(), cap)
-            sp["ws"] = {"sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
-                        "overflow": torch.empty(max(cap, 1), dtype=torch.int32, device=self.device),
-                        "count": torch.zeros(1, dtype=torch.int32, device=self.device),
-                        "tiling": _lib.lpa_tiling()}
-        ws = sp["ws"]
-        src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
-        check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), self.block_particles, _lib.LPA_ORDER_STRIPED,
-                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
-        n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
-        sp["data"], sp["alt"] = sp["alt"], sp["data"]
-        sp["n"] = n_live
-        sp["c"] = self._cstruct(sp["data"], n_live)
-        ws["tiling"].n_sorted = n_live
-        sp["tiling"] = ws["tiling"]
-        sp["since"] = 0
-
     def download_species(self, i):
-        d = self.species[i]["data"][:, : self.species[i]["n"]].cpu().numpy()
+        sp = self.species[i]
+        d = sp["data"][:, : sp["n"]]
+        d = d[:, ~torch.isnan(d[0])].cpu().numpy()
         return {a: d[k] for k, a in enumerate(ATTRS3)}
 
     def _g(self):
         return C.byref(self.c)
 
+    def _ws(self, sp):
+        if sp["ws"] is None:
+            cap = sp["data"].shape[1]
+            sp["alt"] = torch.empty_like(sp["data"])
+            nbytes = self.L.lpa_sort_workspace_bytes(self._g(), cap)
+            cnt = torch.zeros(4, dtype=torch.int32, device=self.device)   # 0: overflow, 1: arrivals
+            sp["ws"] = {"sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
+                        "overflow": torch.empty(max(cap, 1), dtype=torch.int32, device=self.device),
+                        "counters": cnt, "count": cnt[0:1], "tiling": _lib.lpa_tiling(), "mig": None}
+        return sp["ws"]
+
+    def sort(self, i):
+        """tile-bin species ``i`` (replaces sort_particles_patches_3d, core/sort/cpu3d.c); drops dead
+        slots; one host sync for the live count"""
+        sp = self.species[i]
+        ws = self._ws(sp)
+        cap = sp["data"].shape[1]
+        src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
+        check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
+                                       ws["sort"].numel(), self.block_particles, _lib.LPA_ORDER_STRIPED,
+                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
+        n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
+        area = self.arrival_area()
+        if int(ws["counters"][1].item()) > area:
+            raise _lib.LpaError("arrival area overflow (raise migrate_capacity)")
+        if n_live + area > cap:
+            raise _lib.LpaError(f"particle capacity {cap} < live {n_live} + arrival area {area}")
+        sp["data"], sp["alt"] = sp["alt"], sp["data"]
+        if area:
+            sp["data"][0, n_live:n_live + area] = float("nan")
+        sp["n_sorted"], sp["n"] = n_live, n_live + area
+        sp["c"] = self._cstruct(sp["data"], sp["n"])
+        ws["counters"].zero_()
+        ws["tiling"].n_sorted = n_live
+        sp["tiling"] = ws["tiling"]
+        sp["since"] = 0
+
+    # ---- guards / currents between slabs (sync_guard_fields_3d, sync_currents_3d) -------------------
+    def _halo_bufs(self):
+        if self._halo is None:
+            n = 4 * self.ng * self.N[1] * self.N[2]
+            mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)
+            self._halo = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
+        return self._halo
+
+    def sync_guard_fields(self, which):
+        """``which``: 1 = E, 2 = B"""
+        st = self.stream
+        check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
+        if self.comm.size > 1:
+            n = 3 * self.ng * self.N[1] * self.N[2]
+            h = {k: v[:n] for k, v in self._halo_bufs().items()}
+            exchange_faces(
+                self.comm,
+                lambda side, b: check(self.L.lpa_halo_pack_guard_src(self._g(), which, side, b.data_ptr(), st),
+                                      "lpa_halo_pack_guard_src"),
+                lambda side, b: check(self.L.lpa_halo_unpack_guard(self._g(), which, side, b.data_ptr(), st),
+                                      "lpa_halo_unpack_guard"),
+                h)      # whole planes travel: the sender wrapped their y / z guard strips already
+
+    def sync_currents(self):
+        st = self.stream
+        if self.comm.size > 1:
+            h = self._halo_bufs()
+            exchange_faces(
+                self.comm,
+                lambda side, b: check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st),
+                                      "lpa_halo_pack_current"),
+                lambda side, b: check(self.L.lpa_halo_unpack_current(self._g(), side, b.data_ptr(), st),
+                                      "lpa_halo_unpack_current"),
+                h)
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+
+    def sync_particles(self, i):
+        """leavers travel to the ring neighbours in one fixed-size message per face (count in band)"""
+        if self.comm.size == 1:
+            return
+        sp = self.species[i]
+        ws, cap, st = self._ws(sp), self.migrate_capacity, self.stream
+        if ws["mig"] is None:
+            mk = lambda: torch.zeros(1 + LPA_MIG_NATTR * cap, dtype=torch.float64, device=self.device)
+            ws["mig"] = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
+        m = ws["mig"]
+        xlo = self.x0 - self.d[0] / 2
+        xhi = self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
+        check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
+                                        cap, st), "lpa_migrate_pack_x")
+        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        cur = ws["counters"][1:2].data_ptr()
+        area = self.arrival_area()
+        shift_lo = -self.Lbox[0] if self.comm.rank == 0 else 0.0
+        shift_hi = self.Lbox[0] if self.comm.rank == self.comm.size - 1 else 0.0
+        check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_lo"].data_ptr(), cap,
+                                        shift_lo, st), "unpack lo")
+        check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_hi"].data_ptr(), cap,
+                                        shift_hi, st), "unpack hi")
+
+    # ---- one step --------------------------------------------------------------------------------------
+    def push_deposit(self, i, dt):
+        L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
+        pp = _lib.lpa_push_params()
+        pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes
+        for a in range(3):
+            pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.Lbox[a] - self.d[a] / 2
+        if not self.tiled:
+            check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
+            return
+        if sp["tiling"] is None or sp["since"] >= self.sort_interval:
+            self.sort(i)
+        ws = sp["ws"]
+        ws["count"].zero_()
+        check(L.lpa_push_deposit_tiled_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
+                                          ws["overflow"].data_ptr(), ws["count"].data_ptr(), st),
+              "lpa_push_deposit_tiled_3d")
+        check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ws["overflow"].data_ptr(),
+                                         ws["count"].data_ptr(), sp["n_sorted"], st), "lpa_push_deposit_list_3d")
+        loose = sp["n"] - sp["n_sorted"]        # arrival area: pushed by the global kernel until the next sort
+        if loose > 0:
+            check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), sp["n_sorted"], loose, st),
+                  "lpa_push_deposit_3d")
+        sp["since"] += 1
+
     def step(self, dt):
         L, st, g = self.L, self.stream, self._g()
         check(L.lpa_fdtd_e_3d(g, 0.5 * dt, self.eps0, st), "lpa_fdtd_e_3d")
-        check(L.lpa_guard_wrap(g, 1, 7, st), "lpa_guard_wrap")
+        self.sync_guard_fields(1)
         check(L.lpa_fdtd_b_3d(g, 0.5 * dt, st), "lpa_fdtd_b_3d")
-        check(L.lpa_guard_wrap(g, 2, 7, st), "lpa_guard_wrap")
+        self.sync_guard_fields(2)
         check(L.lpa_reset_current(g, st), "lpa_reset_current")
-        for sp in self.species:
-            pp = _lib.lpa_push_params()
-            pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], 7
-            for a in range(3):
-                pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.n[a] * self.d[a] - self.d[a] / 2
-            if not self.tiled:
-                check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
-                continue
-            if sp["tiling"] is None or sp["since"] >= self.sort_interval:
-                self.sort(self.species.index(sp))
-            ws = sp["ws"]
-            ws["count"].zero_()
-            check(L.lpa_push_deposit_tiled_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
-                                              ws["overflow"].data_ptr(), ws["count"].data_ptr(), st),
-                  "lpa_push_deposit_tiled_3d")
-            check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ws["overflow"].data_ptr(),
-                                             ws["count"].data_ptr(), sp["n"], st), "lpa_push_deposit_list_3d")
-            sp["since"] += 1
-        check(L.lpa_current_fold(g, 7, st), "lpa_current_fold")
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt)
+        self.sync_currents()
+        for i in range(len(self.species)):
+            self.sync_particles(i)
         check(L.lpa_fdtd_b_3d(g, 0.5 * dt, st), "lpa_fdtd_b_3d")
-        check(L.lpa_guard_wrap(g, 2, 7, st), "lpa_guard_wrap")
+        self.sync_guard_fields(2)
         check(L.lpa_fdtd_e_3d(g, 0.5 * dt, self.eps0, st), "lpa_fdtd_e_3d")
-        check(L.lpa_guard_wrap(g, 1, 7, st), "lpa_guard_wrap")
+        self.sync_guard_fields(1)
 
     def diagnostics(self):
+        """this rank's share (sum over ranks = the box)"""
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), self.stream), "diag")
         f = self._diag.cpu().numpy().copy()

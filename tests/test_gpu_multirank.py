@@ -246,3 +246,72 @@ def test_moving_window_chain_matches_single_rank():
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
+
+
+# ---- 3-D slabs: two ranks against one on the same periodic box ----------------------------------------
+def _run_3d(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.engine3d import ATTRS3, PicEngine3D
+    nxg, ny, nz, ppc = 16, 8, 16, 4
+    dx, dy, dz = 4e-8, 5e-8, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    rng = np.random.default_rng(3)
+    n = nxg * ny * nz * ppc
+    pos = np.stack([rng.uniform(-0.5, m - 0.5, n) * d for m, d in ((nxg, dx), (ny, dy), (nz, dz))])
+    u = rng.normal(size=(3, n)) * 0.3                       # hot: slab crossings and box wraps
+    ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
+    w = np.full(n, 1e27 * dx * dy * dz / ppc)
+    comm = SlabComm(None, periodic=True, single=(world == 1))
+    nx = nxg // world
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=True, sort_interval=3, block_particles=1024, comm=comm,
+                      migrate_capacity=2048)
+    lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
+    mine = (pos[0] >= lo) & (pos[0] < hi)
+    k = int(mine.sum())
+    cap = 3 * k + eng.arrival_area()
+    data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device="cuda:0")
+    data[:, :k] = torch.from_numpy(np.concatenate([pos[:, mine], u[:, mine], ig[None, mine], w[None, mine]])).cuda()
+    eng.add_species_device(-1.602176634e-19, 9.1093837139e-31, data, k)
+    trace = []
+    for _ in range(14):
+        eng.step(dt)
+        d = eng.diagnostics()
+        trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+    sl = (slice(3, 3 + nx), slice(3, 3 + ny), slice(3, 3 + nz))
+    fields = {a: eng.view(a)[sl].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch_3d(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_3d, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trace = sum(r[1] for r in res)
+    fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+    return trace, fields
+
+
+def test_3d_slabs_match_single_rank():
+    t1, f1 = _launch_3d(1)
+    t2, f2 = _launch_3d(2)
+    assert np.array_equal(t2[:, 3], t1[:, 3])                       # particle count conserved
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-12)
+    assert np.abs(t2[:, 1] - t1[:, 1]).max() <= 1e-12 * 8192 * 1e27 * 4e-8 * 5e-8 * 6e-8 / 4 * 1.6e-19
+    for a in f1:
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * scale, a

@@ -36,11 +36,7 @@ for k in (3, 4, 5):
 data[6] = 1.0 / torch.sqrt(1 + data[3] ** 2 + data[4] ** 2 + data[5] ** 2)
 omega = 2 * np.pi * 299792458.0 / lam
 data[7] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE ** 2 * dx * dy * dz / a.ppc
-p = _lib.lpa_particles(); p.n = n
-for k, name in enumerate(ATTRS3):
-    setattr(p, name, data[k].data_ptr())
-eng.species.append({"q": -constants.E_CHARGE, "m": constants.M_E, "data": data, "c": p, "n": n, "alt": None,
-                    "tiling": None, "since": 0, "ws": None})
+eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
 for _ in range(a.warmup):
     eng.step(dt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
