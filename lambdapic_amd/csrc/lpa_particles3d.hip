@@ -105,6 +105,65 @@ __device__ __forceinline__ void esirkepov_3d(const AxisW &ax, const AxisW &ay, c
     }
 }
 
+// The same deposit in two sweeps over the window, for the LDS kernel where registers are the scarce
+// resource: sweep 1 walks x innermost and needs ONE running sum for jx; sweep 2 walks x outermost for jy
+// (4 running sums), jz (1) and rho.  The single-sweep form above keeps 16 + 4 + 1 running sums alive.
+// Every product is formed exactly as above (same operands, same order), so the results are bit-identical;
+// DS is re-derived as S1 - S0 (its definition in axis_window) instead of being kept in registers.
+template <class SinkX, class SinkYZR>
+__device__ __forceinline__ void esirkepov_3d_lean(const AxisW &ax, const AxisW &ay, const AxisW &az, double w,
+                                                  double q, double dx, double dy, double dz, double dt,
+                                                  SinkX &&sink_x, SinkYZR &&sink_yzr) {
+    const double one_third = 0.3333333333333333;
+    {
+        double fdx_ = (q / (dy * dz * dt)) * w;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double dsy = ay.S1[j] - ay.S0[j];
+            double a_y = ay.S0[j] + 0.5 * dsy;
+            double c_y = 0.5 * ay.S0[j] + one_third * dsy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double tjx = a_y * az.S0[k] + c_y * (az.S1[k] - az.S0[k]);
+                double run = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    double fdx = fdx_ * (ax.S1[i] - ax.S0[i]);
+                    run -= fdx * tjx;
+                    sink_x(i, j, k, (ax.tail_zero && i == 3) ? 0.0 : run);
+                }
+            }
+        }
+    }
+    double cd = (q / (dx * dy * dz)) * w;
+    double fdy_ = (q / (dx * dz * dt)) * w;
+    double fdz_ = (q / (dx * dy * dt)) * w;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double dsx = ax.S1[i] - ax.S0[i];
+        double a_x = ax.S0[i] + 0.5 * dsx;
+        double c_x = 0.5 * ax.S0[i] + one_third * dsx;
+        double jy_run[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double dsy = ay.S1[j] - ay.S0[j];
+            double fdy = fdy_ * dsy;
+            double tz_ij = a_x * ay.S0[j] + c_x * dsy;
+            bool yz = ay.tail_zero && j == 3;
+            double jz_run = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double dsz = az.S1[k] - az.S0[k];
+                double tjy = a_x * az.S0[k] + c_x * dsz;
+                jy_run[k] -= fdy * tjy;
+                jz_run -= fdz_ * dsz * tz_ij;
+                bool zz = az.tail_zero && k == 3;
+                sink_yzr(i, j, k, yz ? 0.0 : jy_run[k], zz ? 0.0 : jz_run, cd * ax.S1[i] * ay.S1[j] * az.S1[k]);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, double y, double z,
                                                   double ux, double uy, double uz, double ig, double w,
                                                   double q, double dt) {
@@ -208,14 +267,21 @@ constexpr int R3N = R3X * R3Y * R3Z;                                       // 22
 constexpr int G3L = LPA_TILE3_MARGIN + 2, G3H = LPA_TILE3_MARGIN + 1;      // gather reach below / above the tile
 constexpr int E3X = T3X + G3L + G3H, E3Y = T3Y + G3L + G3H, E3Z = T3Z + G3L + G3H;  // 9 x 9 x 21
 constexpr int E3N = E3X * E3Y * E3Z;                                       // 1701
-constexpr int K13_THREADS = 512;
+#ifndef LPA_K13_THREADS
+#define LPA_K13_THREADS 768
+#endif
+constexpr int K13_THREADS = LPA_K13_THREADS;
 
 typedef const volatile __attribute__((address_space(3))) double *lds_ptr3;
 
 // 27-point gather from the LDS image of one component; (lx, ly, lz) = local index of the stencil
 // centre; evaluation order of interp_field_fast_3d (unified_pusher_3d.c:111-143): z outermost
-__device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, int lz, const double fx[3],
-                                             const double fy[3], const double fz[3]) {
+// The TSC weights are rebuilt from the three offsets here (5 flops per axis) instead of keeping six
+// weight triples alive across the whole gather: registers, not flops, bound this kernel.
+__device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, int lz, double ddx, double ddy,
+                                             double ddz) {
+    double fx[3], fy[3], fz[3];
+    tsc3(ddx, fx); tsc3(ddy, fy); tsc3(ddz, fz);
     lds_ptr3 c = (lds_ptr3)(f + (lx * E3Y + ly) * E3Z + lz);
     double acc = 0.0;
 #pragma unroll
@@ -305,24 +371,23 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                 overflow[slot] = (uint32_t)ip;
                 continue;
             }
-            double gx[3], hx[3], gy[3], hy[3], gz[3], hz[3];
-            tsc3(ix1 - xo, gx); tsc3(ix2 - xo + 0.5, hx);
-            tsc3(iy1 - yo, gy); tsc3(iy2 - yo + 0.5, hy);
-            tsc3(iz1 - zo, gz); tsc3(iz2 - zo + 0.5, hz);
+            // offsets of the node-centred (g) and half-cell-centred (h) stencils
+            const double gxd = ix1 - xo, hxd = ix2 - xo + 0.5, gyd = iy1 - yo, hyd = iy2 - yo + 0.5,
+                         gzd = iz1 - zo, hzd = iz2 - zo + 0.5;
             const int lx1 = ix1 - e0[0], lx2 = ix2 - e0[0], ly1 = iy1 - e0[1], ly2 = iy2 - e0[1],
                       lz1 = iz1 - e0[2], lz2 = iz2 - e0[2];
             // stagger table: unified_pusher_3d.c:190-195
-            eb[0] = gather27_l(s_eb[0], lx2, ly1, lz1, hx, gy, gz);
+            eb[0] = gather27_l(s_eb[0], lx2, ly1, lz1, hxd, gyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[1] = gather27_l(s_eb[1], lx1, ly2, lz1, gx, hy, gz);
+            eb[1] = gather27_l(s_eb[1], lx1, ly2, lz1, gxd, hyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[2] = gather27_l(s_eb[2], lx1, ly1, lz2, gx, gy, hz);
+            eb[2] = gather27_l(s_eb[2], lx1, ly1, lz2, gxd, gyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[3] = gather27_l(s_eb[3], lx1, ly2, lz2, gx, hy, hz);
+            eb[3] = gather27_l(s_eb[3], lx1, ly2, lz2, gxd, hyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[4] = gather27_l(s_eb[4], lx2, ly1, lz2, hx, gy, hz);
+            eb[4] = gather27_l(s_eb[4], lx2, ly1, lz2, hxd, gyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[5] = gather27_l(s_eb[5], lx2, ly2, lz1, hx, hy, gz);
+            eb[5] = gather27_l(s_eb[5], lx2, ly2, lz1, hxd, hyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
         }
         boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
@@ -356,20 +421,29 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
         }
         const int b0 = (bx * R3Y + by) * R3Z + bz;
-        esirkepov_3d(ax, ay, az, w, k.q, g.dx, g.dy, g.dz, k.dt,
-                     [&](int i, int j, int kk, double djx, double djy, double djz, double dr) {
-                         // window plane 3 of an axis carries exact zeros unless the particle changed
-                         // cell along that axis (see the 2-D kernel)
-                         bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) &&
-                                   (kk < 3 || !az.tail_zero);
-                         if (on) {
-                             int o = b0 + (i * R3Y + j) * R3Z + kk;
-                             atomicAdd(&s_j[0][o], djx);
-                             atomicAdd(&s_j[1][o], djy);
-                             atomicAdd(&s_j[2][o], djz);
-                             atomicAdd(&s_j[3][o], dr);
-                         }
-                     });
+        // window plane 3 of an axis carries exact zeros unless the particle changed cell along that axis
+        // (see the 2-D kernel)
+        esirkepov_3d_lean(
+            ax, ay, az, w, k.q, g.dx, g.dy, g.dz, k.dt,
+            [&](int i, int j, int kk, double djx) {
+                bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
+#ifdef LPA_ABLATE_NO_TAIL
+                on = i < 3 && j < 3 && kk < 3;
+#endif
+                if (on) atomicAdd(&s_j[0][b0 + (i * R3Y + j) * R3Z + kk], djx);
+            },
+            [&](int i, int j, int kk, double djy, double djz, double dr) {
+                bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
+#ifdef LPA_ABLATE_NO_TAIL
+                on = i < 3 && j < 3 && kk < 3;
+#endif
+                if (on) {
+                    int o = b0 + (i * R3Y + j) * R3Z + kk;
+                    atomicAdd(&s_j[1][o], djy);
+                    atomicAdd(&s_j[2][o], djz);
+                    atomicAdd(&s_j[3][o], dr);
+                }
+            });
     }
     __syncthreads();
     // flush: one FP64 global atomic per touched node and component, on the torus
