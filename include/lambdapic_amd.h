@@ -136,6 +136,18 @@ int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int start, int stop
  *      rows iy in [iy_start, iy_end) are driven. */
 int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
                         int iy_end, const double *ey_source, const double *ez_source, void *stream);
+/* 3-D twins: update_efield/bfield_cpml_3d (core/boundary/cpml.py:431-475), update_psi_{x,y,z}_and_{e,b}_3d
+ * (:609-729; psi arrays compact: axis 0 [layer][ny][nz], axis 1 [nx][layer][nz], axis 2 [nx][ny][layer]),
+ * _update_laser_bfields_3d (callback/laser.py:63-92; sources [ny][nz] over the interior nodes) */
+int lpa_fdtd_e_cpml_3d(const lpa_grid *g, double dt, double eps0, const double *kappa_ex,
+                       const double *kappa_ey, const double *kappa_ez, void *stream);
+int lpa_fdtd_b_cpml_3d(const lpa_grid *g, double dt, const double *kappa_bx, const double *kappa_by,
+                       const double *kappa_bz, void *stream);
+int lpa_cpml_psi_3d(const lpa_grid *g, int efield, int axis, int start, int stop, double dt,
+                    const double *bcoeff, const double *ccoeff_d, double *psi_a, double *psi_b, void *stream);
+int lpa_laser_inject_3d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start, int iy_end,
+                        int iz_start, int iz_end, const double *ey_source, const double *ez_source,
+                        void *stream);
 
 /* ---- zero jx jy jz rho including guards (replaces reset_current_cpu_2d/3d,
  *      core/current/cpu2d.c:19-72, cpu3d.c:185-240) */

@@ -69,6 +69,10 @@ SIGNATURES = {
     "lpa_fdtd_b_cpml_2d": (_i, [_G, _d, _vp, _vp, _vp]),
     "lpa_cpml_psi_2d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "lpa_laser_inject_2d": (_i, [_G, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
+    "lpa_fdtd_e_cpml_3d": (_i, [_G, _d, _d, _vp, _vp, _vp, _vp]),
+    "lpa_fdtd_b_cpml_3d": (_i, [_G, _d, _vp, _vp, _vp, _vp]),
+    "lpa_cpml_psi_3d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "lpa_laser_inject_3d": (_i, [_G, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "lpa_reset_current": (_i, [_G, _vp]),
     "lpa_guard_wrap": (_i, [_G, _i, _i, _vp]),
     "lpa_current_fold": (_i, [_G, _i, _vp]),

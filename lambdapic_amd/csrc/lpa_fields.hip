@@ -235,6 +235,135 @@ extern "C" int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int star
     return LPA_OK;
 }
 
+// ---- 3-D CPML (cpml.py:431-475 kappa-scaled update, :609-729 psi recursions) ---------------------------
+__global__ void __launch_bounds__(256) k_fdtd_e_cpml_3d(GridV g, double bfac, double jfac,
+                                                        const double *__restrict__ kx,
+                                                        const double *__restrict__ ky,
+                                                        const double *__restrict__ kz) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    long xm = c - sx, ym = c - sy, zm = c - 1;
+    double bfx = bfac / kx[i], bfy = bfac / ky[j], bfz = bfac / kz[k];
+    double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
+    g.ex[c] += (bfy * (bzc - g.bz[ym]) / g.dy - bfz * (byc - g.by[zm]) / g.dz) - jfac * g.jx[c];
+    g.ey[c] += (bfz * (bxc - g.bx[zm]) / g.dz - bfx * (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    g.ez[c] += (bfx * (byc - g.by[xm]) / g.dx - bfy * (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_3d(GridV g, double dt, const double *__restrict__ kx,
+                                                        const double *__restrict__ ky,
+                                                        const double *__restrict__ kz) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    long xp = c + sx, yp = c + sy, zp = c + 1;
+    double efx = dt / kx[i], efy = dt / ky[j], efz = dt / kz[k];
+    double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
+    g.bx[c] -= (efy * (g.ez[yp] - ezc) / g.dy - efz * (g.ey[zp] - eyc) / g.dz);
+    g.by[c] -= (efz * (g.ex[zp] - exc) / g.dz - efx * (g.ez[xp] - ezc) / g.dx);
+    g.bz[c] -= (efx * (g.ey[xp] - eyc) / g.dx - efy * (g.ex[yp] - exc) / g.dy);
+}
+
+// psi recursion + field correction of one layer, normal to AXIS; psi arrays are compact:
+// AXIS 0: [layer][ny][nz], AXIS 1: [nx][layer][nz], AXIS 2: [nx][ny][layer].
+//   E: x: psi(ey,ez) <- (bz,by), ey -= , ez +=   y: psi(ex,ez) <- (bz,bx), ex +=, ez -=
+//      z: psi(ex,ey) <- (by,bx), ex -= , ey +=                       (cpml.py:609-628,651-669,691-710)
+//   B: x: psi(by,bz) <- (ez,ey), by += , bz -=   y: psi(bx,bz) <- (ez,ex), bx -=, bz +=
+//      z: psi(bx,by) <- (ey,ex), bx += , by -=                       (cpml.py:630-649,671-689,712-729)
+template <int AXIS, bool EFIELD>
+__global__ void __launch_bounds__(256) k_cpml_psi_3d(GridV g, int start, int stop, double fac,
+                                                     const double *__restrict__ bco,
+                                                     const double *__restrict__ cco, double *psi_a,
+                                                     double *psi_b) {
+    const int nl = stop - start;
+    // thread grid: x = fastest transverse (or layer, for AXIS 2) index
+    int n0 = AXIS == 0 ? nl : g.nx, n1 = AXIS == 1 ? nl : g.ny, n2 = AXIS == 2 ? nl : g.nz;
+    int t2 = blockIdx.x * blockDim.x + threadIdx.x, t1 = blockIdx.y, t0 = blockIdx.z;
+    if (t2 >= n2 || t1 >= n1 || t0 >= n0) return;
+    int i = AXIS == 0 ? start + t0 : t0, j = AXIS == 1 ? start + t1 : t1, k = AXIS == 2 ? start + t2 : t2;
+    int ipos = AXIS == 0 ? i : (AXIS == 1 ? j : k);
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    long step = AXIS == 0 ? sx : (AXIS == 1 ? sy : 1);
+    long ps = ((long)t0 * n1 + t1) * n2 + t2;
+    double b = bco[ipos], cc = cco[ipos];
+    const double *f1, *f2;
+    double *ta, *tb;
+    double sa, sb;
+    if (EFIELD) {
+        if (AXIS == 0) { f1 = g.bz; f2 = g.by; ta = g.ey; tb = g.ez; sa = -1; sb = 1; }
+        else if (AXIS == 1) { f1 = g.bz; f2 = g.bx; ta = g.ex; tb = g.ez; sa = 1; sb = -1; }
+        else { f1 = g.by; f2 = g.bx; ta = g.ex; tb = g.ey; sa = -1; sb = 1; }
+        double pa = b * psi_a[ps] + cc * (f1[c] - f1[c - step]);
+        double pb = b * psi_b[ps] + cc * (f2[c] - f2[c - step]);
+        psi_a[ps] = pa; psi_b[ps] = pb;
+        ta[c] += sa * (fac * pa);
+        tb[c] += sb * (fac * pb);
+    } else {
+        if (AXIS == 0) { f1 = g.ez; f2 = g.ey; ta = g.by; tb = g.bz; sa = 1; sb = -1; }
+        else if (AXIS == 1) { f1 = g.ez; f2 = g.ex; ta = g.bx; tb = g.bz; sa = -1; sb = 1; }
+        else { f1 = g.ey; f2 = g.ex; ta = g.bx; tb = g.by; sa = 1; sb = -1; }
+        double pa = b * psi_a[ps] + cc * (f1[c + step] - f1[c]);
+        double pb = b * psi_b[ps] + cc * (f2[c + step] - f2[c]);
+        psi_a[ps] = pa; psi_b[ps] = pb;
+        ta[c] += sa * (fac * pa);
+        tb[c] += sb * (fac * pb);
+    }
+}
+
+extern "C" int lpa_fdtd_e_cpml_3d(const lpa_grid *g, double dt, double eps0, const double *kappa_ex,
+                                  const double *kappa_ey, const double *kappa_ez, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1) && kappa_ex && kappa_ey && kappa_ez && eps0 > 0,
+                "lpa_fdtd_e_cpml_3d: bad args");
+    LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_e_cpml_3d: nx, ny must be <= 65535");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_cpml_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
+                       dt / eps0, kappa_ex, kappa_ey, kappa_ez);
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_cpml_3d(const lpa_grid *g, double dt, const double *kappa_bx, const double *kappa_by,
+                                  const double *kappa_bz, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && kappa_bx && kappa_by && kappa_bz, "lpa_fdtd_b_cpml_3d: bad args");
+    LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_cpml_3d: nx, ny must be <= 65535");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_cpml_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, kappa_bx, kappa_by,
+                       kappa_bz);
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_cpml_psi_3d(const lpa_grid *g, int efield, int axis, int start, int stop, double dt,
+                               const double *bcoeff, const double *ccoeff_d, double *psi_a, double *psi_b,
+                               void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && axis >= 0 && axis <= 2 && bcoeff && ccoeff_d && psi_a && psi_b,
+                "lpa_cpml_psi_3d: bad args");
+    int n = axis == 0 ? g->nx : (axis == 1 ? g->ny : g->nz);
+    LPA_REQUIRE(start >= 0 && stop > start && stop <= n, "lpa_cpml_psi_3d: layer [%d,%d) outside [0,%d)",
+                start, stop, n);
+    int nl = stop - start;
+    int n0 = axis == 0 ? nl : g->nx, n1 = axis == 1 ? nl : g->ny, n2 = axis == 2 ? nl : g->nz;
+    LPA_REQUIRE(n0 <= 65535 && n1 <= 65535, "lpa_cpml_psi_3d: nx, ny must be <= 65535");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((n2 + 255) / 256, n1, n0), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    double fac = efield ? dt * (LPA_C * LPA_C) : dt;
+#define LPA_PSI3(A, E) hipLaunchKernelGGL((k_cpml_psi_3d<A, E>), grid, blk, 0, st, v, start, stop, fac, bcoeff, ccoeff_d, psi_a, psi_b)
+    if (efield) { if (axis == 0) LPA_PSI3(0, true); else if (axis == 1) LPA_PSI3(1, true); else LPA_PSI3(2, true); }
+    else { if (axis == 0) LPA_PSI3(0, false); else if (axis == 1) LPA_PSI3(1, false); else LPA_PSI3(2, false); }
+#undef LPA_PSI3
+    LPA_CHECK_LAUNCH("lpa_cpml_psi_3d");
+    return LPA_OK;
+}
+
 // =====================================================================================================
 // laser injection at the x-min boundary (callback/laser.py:17-46): Mur-type condition on bz, by (and a
 // copy of bx) on the node row laserpos-1, driven by the source fields ey_source, ez_source [ny].
@@ -274,6 +403,52 @@ extern "C" int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, d
     hipLaunchKernelGGL(k_laser_inject_2d, dim3((iy_end - iy_start + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, v, laserpos, dt, eps0, iy_start, iy_end, ey_source, ez_source);
     LPA_CHECK_LAUNCH("lpa_laser_inject_2d");
+    return LPA_OK;
+}
+
+// 3-D twin (callback/laser.py:63-92): the bx copy runs over the whole z row (guards included), bz gets
+// the extra d(bx)/dz term; sources are [ny][nz] over the interior nodes
+__global__ void __launch_bounds__(256) k_laser_inject_3d(GridV g, int lp, double dt, double eps0, int iy0,
+                                                         int iy1, int iz0, int iz1,
+                                                         const double *__restrict__ eys,
+                                                         const double *__restrict__ ezs) {
+    int kz = blockIdx.x * blockDim.x + threadIdx.x;   // padded z index
+    int j = iy0 + blockIdx.y;
+    if (kz >= g.NZ || j >= iy1) return;
+    const double c = LPA_C;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long r0 = (long)g.ng * sx + (long)(j + g.ng) * sy + kz;   // row 0
+    long rm = r0 - sx;                                         // row -1 (low guard)
+    long rl = (long)(lp + g.ng) * sx + (long)(j + g.ng) * sy + kz;
+    long rt = rl - sx;
+    g.bx[rt] = g.bx[r0];
+    int k = kz - g.ng;
+    if (k < iz0 || k >= iz1) return;
+    long si = (long)j * g.nz + k;
+    double f = 1 / ((c * dt / g.dx + 1) * c);
+    double bzv = f * (+4 * eys[si] + 2 * (g.ey[r0] + c * 0.5 * (g.bz[r0] + g.bz[rm])) - 2 * g.ey[rl] -
+                      (dt * (c * c)) * (g.bx[rl] - g.bx[rl - 1]) / g.dz + dt / eps0 * g.jy[rl] +
+                      (c * dt / g.dx - 1) * c * g.bz[rl]);
+    double byv = f * (-4 * ezs[si] - 2 * (g.ez[r0] - c * 0.5 * (g.by[r0] + g.by[rm])) + 2 * g.ez[rl] -
+                      (dt * (c * c)) * (g.bx[rl] - g.bx[rl - sy]) / g.dy - dt / eps0 * g.jz[rl] +
+                      (c * dt / g.dx - 1) * c * g.by[rl]);
+    g.bz[rt] = bzv;
+    g.by[rt] = byv;
+}
+
+extern "C" int lpa_laser_inject_3d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
+                                   int iy_end, int iz_start, int iz_end, const double *ey_source,
+                                   const double *ez_source, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1) && ey_source && ez_source && eps0 > 0, "lpa_laser_inject_3d: bad args");
+    LPA_REQUIRE(laserpos >= 2 && laserpos < g->nx && iy_start >= 0 && iy_end <= g->ny && iz_start >= 0 &&
+                    iz_end <= g->nz,
+                "lpa_laser_inject_3d: laserpos / iy / iz range outside the slab");
+    if (iy_end <= iy_start) return LPA_OK;
+    GridV v = make_gridv(g, 3);
+    dim3 grid((v.NZ + 255) / 256, iy_end - iy_start);
+    hipLaunchKernelGGL(k_laser_inject_3d, grid, dim3(256), 0, (hipStream_t)stream, v, laserpos, dt, eps0,
+                       iy_start, iy_end, iz_start, iz_end, ey_source, ez_source);
+    LPA_CHECK_LAUNCH("lpa_laser_inject_3d");
     return LPA_OK;
 }
 

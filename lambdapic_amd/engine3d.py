@@ -26,19 +26,91 @@ from .dist import SlabComm, exchange_faces
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 
 ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
+SIDES3 = ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")
+
+
+class DevicePML3D:
+    """CPML coefficients and psi arrays of one rank's 3-D slab (reference: per-patch ``PML`` objects,
+    `core/boundary/cpml.py:23-340`; slab mapping as in oracle/cpml.py:SlabPML3D).  psi arrays are compact
+    (axis 0: [layer][ny][nz], axis 1: [nx][layer][nz], axis 2: [nx][ny][layer])."""
+
+    def __init__(self, n, d, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7):
+        self.n, self.d, self.t = tuple(n), tuple(d), int(thickness)
+        self.sides, self.device = set(sides), device
+        m, ma = 3, 1
+        smax = sigma_max * constants.C_LIGHT * 0.8 * (m + 1.0) / d[0]      # cpml.py:60 (dx for every axis)
+        self.host = {}
+        ar = np.arange(self.t, dtype=float)
+        for ax, nn in zip("xyz", self.n):
+            for fld in ("e", "b"):
+                self.host[fld + ax] = dict(kappa=np.ones(nn), sigma=np.zeros(nn), a=np.zeros(nn))
+
+            def fill(fld, pos, sl, ax=ax):
+                c = self.host[fld + ax]
+                c["kappa"][sl] = 1 + (kappa_max - 1) * pos ** m           # cpml.py:119-125
+                c["sigma"][sl] = smax * pos ** m
+                c["a"][sl] = a_max * (1 - pos) ** ma
+
+            if ax + "min" in self.sides:
+                fill("e", 1.0 - ar / self.t, np.s_[:self.t])
+                fill("b", 1.0 - (ar + 0.5) / self.t, np.s_[:self.t])
+            if ax + "max" in self.sides:
+                fill("e", 1.0 - ar[::-1] / self.t, np.s_[nn - self.t:nn])
+                fill("b", 1.0 - (ar + 0.5)[::-1] / self.t, np.s_[nn - self.t - 1:nn - 1])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.kappa = {k: dev(v["kappa"]) for k, v in self.host.items()}
+        self.layers = []
+        for fld in ("e", "b"):
+            for axis, ax in enumerate("xyz"):
+                nn = self.n[axis]
+                rng = []
+                if ax + "min" in self.sides:
+                    rng.append((0, self.t))
+                if ax + "max" in self.sides:
+                    rng.append((nn - self.t, nn) if fld == "e" else (nn - self.t - 1, nn - 1))
+                for s0, s1 in rng:
+                    cells = (s1 - s0) * int(np.prod([v for k, v in enumerate(self.n) if k != axis]))
+                    z = lambda: torch.zeros(cells, dtype=torch.float64, device=device)
+                    self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
+                                            psi_a=z(), psi_b=z()))
+        self._coef = {}
+
+    def coef(self, key, dt, d):
+        k = (key, dt)
+        if k not in self._coef:
+            c = self.host[key]
+            kap, sig, a = c["kappa"], c["sigma"], c["a"]
+            b = np.exp(-(sig / kap + a) * dt)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cc = (b - 1) * sig / kap / (sig + kap * a) / d
+            cc = np.where(np.isfinite(cc), cc, 0.0)
+            mk = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
+            self._coef[k] = (mk(b), mk(cc))
+        return self._coef[k]
 
 
 class PicEngine3D:
     def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
-                 block_particles=4096, comm=None, migrate_capacity=32768):
-        """``nx`` = cells of THIS rank's slab along x; the box is ``nx * comm.size`` cells long"""
+                 block_particles=4096, comm=None, migrate_capacity=32768, boundary_conditions=None,
+                 cpml_thickness=6):
+        """``nx`` = cells of THIS rank's slab along x; the box is ``nx * comm.size`` cells long.
+        ``boundary_conditions``: {'xmin': 'pml' | 'periodic', ...} for the six faces (default: periodic)"""
+        bc = dict(boundary_conditions or {k: "periodic" for k in SIDES3})
+        for ax in "xyz":
+            if (bc[ax + "min"] == "periodic") != (bc[ax + "max"] == "periodic"):
+                raise ValueError(f"{ax}: periodic must be set on both faces")
+        self.bc = bc
+        self.periodic = tuple(bc[ax + "min"] == "periodic" for ax in "xyz")
+        self.cpml_thickness = int(cpml_thickness)
         self.L = lib()
         fits = nx % _lib.LPA_TILE3_X == 0 and ny % _lib.LPA_TILE3_Y == 0 and nz % _lib.LPA_TILE3_Z == 0
         if tiled and not fits:
             raise ValueError("tiled 3-D path needs nx, ny multiples of 4 and nz a multiple of 16")
         self.tiled = fits if tiled is None else bool(tiled)
         self.sort_interval, self.block_particles = int(sort_interval), int(block_particles)
-        self.comm = comm or SlabComm(None, periodic=True, single=True)
+        self.comm = comm or SlabComm(None, periodic=self.periodic[0], single=True)
+        if self.comm.periodic != self.periodic[0]:
+            raise ValueError("SlabComm(periodic=...) must match the x boundary condition")
         if self.comm.size > 1 and not self.tiled:
             raise ValueError("a slab decomposition needs the tile-sorted store (arrival area)")
         self.migrate_capacity = int(migrate_capacity)
@@ -60,8 +132,26 @@ class PicEngine3D:
         for k, name in enumerate(FIELD_ATTRS):
             setattr(g, name, self.buf[k].data_ptr())
         self.c = g
-        # axes wrapped locally: y and z always, x only when this rank owns the whole box
-        self.local_axes = 6 | (1 if self.comm.size == 1 else 0)
+        # axes wrapped locally: periodic y and z; x only when periodic AND this rank owns the whole box
+        self.local_axes = (2 if self.periodic[1] else 0) | (4 if self.periodic[2] else 0) | \
+                          (1 if (self.periodic[0] and self.comm.size == 1) else 0)
+        # CPML layers owned by this rank: x faces only on the end ranks
+        sides = [s_ for s_ in SIDES3[2:] if bc[s_] == "pml"]
+        if bc["xmin"] == "pml" and self.comm.rank == 0:
+            sides.append("xmin")
+        if bc["xmax"] == "pml" and self.comm.rank == self.comm.size - 1:
+            sides.append("xmax")
+        self.pml = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device) if sides else None
+        # particle absorption at open faces: bounds pulled in by the layer thickness (patch.py:105-148)
+        self.absorb = 0
+        self.alo, self.ahi = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
+        ntot = (self.n[0] * self.comm.size, self.n[1], self.n[2])
+        for a in range(3):
+            if not self.periodic[a]:
+                self.absorb |= _lib.LPA_ABSORB_X << a
+                t = self.cpml_thickness
+                self.alo[a] = t * self.d[a] - self.d[a] / 2
+                self.ahi[a] = (ntot[a] - 1 - t) * self.d[a] + self.d[a] / 2
         self.species = []
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
@@ -211,20 +301,71 @@ class PicEngine3D:
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         cur = ws["counters"][1:2].data_ptr()
         area = self.arrival_area()
-        shift_lo = -self.Lbox[0] if self.comm.rank == 0 else 0.0
-        shift_hi = self.Lbox[0] if self.comm.rank == self.comm.size - 1 else 0.0
+        if not self.comm.has_left:
+            m["r_lo"][:1].zero_()    # open face: nothing arrives
+        if not self.comm.has_right:
+            m["r_hi"][:1].zero_()
+        shift_lo = -self.Lbox[0] if (self.comm.rank == 0 and self.periodic[0]) else 0.0
+        shift_hi = self.Lbox[0] if (self.comm.rank == self.comm.size - 1 and self.periodic[0]) else 0.0
         check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_lo"].data_ptr(), cap,
                                         shift_lo, st), "unpack lo")
         check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_hi"].data_ptr(), cap,
                                         shift_hi, st), "unpack hi")
 
+    # ---- Maxwell with CPML layers (update_e/bfield_cpml_patches_3d, cpml.py:477-530) --------------------
+    def update_efield(self, dt):
+        g, st = self._g(), self.stream
+        if self.pml is None:
+            check(self.L.lpa_fdtd_e_3d(g, dt, self.eps0, st), "lpa_fdtd_e_3d")
+            return
+        k = self.pml.kappa
+        check(self.L.lpa_fdtd_e_cpml_3d(g, dt, self.eps0, k["ex"].data_ptr(), k["ey"].data_ptr(),
+                                        k["ez"].data_ptr(), st), "lpa_fdtd_e_cpml_3d")
+        self._psi(True, dt)
+
+    def update_bfield(self, dt):
+        g, st = self._g(), self.stream
+        if self.pml is None:
+            check(self.L.lpa_fdtd_b_3d(g, dt, st), "lpa_fdtd_b_3d")
+            return
+        k = self.pml.kappa
+        check(self.L.lpa_fdtd_b_cpml_3d(g, dt, k["bx"].data_ptr(), k["by"].data_ptr(), k["bz"].data_ptr(), st),
+              "lpa_fdtd_b_cpml_3d")
+        self._psi(False, dt)
+
+    def _psi(self, efield, dt):
+        for ly in self.pml.layers:
+            if ly["e"] != efield:
+                continue
+            b, cc = self.pml.coef(ly["key"], dt, self.d[ly["axis"]])
+            check(self.L.lpa_cpml_psi_3d(self._g(), int(efield), ly["axis"], ly["start"], ly["stop"], dt,
+                                         b.data_ptr(), cc.data_ptr(), ly["psi_a"].data_ptr(),
+                                         ly["psi_b"].data_ptr(), self.stream), "lpa_cpml_psi_3d")
+
+    def laser_inject(self, ey_source, ez_source, dt):
+        """``ey_source, ez_source``: [ny][nz] source fields on the x-min boundary at the current time
+        (Laser.__call__ at stage '_laser', callback/laser.py:109-137,218-238); only the rank that owns
+        the x-min layer injects"""
+        if self.pml is None or "xmin" not in self.pml.sides:
+            return
+        t = self.cpml_thickness
+        iy0, iy1 = (t, self.n[1] - t) if self.bc["ymin"] == "pml" else (0, self.n[1])
+        iz0, iz1 = (t, self.n[2] - t) if self.bc["zmin"] == "pml" else (0, self.n[2])
+        to = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(
+            self.device, torch.float64).contiguous()
+        ey, ez = to(ey_source), to(ez_source)
+        check(self.L.lpa_laser_inject_3d(self._g(), t + 2, dt, self.eps0, iy0, iy1, iz0, iz1, ey.data_ptr(),
+                                         ez.data_ptr(), self.stream), "lpa_laser_inject_3d")
+        self._keep = (ey, ez)
+
     # ---- one step --------------------------------------------------------------------------------------
     def push_deposit(self, i, dt):
         L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
         pp = _lib.lpa_push_params()
-        pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes
+        pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes | self.absorb
         for a in range(3):
             pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.Lbox[a] - self.d[a] / 2
+            pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
         if not self.tiled:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
             return
@@ -243,11 +384,13 @@ class PicEngine3D:
                   "lpa_push_deposit_3d")
         sp["since"] += 1
 
-    def step(self, dt):
+    def step(self, dt, laser=None):
+        """``laser``: optional callable ``laser(engine, dt)`` run at the reference's '_laser' stage
+        (between the second B half step and its guard sync, simulation.py:1098-1112)"""
         L, st, g = self.L, self.stream, self._g()
-        check(L.lpa_fdtd_e_3d(g, 0.5 * dt, self.eps0, st), "lpa_fdtd_e_3d")
+        self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)
-        check(L.lpa_fdtd_b_3d(g, 0.5 * dt, st), "lpa_fdtd_b_3d")
+        self.update_bfield(0.5 * dt)
         self.sync_guard_fields(2)
         check(L.lpa_reset_current(g, st), "lpa_reset_current")
         for i in range(len(self.species)):
@@ -255,9 +398,11 @@ class PicEngine3D:
         self.sync_currents()
         for i in range(len(self.species)):
             self.sync_particles(i)
-        check(L.lpa_fdtd_b_3d(g, 0.5 * dt, st), "lpa_fdtd_b_3d")
+        self.update_bfield(0.5 * dt)
+        if laser is not None:
+            laser(self, dt)
         self.sync_guard_fields(2)
-        check(L.lpa_fdtd_e_3d(g, 0.5 * dt, self.eps0, st), "lpa_fdtd_e_3d")
+        self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)
 
     def diagnostics(self):

@@ -16,6 +16,18 @@ from . import constants
 C = constants.C_LIGHT
 
 
+class _LaserBase:
+    """shared state of the 2-D and 3-D callbacks"""
+    stage = "_laser"
+    interval = 1
+    device_native = True      # touches device state through the engine; no mirror download/upload
+    side = "xmin"
+    y0 = None
+    z0 = None
+    tstop = np.inf
+    disabled = False
+
+
 class Laser2D:
     """common part (`callback/laser.py:79-137,154-192`): stage, stop time, the x-min layer check and
     the hand-over of the source rows to the device kernel"""
@@ -176,6 +188,94 @@ class GaussianLaser2D(Laser2D):
         r = np.abs(y)
         if self._is_lg:
             phi = np.arctan2(0.0, y)             # 2-D: the azimuth is 0 or pi
+            u = np.sqrt(2) * r / w
+            amp_lg = self.lg_norm * u ** abs(self.l) * self.laguerre(u ** 2)
+            phase_lg = self.l * phi
+        else:
+            amp_lg, phase_lg = 1.0, 0.0
+        amp = self.E0 * (self.w0 / w) * np.exp(-r ** 2 / w ** 2) * amp_lg * tprof
+        phase = (self.omega0 * time + self.cep - self.k0 * x_rel - self.k0 * r ** 2 / (2 * R)
+                 - (2 * self.p + abs(self.l) + 1) * psi - phase_lg)
+        return _polarise(amp, phase, self.pol_angle, self.ellipticity)
+
+
+# ---- 3-D (callback/laser.py:194-238: r and phi from the y-z plane of the boundary) ----------------------
+class Laser3D(_LaserBase):
+    """callable ``laser(engine3d, dt)`` for ``PicEngine3D.step(dt, laser=...)`` and, as a callback object,
+    ``laser(sim)`` for a driver exposing ``sim.engine`` (a PicEngine3D), ``sim.time``, ``sim.dt``,
+    ``sim.Ly``, ``sim.Lz``, ``sim.dx``, ``sim.cpml_thickness``"""
+
+    def boundary_yz(self, sim):
+        """(y, z, r): f.yaxis - dy/2 - y0, f.zaxis - dz/2 - z0 on the interior nodes, [ny][nz]"""
+        eng = sim.engine
+        y = (np.arange(eng.n[1]) * eng.d[1] - eng.d[1] / 2 - (self.y0 or sim.Ly / 2))[:, None]
+        z = (np.arange(eng.n[2]) * eng.d[2] - eng.d[2] / 2 - (self.z0 or sim.Lz / 2))[None, :]
+        return y + 0 * z, z + 0 * y, np.sqrt(y ** 2 + z ** 2)
+
+    def source_fields(self, sim, y, z, r):
+        raise NotImplementedError
+
+    def __call__(self, sim):
+        if self.disabled:
+            return
+        if C * sim.time >= self.tstop:
+            self.disabled = True
+            return
+        eng = sim.engine
+        if eng.bc["xmin"] != "pml" or (eng.comm.rank == 0 and (eng.pml is None or "xmin" not in eng.pml.sides)):
+            self.disabled = True
+            return
+        ey, ez = self.source_fields(sim, *self.boundary_yz(sim))
+        if ey is not None:
+            eng.laser_inject(ey, ez, sim.dt)
+
+
+class SimpleLaser3D(Laser3D):
+    """`callback/laser.py:272-391` with the 3-D boundary coordinates (angle_z is not implemented there)"""
+
+    def __init__(self, a0, w0, ctau, y0=None, z0=None, angle_y=0.0, angle_z=0.0, tstop=None, pol_angle=0.0,
+                 ellipticity=0.0, cep=0.0, l0=0.8e-6, side="xmin"):
+        if angle_z != 0:
+            raise NotImplementedError("Angle_z is not implemented")
+        SimpleLaser2D.__init__(self, a0, w0, ctau, y0=y0, angle_y=angle_y, tstop=tstop, pol_angle=pol_angle,
+                               ellipticity=ellipticity, cep=cep, l0=l0, side=side)
+        self.z0 = z0
+
+    def source_fields(self, sim, y, z, r):
+        time = sim.time
+        if C * time >= self.tstop:
+            return None, None
+        r_rot = np.sqrt((y / np.cos(self.angle_y)) ** 2 + z ** 2)
+        transverse_phase = -(self.ky * y)
+        t_rot = C * time - y * np.sin(self.angle_y)
+        tprof = np.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
+        amp = self.E0 * np.exp(-r_rot ** 2 / self.w0 ** 2) * tprof
+        phase = self.omega0 * time + self.cep + transverse_phase
+        ey, ez = _polarise(amp, phase, self.pol_angle, self.ellipticity)
+        return ey * np.cos(self.angle_y), ez
+
+
+class GaussianLaser3D(Laser3D):
+    """`callback/laser.py:397-555` with r, phi taken in the y-z plane (Laguerre-Gaussian vortex phase
+    l * atan2(z, y))"""
+
+    def __init__(self, a0, l0, w0, ctau, x0=None, y0=None, z0=None, tstop=None, pol_angle=0.0, ellipticity=0.0,
+                 cep=0.0, focus_position=0.0, side="xmin", l=0, p=0):
+        GaussianLaser2D.__init__(self, a0, l0, w0, ctau, x0=x0, y0=y0, z0=z0, tstop=tstop, pol_angle=pol_angle,
+                                 ellipticity=ellipticity, cep=cep, focus_position=focus_position, side=side,
+                                 l=l, p=p)
+
+    beam_params = GaussianLaser2D.beam_params
+
+    def source_fields(self, sim, y, z, r):
+        time = sim.time
+        if C * time >= self.tstop:
+            return None, None
+        tprof = np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2)
+        x_rel = sim.cpml_thickness * sim.dx
+        w, R, psi = self.beam_params(x_rel)
+        if self._is_lg:
+            phi = np.arctan2(z, y)
             u = np.sqrt(2) * r / w
             amp_lg = self.lg_norm * u ** abs(self.l) * self.laguerre(u ** 2)
             phase_lg = self.l * phi

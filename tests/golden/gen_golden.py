@@ -568,12 +568,89 @@ def g11_laser_profiles():
             if ey is None:                      # pulse over: stored as empty rows
                 ey = ez = np.zeros(0)
             out[f"{name}_t{it}_ey"], out[f"{name}_t{it}_ez"] = ey, ez
+    # 3-D classes: r, phi from the y-z plane of the boundary (callback/laser.py:194-238)
+    nz3, dz3 = 20, 7e-8
+    Lz = nz3 * dz3
+    ya3 = np.roll((np.arange(24 + 2 * ng) - ng) * dy, -ng)[None, :, None]
+    za3 = np.roll((np.arange(nz3 + 2 * ng) - ng) * dz3, -ng)[None, None, :]
+    patch3 = types.SimpleNamespace(fields=types.SimpleNamespace(yaxis=ya3, zaxis=za3))
+    cases3 = {
+        "simple3": ("SimpleLaser3D", dict(a0=1.2, w0=0.6e-6, ctau=1.5e-6, pol_angle=0.4, ellipticity=0.3, angle_y=0.2)),
+        "gauss3_lg": ("GaussianLaser3D", dict(a0=0.9, l0=0.8e-6, w0=0.5e-6, ctau=1.0e-6, focus_position=2e-6,
+                                               l=-1, p=1, z0=0.6e-6, ellipticity=0.5)),
+    }
+    out.update(ny3=24, nz3=nz3, dz3=dz3, Ly3=24 * dy, Lz3=Lz, cases3=np.array(json.dumps(cases3)))
+    for name, (cls, kw) in cases3.items():
+        las = ns[cls](**kw)
+        for it, tm in enumerate(times):
+            sim = types.SimpleNamespace(time=float(tm), Ly=24 * dy, Lz=Lz, dy=dy, dz=dz3, dx=dx, cpml_thickness=t)
+            ey, ez = las._calculate_bound_fields(sim, patch3)
+            if ey is None:
+                ey = ez = np.zeros(0)
+            out[f"{name}_t{it}_ey"], out[f"{name}_t{it}_ez"] = ey, ez
     np.savez_compressed(OUT / "g11_laser_profiles.npz", **out)
+
+
+def g12_cpml_laser_3d():
+    """3-D: the reference's six PML objects on ONE field bag (function level: kappa-scaled update with the
+    min / max kappa arrays merged, then every object's psi recursion), three half steps of E and B on
+    random fields with static random guards; and the 3-D laser boundary kernel.  The slab = union of
+    edge patches argument is the 2-D one (g9)."""
+    import ast
+    RF, RC = load_ref_cpml()
+    rng = np.random.default_rng(SEED + 12)
+    nx, ny, nz, ng, th = 10, 9, 11, 3, 3
+    dx, dy, dz = 4e-8, 5e-8, 6e-8
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    f = RF.Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, ng)
+    scale = dict(ex=1e12, ey=1e12, ez=1e12, bx=3e3, by=3e3, bz=3e3, jx=1e15, jy=1e15, jz=1e15)
+    for a, sc in scale.items():
+        getattr(f, a)[...] = rng.normal(size=getattr(f, a).shape) * sc
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng, dx=dx, dy=dy, dz=dz, dt=dt, thickness=th)
+    for a in scale:
+        out["in_" + a] = getattr(f, a).copy()
+    pmls = [cls(f, thickness=th) for cls in (RC.PMLXmin, RC.PMLXmax, RC.PMLYmin, RC.PMLYmax, RC.PMLZmin, RC.PMLZmax)]
+
+    def merged(name):
+        lo, hi = {"x": pmls[0:2], "y": pmls[2:4], "z": pmls[4:6]}[name[-1]]
+        a, b = getattr(lo, name), getattr(hi, name)
+        return np.where(a != 1.0, a, b)
+
+    for it in range(3):
+        RC.update_efield_cpml_3d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, f.jx, f.jy, f.jz, merged("kappa_ex"),
+                                 merged("kappa_ey"), merged("kappa_ez"), dx, dy, dz, 0.5 * dt, nx, ny, nz, ng)
+        for p in pmls:
+            p.advance_e_currents(0.5 * dt)
+        RC.update_bfield_cpml_3d(f.ex, f.ey, f.ez, f.bx, f.by, f.bz, merged("kappa_bx"), merged("kappa_by"),
+                                 merged("kappa_bz"), dx, dy, dz, 0.5 * dt, nx, ny, nz, ng)
+        for p in pmls:
+            p.advance_b_currents(0.5 * dt)
+        if it in (0, 2):
+            for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+                out[f"it{it}_{a}"] = getattr(f, a).copy()
+    # laser kernel (the module defines _update_laser_bfields_3d twice; the later definition is the live one)
+    tree = ast.parse((REF / "callback/laser.py").read_text())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_update_laser_bfields_3d"][-1]
+    fn.decorator_list = []
+    from scipy.constants import c, epsilon_0
+    ns = {"np": np, "NDArray": object, "prange": range, "c": c, "epsilon_0": epsilon_0}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[fn], type_ignores=[])), "laser_kernel_3d", "exec"), ns)
+    g = f                                      # input of the laser kernel = the state after it2 (+ in_j*)
+    eys, ezs = rng.normal(size=g.ex.shape[1:]) * 1e12, rng.normal(size=g.ex.shape[1:]) * 1e12
+    out.update(laserpos=th + 2, iy_start=th, iy_end=ny - th, iz_start=th, iz_end=nz - th, ey_source=eys, ez_source=ezs)
+    ns["_update_laser_bfields_3d"](th + 2, g.ex, g.ey, g.ez, g.bx, g.by, g.bz, g.jx, g.jy, g.jz, dx, dy, dz, dt,
+                                   th, ny - th, th, nz - th, eys, ezs)
+    for a in ("bx", "by", "bz"):
+        out["lout_" + a] = getattr(g, a).copy()
+    np.savez_compressed(OUT / "g12_cpml_laser_3d.npz", **out)
 
 
 def main():
     if "--only-g11" in sys.argv:
         g11_laser_profiles()
+        return
+    if "--only-g12" in sys.argv:
+        g12_cpml_laser_3d()
         return
     assert oracle.ref_available(), "run `make -C oracle ref` first"
     mx = load_ref_maxwell()
@@ -589,6 +666,7 @@ def main():
     g9_cpml(mx)
     g10_laser(np.random.default_rng(SEED + 10))
     g11_laser_profiles()
+    g12_cpml_laser_3d()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

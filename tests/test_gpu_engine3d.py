@@ -109,3 +109,68 @@ def test_3d_tiled_step_vs_oracle(uth, sort_interval):
     og, oo = np.argsort(got["x"]), np.argsort(parts[0].x)         # the sort permuted the store
     for a in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma"):
         assert_close(got[a][og], getattr(parts[0], a)[oo], 1e-11, what=a)
+
+
+PML3 = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
+
+
+def test_cpml_and_laser_3d_vs_reference_golden(golden):
+    """device 3-D CPML (kappa-scaled sweeps + psi kernels of the six layers) and the 3-D laser boundary
+    kernel against the reference's PML objects / kernel (g12): three E and B half steps on random
+    fields with static guards, then one laser injection"""
+    g = golden("g12_cpml_laser_3d")
+    nx, ny, nz, ng, th = (int(g[k]) for k in ("nx", "ny", "nz", "ng", "thickness"))
+    dx, dy, dz, dt = (float(g[k]) for k in ("dx", "dy", "dz", "dt"))
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, ng, boundary_conditions=PML3, cpml_thickness=th)
+    assert not eng.tiled and len(eng.pml.layers) == 12
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
+        eng.upload_field(a, g["in_" + a])
+    for it in range(3):
+        eng.update_efield(0.5 * dt)
+        eng.update_bfield(0.5 * dt)
+        if it in (0, 2):
+            for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+                assert_close(eng.download_field(a), g[f"it{it}_{a}"], 1e-13, what=f"it{it} {a}")
+    assert eng.cpml_thickness + 2 == int(g["laserpos"])
+    eng.laser_inject(g["ey_source"][:ny, :nz], g["ez_source"][:ny, :nz], dt)
+    for a in ("bx", "by", "bz"):
+        assert_close(eng.download_field(a), g["lout_" + a], 1e-13, what="laser " + a)
+
+
+def test_3d_laser_crosses_vacuum_box_and_is_absorbed():
+    """a Gaussian-profile pulse injected at x-min crosses a 3-D vacuum box with CPML on all six faces:
+    the peak field is a0 m c w0 / e, and the layers absorb it (residual energy < 5 % of the peak: the
+    box is only 4 waists wide and the transverse grid is lambda / 6, so the side layers see grazing
+    incidence; the kernels themselves are pinned to 1e-13 by the test above)"""
+    from lambdapic_amd import constants
+    lam = 0.8e-6
+    nx, ny, nz = 96, 48, 48
+    dx = lam / 12
+    dy = dz = lam / 6
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, boundary_conditions=PML3, cpml_thickness=6)
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    a0, w0, ctau = 0.5, 1.6e-6, 1.6e-6
+    om = 2 * np.pi * C / lam
+    E0 = a0 * constants.M_E * C * om / constants.E_CHARGE
+    y = (np.arange(ny) * dy - dy / 2 - ny * dy / 2)[:, None]
+    z = (np.arange(nz) * dz - dz / 2 - nz * dz / 2)[None, :]
+    prof = E0 * np.exp(-(y ** 2 + z ** 2) / w0 ** 2)
+    state = {"t": 0.0}
+
+    def laser(e, h):                     # SimpleLaser3D profile (callback/laser.py:351-386), y-polarised
+        t = state["t"]
+        if C * t < 2 * ctau:
+            env = np.sin(C * t / (2 * ctau) * np.pi) ** 2
+            e.laser_inject(prof * env * np.sin(om * t), np.zeros_like(prof), h)
+
+    hist, peak = [], 0.0
+    nsteps = int(2.4 * nx * dx / C / dt)
+    for it in range(nsteps):
+        eng.step(dt, laser=laser)
+        state["t"] += dt
+        if it % 8 == 0:
+            hist.append(eng.diagnostics()["field_energy"])
+        if it == int(0.55 * nx * dx / C / dt):
+            peak = eng.view("ey").abs().max().item()
+    assert peak == pytest.approx(E0, rel=0.12)          # coarse grid (lambda / 12, lambda / 6)
+    assert hist[-1] < 5e-2 * max(hist)

@@ -315,3 +315,87 @@ def test_3d_slabs_match_single_rank():
     for a in f1:
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * scale, a
+
+
+# ---- 3-D chain with CPML on all faces, laser from x-min, plasma slab: 2 slabs against 1 ----------------
+def _run_3d_open(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd import constants
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.engine3d import ATTRS3, PicEngine3D
+    lam = 0.8e-6
+    nxg, ny, nz, ppc = 48, 24, 32, 2
+    dx, dy, dz = lam / 10, lam / 5, lam / 5
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    bc = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
+    comm = SlabComm(None, periodic=False, single=(world == 1))
+    nx = nxg // world
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=True, sort_interval=4, block_particles=1024, comm=comm,
+                      migrate_capacity=2048, boundary_conditions=bc, cpml_thickness=4)
+    rng = np.random.default_rng(8)
+    cells = np.array([(i, j, k) for i in range(20, 30) for j in range(6, 18) for k in range(8, 24)])
+    n = len(cells) * ppc
+    pos = (np.repeat(cells, ppc, axis=0) + rng.uniform(-0.5, 0.5, (n, 3))).T * np.array([[dx], [dy], [dz]])
+    u = rng.normal(size=(3, n)) * 0.05
+    ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
+    w = np.full(n, 3e27 * dx * dy * dz / ppc)
+    lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
+    mine = (pos[0] >= lo) & (pos[0] < hi)
+    k = int(mine.sum())
+    cap = 2 * n + eng.arrival_area()
+    data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device="cuda:0")
+    data[:, :k] = torch.from_numpy(np.concatenate([pos[:, mine], u[:, mine], ig[None, mine], w[None, mine]])).cuda()
+    eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, k)
+    om = 2 * np.pi * C / lam
+    E0 = 3.0 * constants.M_E * C * om / constants.E_CHARGE
+    y = (np.arange(ny) * dy - dy / 2 - ny * dy / 2)[:, None]
+    z = (np.arange(nz) * dz - dz / 2 - nz * dz / 2)[None, :]
+    prof = E0 * np.exp(-(y ** 2 + z ** 2) / (1.2e-6) ** 2)
+    state = {"t": 0.0}
+
+    def laser(e, h):
+        t = state["t"]
+        if C * t < 2 * 1.2e-6:
+            e.laser_inject(prof * np.sin(C * t / (2 * 1.2e-6) * np.pi) ** 2 * np.sin(om * t), 0 * prof, h)
+
+    trace = []
+    for it in range(60):
+        eng.step(dt, laser=laser)
+        state["t"] += dt
+        if it % 6 == 5:
+            d = eng.diagnostics()
+            trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+    sl = (slice(3, 3 + nx), slice(3, 3 + ny), slice(3, 3 + nz))
+    fields = {a: eng.view(a)[sl].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_3d_laser_target_chain_matches_single_rank():
+    def launch(world):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_run_3d_open, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return sum(r[1] for r in res), {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+
+    t1, f1 = launch(1)
+    t2, f2 = launch(2)
+    assert t1[-1, 2] > 5 * t1[0, 2]                              # the laser heats the slab
+    assert np.array_equal(t2[:, 3], t1[:, 3])
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
+    for a in f1:
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a

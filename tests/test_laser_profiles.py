@@ -58,3 +58,23 @@ def test_parameter_validation():
         L.GaussianLaser2D(a0=1, l0=1e-6, w0=1e-6, ctau=1e-6, l=0.5)
     with pytest.raises(TypeError):
         L.SimpleLaser2D(a0=1, w0=1e-6, ctau=1e-6) + 3
+
+
+def test_3d_profiles_match_reference_rows(golden):
+    g = golden("g11_laser_profiles")
+    cases = json.loads(str(g["cases3"]))
+    ny, nz = int(g["ny3"]), int(g["nz3"])
+    eng = types.SimpleNamespace(n=(8, ny, nz), d=(float(g["dx"]), float(g["dy"]), float(g["dz3"])))
+    for name, (cls, kw) in cases.items():
+        las = getattr(L, cls)(**kw)
+        for it, tm in enumerate(g["times"]):
+            sim = types.SimpleNamespace(time=float(tm), dx=float(g["dx"]), cpml_thickness=int(g["thickness"]),
+                                        Ly=float(g["Ly3"]), Lz=float(g["Lz3"]), engine=eng)
+            ey, ez = las.source_fields(sim, *las.boundary_yz(sim))
+            want_y = g[f"{name}_t{it}_ey"]
+            if want_y.size == 0:
+                assert ey is None
+                continue
+            for got, want in ((ey, want_y), (ez, g[f"{name}_t{it}_ez"])):
+                want = want.reshape(want.shape[-2], want.shape[-1])[:ny, :nz]
+                assert np.abs(got - want).max() <= 1e-13 * max(np.abs(want).max(), 1.0) + 1e-300, (name, it)

@@ -285,3 +285,27 @@ def test_g10_laser_injection_kernel(golden):
                          g["ey_source"], g["ez_source"])
     for a in ("bx", "by", "bz"):
         assert_close(getattr(f, a), g["out_" + a], 1e-14, what=a)
+
+
+def test_cpml_and_laser_3d_vs_reference(golden):
+    """oracle/cpml.py 3-D restatement against the reference's six PML objects on one field bag and its
+    3-D laser boundary kernel (g12)"""
+    from oracle import cpml
+    from lambdapic_amd.fields import Fields3D
+    g = golden("g12_cpml_laser_3d")
+    nx, ny, nz, ng, th = (int(g[k]) for k in ("nx", "ny", "nz", "ng", "thickness"))
+    dx, dy, dz, dt = (float(g[k]) for k in ("dx", "dy", "dz", "dt"))
+    f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, ng)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
+        getattr(f, a)[...] = g["in_" + a]
+    pml = cpml.SlabPML3D(nx, ny, nz, dx, dy, dz, ["xmin", "xmax", "ymin", "ymax", "zmin", "zmax"], thickness=th)
+    for it in range(3):
+        cpml.update_efield_cpml_3d(f, pml, 0.5 * dt)
+        cpml.update_bfield_cpml_3d(f, pml, 0.5 * dt)
+        if it in (0, 2):
+            for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+                assert_close(getattr(f, a), g[f"it{it}_{a}"], 1e-13, what=f"it{it} {a}")
+    cpml.laser_inject_3d(f, int(g["laserpos"]), dt, int(g["iy_start"]), int(g["iy_end"]), int(g["iz_start"]),
+                         int(g["iz_end"]), g["ey_source"], g["ez_source"])
+    for a in ("bx", "by", "bz"):
+        assert_close(getattr(f, a), g["lout_" + a], 1e-13, what="laser " + a)
