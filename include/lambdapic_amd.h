@@ -203,6 +203,18 @@ int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_pus
 int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles *p,
                               const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
                               uint32_t *overflow_count, void *stream);
+/* the same launch restricted to the `edge_cols` tile columns at each x face (LPA_PART_EDGE) or to all the
+ * others (LPA_PART_INTERIOR): only edge tiles (and overflow / loose particles) deposit into the x guard planes
+ * -- provided edge_cols * LPA_TILE_X - 2 cells exceed what a particle can drift between two sorts --,
+ * so the slab engine pushes them first and sends the J / rho guard planes to the ring neighbours on a
+ * second stream while the interior tiles are pushed (the overlap the reference gets from
+ * sync_currents_start / _wait around its intra-rank work, simulation.py:1155-1188) */
+#define LPA_PART_ALL 0
+#define LPA_PART_EDGE 1
+#define LPA_PART_INTERIOR 2
+int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_particles *p,
+                                   const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
+                                   uint32_t *overflow_count, int part, int edge_cols, void *stream);
 int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                              const uint32_t *list, const uint32_t *list_count, int64_t max_count,
                              void *stream);

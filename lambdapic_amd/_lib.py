@@ -20,6 +20,7 @@ LPA_ORDER_STRIPED = 1
 LPA_TILE_MARGIN = 2
 LPA_TILE3_X, LPA_TILE3_Y, LPA_TILE3_Z, LPA_TILE3_MARGIN = 4, 4, 16, 1
 LPA_MIG_NATTR = 9
+LPA_PART_ALL, LPA_PART_EDGE, LPA_PART_INTERIOR = 0, 1, 2
 LPA_ABSORB_X = 16
 
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     "lpa_halo_unpack_current": (_i, [_G, _i, _vp, _vp]),
     "lpa_push_deposit_2d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
     "lpa_push_deposit_tiled_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
+    "lpa_push_deposit_tiled_part_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _i, _i, _vp]),
     "lpa_push_deposit_list_2d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
     "lpa_push_deposit_3d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
     "lpa_push_deposit_tiled_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),

@@ -209,11 +209,17 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                                               const int32_t *__restrict__ blk_end,
                                                               const int32_t *__restrict__ n_blocks,
                                                               int tiles_y, uint32_t *overflow,
-                                                              uint32_t *overflow_count) {
+                                                              uint32_t *overflow_count, int part,
+                                                              int tiles_x, int edge_cols) {
     __shared__ double s_eb[RSZ];
     __shared__ double s_j[4][RSZJ];
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
+    if (part) {  // LPA_PART_EDGE: the edge_cols tile columns at each x face; LPA_PART_INTERIOR: the others
+        const int txi = tile / tiles_y;
+        const bool edge = txi < edge_cols || txi >= tiles_x - edge_cols;
+        if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform
+    }
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
     const int tx0 = (tile / tiles_y) * TX, ty0 = (tile % tiles_y) * TY;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
@@ -502,7 +508,17 @@ extern "C" int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *
 extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles *p,
                                          const lpa_push_params *pp, const lpa_tiling *t,
                                          uint32_t *overflow, uint32_t *overflow_count, void *stream) {
+    return lpa_push_deposit_tiled_part_2d(g, p, pp, t, overflow, overflow_count, LPA_PART_ALL, 0, stream);
+}
+
+extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_particles *p,
+                                              const lpa_push_params *pp, const lpa_tiling *t,
+                                              uint32_t *overflow, uint32_t *overflow_count, int part,
+                                              int edge_cols, void *stream) {
     if (int e = check_push(g, p, pp, "lpa_push_deposit_tiled_2d")) return e;
+    LPA_REQUIRE(part == LPA_PART_ALL || part == LPA_PART_EDGE || part == LPA_PART_INTERIOR,
+                "lpa_push_deposit_tiled_part_2d: bad part");
+    LPA_REQUIRE(part == LPA_PART_ALL || edge_cols >= 1, "lpa_push_deposit_tiled_part_2d: edge_cols must be >= 1");
     LPA_REQUIRE(t && t->blk_tile && t->blk_begin && t->blk_end && t->n_blocks && t->max_blocks > 0 &&
                     overflow && overflow_count,
                 "lpa_push_deposit_tiled_2d: bad tiling");
@@ -522,7 +538,7 @@ extern "C" int lpa_push_deposit_tiled_2d(const lpa_grid *g, const lpa_particles 
 #define LPA_LAUNCH_TILED(E, W)                                                                          \
     hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W>), dim3(t->max_blocks), dim3(K1_THREADS), 0,      \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
-                       t->tiles_y, overflow, overflow_count)
+                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols)
     if (eb && wr) LPA_LAUNCH_TILED(true, true);
     else if (eb) LPA_LAUNCH_TILED(true, false);
     else if (wr) LPA_LAUNCH_TILED(false, true);

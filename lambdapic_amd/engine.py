@@ -148,6 +148,8 @@ class PicEngine2D:
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._ws = {}
         self._halo = None
+        self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
+        self.overlap = True
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every
         # launch of the tiled push+deposit kernel on the stream it runs on
@@ -323,7 +325,10 @@ class PicEngine2D:
         pp.lo[2], pp.hi[2] = 0.0, 0.0
         return pp
 
-    def push_deposit(self, ispec, dt, tiled=True):
+    def push_deposit(self, ispec, dt, tiled=True, part=_lib.LPA_PART_ALL, edge_cols=0):
+        """``part``: LPA_PART_EDGE pushes the edge tile columns, the overflow list and the loose
+        (arrival-area) particles -- everything that can deposit into the x guard planes --,
+        LPA_PART_INTERIOR the remaining tiles (+ their overflow list)"""
         sp = self.species[ispec]
         if sp.n == 0:
             return
@@ -334,23 +339,69 @@ class PicEngine2D:
             ws = self._sort_ws(sp)
             ws["counters"][0:1].zero_()
             cnt = ws["counters"].data_ptr()
-            if self.kernel_events is not None:
+            timed = self.kernel_events is not None
+            if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
-            check(self.L.lpa_push_deposit_tiled_2d(self._g(), C.byref(pc), C.byref(pp), C.byref(sp.tiling),
-                                                   ws["overflow"].data_ptr(), cnt, st), "tiled")
-            if self.kernel_events is not None:
+            check(self.L.lpa_push_deposit_tiled_part_2d(self._g(), C.byref(pc), C.byref(pp), C.byref(sp.tiling),
+                                                        ws["overflow"].data_ptr(), cnt, part, edge_cols, st),
+                  "tiled")
+            if timed:
                 e1.record(torch.cuda.current_stream(self.device))
                 self.kernel_events.append((e0, e1))
             check(self.L.lpa_push_deposit_list_2d(self._g(), C.byref(pc), C.byref(pp),
                                                   ws["overflow"].data_ptr(), cnt, sp.n_sorted, st), "list")
             loose = sp.n - sp.n_sorted
-            if loose > 0:
+            if loose > 0 and part != _lib.LPA_PART_INTERIOR:
                 check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), sp.n_sorted, loose, st),
                       "loose")
-        else:
+        elif part != _lib.LPA_PART_INTERIOR:
             check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), 0, sp.n, st), "global")
-        sp.steps_since_sort += 1
+        if part != _lib.LPA_PART_EDGE:
+            sp.steps_since_sort += 1
+
+    def edge_columns(self, dt):
+        """tile columns at each x face whose particles (or anything that drifted out of them since the
+        last sort, at < c) can reach the x guard planes: the rest is safe to push while those planes
+        travel.  0 = no overlap possible (slab too thin)."""
+        drift = constants.C_LIGHT * dt / self.dx * max(self.sort_interval, 1) + 2.0
+        cols = int(np.ceil(drift / _lib.LPA_TILE_X))
+        return cols if 2 * cols < self.nx // _lib.LPA_TILE_X else 0
+
+    def push_deposit_overlapped(self, dt):
+        """push + deposit of all species with the J / rho guard-plane exchange hidden behind the interior
+        tiles: edge tile columns (+ overflow + arrivals) first, then the exchange runs on a second
+        stream while the interior is pushed; the received planes are folded in afterwards (the
+        reference overlaps the same way: sync_currents_start ... intra-rank work ... _wait,
+        simulation.py:1155-1188).  Returns False when the slab is too thin to split."""
+        cols = self.edge_columns(dt)
+        if self.comm.size == 1 or cols == 0 or any(sp.tiling is None for sp in self.species if sp.n):
+            return False
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        h = self._halo_bufs()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            st = self.stream
+            for side, b in ((0, h["s_lo"]), (1, h["s_hi"])):
+                check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st), "lpa_halo_pack_current")
+            self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
+            done.record(self._side)
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt, part=_lib.LPA_PART_INTERIOR, edge_cols=cols)
+        main.wait_event(done)
+        st = self.stream
+        if self.comm.has_left:
+            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "lpa_halo_unpack_current")
+        if self.comm.has_right:
+            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "lpa_halo_unpack_current")
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        return True
 
     # ---- split kernels: the path the reference takes when a callback sits in a pusher stage --------
     # (`simulation/simulation.py:993-1038`): push_position, interpolate, boris, push_position, deposit
@@ -548,9 +599,10 @@ class PicEngine2D:
                 if sp.tiling is None or sp.steps_since_sort >= self.sort_interval:
                     self.sort(i)
         self.reset_current()
-        for i in range(len(self.species)):
-            self.push_deposit(i, dt, tiled=tiled)
-        self.sync_currents()
+        if not (tiled and self.overlap and self.push_deposit_overlapped(dt)):
+            for i in range(len(self.species)):
+                self.push_deposit(i, dt, tiled=tiled)
+            self.sync_currents()
         for i in range(len(self.species)):
             self.sync_particles(i)
         self.update_bfield(0.5 * dt)
