@@ -358,6 +358,9 @@ class PicEngine3D:
                                          ez.data_ptr(), self.stream), "lpa_laser_inject_3d")
         self._keep = (ey, ez)
 
+    def reset_current(self):
+        check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
+
     # ---- one step --------------------------------------------------------------------------------------
     def push_deposit(self, i, dt):
         L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
@@ -392,7 +395,7 @@ class PicEngine3D:
         self.sync_guard_fields(1)
         self.update_bfield(0.5 * dt)
         self.sync_guard_fields(2)
-        check(L.lpa_reset_current(g, st), "lpa_reset_current")
+        self.reset_current()
         for i in range(len(self.species)):
             self.push_deposit(i, dt)
         self.sync_currents()

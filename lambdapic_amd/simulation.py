@@ -14,8 +14,9 @@ reproduces exactly that protocol on top of ``PicEngine2D``:
 
 The device owns the state; ``sim.patches[i].fields.*`` / ``.particles[ispec].*`` are host MIRRORS in
 λPIC's layout.  They are refreshed (device -> host) before a stage that has a triggered callback and
-written back (host -> device) after it, so reference-style callbacks run unchanged.  Out of scope
-here: PML, lasers, QED, collisions, load balancing, I/O.
+written back (host -> device) after it, so reference-style callbacks run unchanged.  CPML layers,
+laser injection (``lambdapic_amd.laser``) and the moving window are device native.  Out of scope here
+(SURVEY.md section 2): QED, collisions, load balancing, I/O.  The 3-D twin is ``simulation3d.py``.
 """
 from __future__ import annotations
 

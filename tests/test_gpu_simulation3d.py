@@ -1,0 +1,79 @@
+"""Simulation3D: the reference's stage / callback protocol on PicEngine3D (laser-target-3d in small)."""
+import numpy as np
+import pytest
+import torch
+
+from lambdapic_amd import constants
+from lambdapic_amd.laser import GaussianLaser3D
+from lambdapic_amd.simulation3d import Simulation3D, Species, callback
+
+pytestmark = pytest.mark.gpu
+C = 299792458.0
+LAM = 0.8e-6
+
+
+def _sim(**kw):
+    nx, ny, nz = 48, 24, 32
+    sim = Simulation3D(nx, ny, nz, LAM / 10, LAM / 5, LAM / 5, cpml_thickness=4, random_seed=3, sort_interval=4,
+                       block_particles=1024, **kw)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / LAM) ** 2 / constants.E_CHARGE ** 2
+    dens = lambda x, y, z: np.where((x > 20 * sim.dx) & (x < 30 * sim.dx) & (abs(y - sim.Ly / 2) < 6 * sim.dy)
+                                    & (abs(z - sim.Lz / 2) < 8 * sim.dz), 2 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=2, momentum_sigma=0.02))
+    sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=2))
+    return sim
+
+
+def test_laser_target_3d_through_the_callback_api():
+    """GaussianLaser3D at stage '_laser' heats a plasma block; a host callback at stage 'end' reads the
+    mirrors (fields with guards, particles binned by patch), another writes an external field in; the
+    device-native path and the mirrored path advance the same physics"""
+    sim = _sim(npatch_x=2, npatch_y=1, npatch_z=2)
+    laser = GaussianLaser3D(a0=3.0, l0=LAM, w0=1.0e-6, ctau=0.8e-6, x0=1.6e-6)
+    seen = {}
+
+    @callback(stage="end", interval=10)
+    def probe(s):
+        f = s.patches[0].fields
+        assert f.ey.shape == (24 + 6, 24 + 6, 16 + 6)          # patch interior + guards, reference layout
+        seen[s.itime] = (sum(float(np.sum(p.fields.ey[:24, :24, :16] ** 2)) for p in s.patches),
+                         sum(p.particles[0].npart for p in s.patches),
+                         float(sum(np.sum(1 / p.particles[0].inv_gamma - 1) for p in s.patches)))
+
+    sim.run(60, callbacks=[laser, probe])
+    d = sim.engine.diagnostics()
+    n0 = seen[0][1]
+    # (an a0 = 3 pulse pushes a few electrons sideways into the absorbing layer by the end)
+    assert n0 > 2000 and seen[30][1] == n0 and 0.98 * n0 <= d["nalive"][0] <= n0
+    assert seen[50][0] > 0 and seen[50][2] > 20 * seen[0][2]               # the pulse arrived and heats
+    e_dev = float((sim.engine.view("ey")[3:-3, 3:-3, 3:-3] ** 2).sum().item())
+    assert e_dev > 0
+
+    # the mirrored path: the same run with a do-nothing host callback at every step gives the same state
+    sim2 = _sim(npatch_x=2, npatch_y=1, npatch_z=2)
+    laser2 = GaussianLaser3D(a0=3.0, l0=LAM, w0=1.0e-6, ctau=0.8e-6, x0=1.6e-6)
+    noop = callback(stage="maxwell_1", interval=1)(lambda s: None)
+    sim2.run(60, callbacks=[laser2, noop])
+    d2 = sim2.engine.diagnostics()
+    assert d2["nalive"] == d["nalive"]
+    assert d2["field_energy"] == pytest.approx(d["field_energy"], rel=1e-9)
+    assert d2["kinetic"][0] == pytest.approx(d["kinetic"][0], rel=1e-9)
+
+
+def test_host_callback_writes_reach_the_device():
+    sim = _sim()
+    sim.initialize()
+
+    @callback(stage="start", interval=1)
+    def kick(s):                       # an external-field plugin in the reference's style
+        for p in s.patches:
+            p.fields.ez[:p.nx, :p.ny, :p.nz] += 1e9
+            p.particles[1].uz[:] += 0.01
+
+    sim.run(1, callbacks=[kick])
+    assert sim.engine.view("ez")[10, 10, 10].item() != 0.0
+    uz = sim.engine.download_species(1)["uz"]
+    assert uz.size and np.all(np.abs(uz - 0.01) < 1e-3)
+
+    with pytest.raises(NotImplementedError):
+        sim.run(1, callbacks=[callback(stage="_interpolator")(lambda s: None)])
