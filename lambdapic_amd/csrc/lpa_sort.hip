@@ -42,7 +42,7 @@ constexpr int32_t SORT_MAGIC = 0x4c504131;
 
 struct SortWs {
     SortHdr *hdr;
-    int32_t *cell_cnt, *cell_off, *tile_cnt, *tile_off, *tile_off_prev, *blk_tile, *blk_begin, *blk_end, *apre;
+    int32_t *cell_cnt, *cell_off, *cell_base, *tile_cnt, *tile_off, *tile_off_prev, *blk_tile, *blk_begin, *blk_end, *apre;
     unsigned long long *masks;
     uint32_t *key, *rank;
     int ntiles, max_blocks;
@@ -69,6 +69,7 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     p = take(sizeof(SortHdr)); if (w) w->hdr = (SortHdr *)p;
     p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_cnt = (int32_t *)p;
     p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_off = (int32_t *)p;
+    p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_base = (int32_t *)p;
     p = take(sizeof(int32_t) * nt); if (w) w->tile_cnt = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off_prev = (int32_t *)p;
@@ -115,57 +116,77 @@ __device__ __forceinline__ uint32_t cell_rank(bool live, uint32_t ck, int32_t *c
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_cell_count(PartV p, double x0, double y0, double inv_dx,
-                                                    double inv_dy, int nx, int ny, int tiles_y,
-                                                    int32_t *cell_cnt, uint32_t *key, uint32_t *rank) {
-    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = false;
-    uint32_t ck = KEY_DEAD;
-    if (ip < p.n) {
-        double x = p.x[ip], y = p.y[ip];
-        live = !((p.dead && p.dead[ip]) || isnan(x) || isnan(y));
-        if (live) {
-            // nearest-node cell, clamped into the slab (a particle may sit up to one cell outside
-            // between the push and the migration)
-            int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5);
-            is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
-            js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
-            int tile = (is / TX) * tiles_y + js / TY;
-            ck = (uint32_t)(tile * TCELLS + (is % TX) * TY + (js % TY));
-        }
+// geometry of the key: nearest-node cell, clamped into the slab (a particle may sit up to one cell
+// outside between the push and the migration); 2-D key = tile * 256 + lx * 32 + ly, 3-D key =
+// tile * 256 + (lx * 4 + ly) * 16 + lz (z fastest, like the grid)
+struct KeyGeom {
+    int dim, nx, ny, nz, tiles_y, tiles_z;
+    double x0, y0, z0, inv_dx, inv_dy, inv_dz;
+};
+
+__device__ __forceinline__ uint32_t cell_key(const PartV &p, long ip, const KeyGeom &k) {
+    double x = p.x[ip], y = p.y[ip];
+    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return KEY_DEAD;
+    int is = ifloor((x - k.x0) * k.inv_dx + 0.5), js = ifloor((y - k.y0) * k.inv_dy + 0.5);
+    is = is < 0 ? 0 : (is >= k.nx ? k.nx - 1 : is);
+    js = js < 0 ? 0 : (js >= k.ny ? k.ny - 1 : js);
+    if (k.dim == 2) {
+        int tile = (is / TX) * k.tiles_y + js / TY;
+        return (uint32_t)(tile * TCELLS + (is % TX) * TY + (js % TY));
     }
-    uint32_t r = cell_rank(live, ck, cell_cnt);
-    if (ip < p.n) {
+    double z = p.z[ip];
+    if (isnan(z)) return KEY_DEAD;
+    int ks = ifloor((z - k.z0) * k.inv_dz + 0.5);
+    ks = ks < 0 ? 0 : (ks >= k.nz ? k.nz - 1 : ks);
+    int tile = ((is / T3X) * k.tiles_y + js / T3Y) * k.tiles_z + ks / T3Z;
+    return (uint32_t)(tile * TCELLS + ((is % T3X) * T3Y + (js % T3Y)) * T3Z + (ks % T3Z));
+}
+
+// any particle order: key + rank by atomics on the global cell counters
+__global__ void __launch_bounds__(256) k_cell_count(PartV p, KeyGeom k, const SortHdr *hdr, int32_t *cell_cnt,
+                                                    uint32_t *key, uint32_t *rank) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hdr->prev_valid && (long)(blockIdx.x + 1) * blockDim.x <= hdr->prev_n) return;  // block-uniform
+    bool mine = ip < p.n && !(hdr->prev_valid && ip < hdr->prev_n);   // the rest: k_cell_count_tiled
+    uint32_t ck = mine ? cell_key(p, ip, k) : KEY_DEAD;
+    uint32_t r = cell_rank(ck != KEY_DEAD, ck, cell_cnt);
+    if (mine) {
         key[ip] = ck;
         rank[ip] = r;
     }
 }
 
-// 3-D key: tile-major, inside the tile (lx * 4 + ly) * 16 + lz (z fastest, like the grid)
-__global__ void __launch_bounds__(256) k_cell_count_3d(PartV p, double x0, double y0, double z0,
-                                                       double inv_dx, double inv_dy, double inv_dz, int nx,
-                                                       int ny, int nz, int tiles_y, int tiles_z,
-                                                       int32_t *cell_cnt, uint32_t *key, uint32_t *rank) {
-    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = false;
-    uint32_t ck = KEY_DEAD;
-    if (ip < p.n) {
-        double x = p.x[ip], y = p.y[ip], z = p.z[ip];
-        live = !((p.dead && p.dead[ip]) || isnan(x) || isnan(y) || isnan(z));
-        if (live) {
-            int is = ifloor((x - x0) * inv_dx + 0.5), js = ifloor((y - y0) * inv_dy + 0.5),
-                ks = ifloor((z - z0) * inv_dz + 0.5);
-            is = is < 0 ? 0 : (is >= nx ? nx - 1 : is);
-            js = js < 0 ? 0 : (js >= ny ? ny - 1 : js);
-            ks = ks < 0 ? 0 : (ks >= nz ? nz - 1 : ks);
-            int tile = ((is / T3X) * tiles_y + js / T3Y) * tiles_z + ks / T3Z;
-            ck = (uint32_t)(tile * TCELLS + ((is % T3X) * T3Y + (js % T3Y)) * T3Z + (ks % T3Z));
+// Re-sorts: the source is tile ordered, so one workgroup walks one OLD tile and ranks the particles
+// that stay in it with LDS counters (rank = RANK_LOCAL | local rank); only particles that changed tile
+// use a global atomic.  At the end the tile's counts are added to the global counters in one atomic
+// per cell, whose return value is the offset of the local ranks (cell_base) -- the scatter adds it.
+constexpr uint32_t RANK_LOCAL = 0x80000000u;
+
+__global__ void __launch_bounds__(512) k_cell_count_tiled(PartV p, KeyGeom k, const SortHdr *hdr,
+                                                          const int32_t *__restrict__ tile_off_prev,
+                                                          int32_t *cell_cnt, int32_t *cell_base,
+                                                          uint32_t *key, uint32_t *rank) {
+    __shared__ int32_t s_cnt[TCELLS];
+    if (!hdr->prev_valid) return;
+    const int t = blockIdx.x;
+    if (threadIdx.x < TCELLS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int sb = tile_off_prev[t], se = tile_off_prev[t + 1];
+    for (int ip = sb + (int)threadIdx.x; ip < se; ip += blockDim.x) {
+        uint32_t ck = cell_key(p, ip, k);
+        uint32_t r = 0;
+        if (ck != KEY_DEAD) {
+            if ((int)(ck >> 8) == t) r = RANK_LOCAL | (uint32_t)atomicAdd(&s_cnt[ck & 255], 1);
+            else r = (uint32_t)atomicAdd(&cell_cnt[ck], 1);
         }
-    }
-    uint32_t r = cell_rank(live, ck, cell_cnt);
-    if (ip < p.n) {
         key[ip] = ck;
         rank[ip] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < TCELLS) {
+        int n = s_cnt[threadIdx.x];
+        long c = (long)t * TCELLS + threadIdx.x;
+        cell_base[c] = n ? atomicAdd(&cell_cnt[c], n) : 0;
     }
 }
 
@@ -349,10 +370,12 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
 }
 
 __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
+                                          const int32_t *__restrict__ cell_base,
                                           const int32_t *__restrict__ tile_off,
                                           const int32_t *__restrict__ cell_off,
                                           const unsigned long long *__restrict__ masks,
                                           const int32_t *__restrict__ apre) {
+    if (r & RANK_LOCAL) r = (r & ~RANK_LOCAL) + (uint32_t)cell_base[ck];
     if (!striped) return (long)cell_off[ck] + r;
     long t = ck >> 8;
     int c = ck & 255;
@@ -371,9 +394,9 @@ constexpr int ST_BITS = 65536;                               // destination slot
 
 __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     AttrList al, const SortHdr *hdr, const int32_t *__restrict__ tile_off_prev,
-    const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ tile_off,
-    const int32_t *__restrict__ cell_off, const unsigned long long *__restrict__ masks,
-    const int32_t *__restrict__ apre, int striped) {
+    const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ cell_base,
+    const int32_t *__restrict__ tile_off, const int32_t *__restrict__ cell_off,
+    const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped) {
     __shared__ double s_val[2][ST_W];           // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
     if (!hdr->prev_valid) return;
@@ -388,7 +411,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
             dest[j] = -1;
             if (ip < se) {
                 uint32_t ck = key[ip];
-                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, tile_off, cell_off, masks, apre);
+                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre);
             }
         }
         // (a tile with more than ST_BITS particles is covered in several passes)
@@ -471,14 +494,17 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                        (long)src->n);
     LPA_CHECK_LAUNCH("k_save_prev");
     if (src->n > 0) {
+        KeyGeom kg;
+        kg.dim = dim; kg.nx = g->nx; kg.ny = g->ny; kg.nz = dim == 3 ? g->nz : 1;
+        kg.tiles_y = tiles_y; kg.tiles_z = tiles_z;
+        kg.x0 = g->x0; kg.y0 = g->y0; kg.z0 = dim == 3 ? g->z0 : 0.0;
+        kg.inv_dx = 1.0 / g->dx; kg.inv_dy = 1.0 / g->dy; kg.inv_dz = dim == 3 ? 1.0 / g->dz : 0.0;
+        // tile-ordered prefix (re-sorts): LDS counters per old tile; does nothing on a first sort
+        hipLaunchKernelGGL(k_cell_count_tiled, dim3(w.ntiles), dim3(512), 0, st, sv, kg, w.hdr, w.tile_off_prev,
+                           w.cell_cnt, w.cell_base, w.key, w.rank);
+        LPA_CHECK_LAUNCH("k_cell_count_tiled");
         unsigned nb = (unsigned)((src->n + 255) / 256);
-        if (dim == 2)
-            hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, 1.0 / g->dx,
-                               1.0 / g->dy, g->nx, g->ny, tiles_y, w.cell_cnt, w.key, w.rank);
-        else
-            hipLaunchKernelGGL(k_cell_count_3d, dim3(nb), dim3(256), 0, st, sv, g->x0, g->y0, g->z0,
-                               1.0 / g->dx, 1.0 / g->dy, 1.0 / g->dz, g->nx, g->ny, g->nz, tiles_y, tiles_z,
-                               w.cell_cnt, w.key, w.rank);
+        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, kg, w.hdr, w.cell_cnt, w.key, w.rank);
         LPA_CHECK_LAUNCH("k_cell_count");
     }
     hipLaunchKernelGGL(k_tile_sum, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_cnt);
@@ -504,7 +530,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         const int striped = (int)(order == LPA_ORDER_STRIPED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
         hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
-                           w.key, w.rank, w.tile_off, w.cell_off, w.masks, w.apre, striped);
+                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
         unsigned nb = (unsigned)((src->n + 255) / 256);
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
