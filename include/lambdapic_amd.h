@@ -227,6 +227,9 @@ int lpa_push_deposit_3d(const lpa_grid *g, const lpa_particles *p, const lpa_pus
 int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles *p,
                               const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
                               uint32_t *overflow_count, void *stream);
+int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_particles *p,
+                                   const lpa_push_params *pp, const lpa_tiling *t, uint32_t *overflow,
+                                   uint32_t *overflow_count, int part, int edge_cols, void *stream);
 int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                              const uint32_t *list, const uint32_t *list_count, int64_t max_count,
                              void *stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "lpa_push_deposit_list_2d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
     "lpa_push_deposit_3d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
     "lpa_push_deposit_tiled_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
+    "lpa_push_deposit_tiled_part_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _i, _i, _vp]),
     "lpa_push_deposit_list_3d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
     "lpa_interpolate_2d": (_i, [_G, _P, _vp]),
     "lpa_boris": (_i, [_P, _d, _d, _d, _vp]),

@@ -300,13 +300,17 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
 __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
-    uint32_t *overflow, uint32_t *overflow_count) {
+    uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols) {
     __shared__ double s_j[4][R3N];
     __shared__ double s_eb[6][E3N];
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
     const int begin = blk_begin[blockIdx.x], end = blk_end[blockIdx.x];
     const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y, tx_ = tile / (tiles_z * tiles_y);
+    if (part) {  // LPA_PART_EDGE / LPA_PART_INTERIOR: see lpa_push_deposit_tiled_part_2d
+        const bool edge = tx_ < edge_cols || tx_ >= tiles_x - edge_cols;
+        if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform, before any barrier
+    }
     const int t0[3] = {tx_ * T3X, ty_ * T3Y, tz_ * T3Z};          // first node of the tile
     const int r0[3] = {t0[0] - H3, t0[1] - H3, t0[2] - H3};       // first node of the LDS region
     const int lane = threadIdx.x & 63;
@@ -500,7 +504,16 @@ extern "C" int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *
 extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles *p,
                                          const lpa_push_params *pp, const lpa_tiling *t,
                                          uint32_t *overflow, uint32_t *overflow_count, void *stream) {
+    return lpa_push_deposit_tiled_part_3d(g, p, pp, t, overflow, overflow_count, LPA_PART_ALL, 0, stream);
+}
+
+extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_particles *p,
+                                              const lpa_push_params *pp, const lpa_tiling *t,
+                                              uint32_t *overflow, uint32_t *overflow_count, int part,
+                                              int edge_cols, void *stream) {
     if (int e = check_push3(g, p, pp, "lpa_push_deposit_tiled_3d")) return e;
+    LPA_REQUIRE(part == LPA_PART_ALL || ((part == LPA_PART_EDGE || part == LPA_PART_INTERIOR) && edge_cols >= 1),
+                "lpa_push_deposit_tiled_part_3d: bad part / edge_cols");
     LPA_REQUIRE(t && t->blk_tile && t->blk_begin && t->blk_end && t->n_blocks && t->max_blocks > 0 &&
                     overflow && overflow_count,
                 "lpa_push_deposit_tiled_3d: bad tiling");
@@ -512,7 +525,7 @@ extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles 
     if (t->n_sorted == 0) return LPA_OK;
     hipLaunchKernelGGL(k_push_deposit_tiled_3d, dim3(t->max_blocks), dim3(K13_THREADS), 0, (hipStream_t)stream,
                        make_gridv(g, 3), make_partv(p), make_pushk3(pp), t->blk_tile, t->blk_begin, t->blk_end,
-                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count);
+                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols);
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
     return LPA_OK;
 }

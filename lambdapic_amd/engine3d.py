@@ -156,6 +156,8 @@ class PicEngine3D:
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
         self._halo = None
+        self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
+        self.overlap = True
 
     @property
     def stream(self):
@@ -362,7 +364,9 @@ class PicEngine3D:
         check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
 
     # ---- one step --------------------------------------------------------------------------------------
-    def push_deposit(self, i, dt):
+    def push_deposit(self, i, dt, part=_lib.LPA_PART_ALL, edge_cols=0):
+        """``part``: LPA_PART_EDGE = edge tile columns + overflow list + arrival area (everything that can
+        deposit into the x guard planes), LPA_PART_INTERIOR = the remaining tiles (+ their overflow)"""
         L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
         pp = _lib.lpa_push_params()
         pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes | self.absorb
@@ -372,20 +376,58 @@ class PicEngine3D:
         if not self.tiled:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
             return
-        if sp["tiling"] is None or sp["since"] >= self.sort_interval:
+        if part != _lib.LPA_PART_INTERIOR and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
             self.sort(i)
         ws = sp["ws"]
         ws["count"].zero_()
-        check(L.lpa_push_deposit_tiled_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
-                                          ws["overflow"].data_ptr(), ws["count"].data_ptr(), st),
-              "lpa_push_deposit_tiled_3d")
+        check(L.lpa_push_deposit_tiled_part_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
+                                               ws["overflow"].data_ptr(), ws["count"].data_ptr(), part, edge_cols,
+                                               st), "lpa_push_deposit_tiled_3d")
         check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ws["overflow"].data_ptr(),
                                          ws["count"].data_ptr(), sp["n_sorted"], st), "lpa_push_deposit_list_3d")
         loose = sp["n"] - sp["n_sorted"]        # arrival area: pushed by the global kernel until the next sort
-        if loose > 0:
+        if loose > 0 and part != _lib.LPA_PART_INTERIOR:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), sp["n_sorted"], loose, st),
                   "lpa_push_deposit_3d")
-        sp["since"] += 1
+        if part != _lib.LPA_PART_EDGE:
+            sp["since"] += 1
+
+    def edge_columns(self, dt):
+        drift = constants.C_LIGHT * dt / self.d[0] * max(self.sort_interval, 1) + 2.0
+        cols = int(np.ceil(drift / _lib.LPA_TILE3_X))
+        return cols if 2 * cols < self.n[0] // _lib.LPA_TILE3_X else 0
+
+    def push_deposit_overlapped(self, dt):
+        """as PicEngine2D.push_deposit_overlapped: edge tile columns first, the J / rho guard planes travel on a
+        second stream while the interior tiles are pushed.  False when the slab is too thin to split."""
+        cols = self.edge_columns(dt)
+        if self.comm.size == 1 or not self.tiled or cols == 0:
+            return False
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        h = self._halo_bufs()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            st = self.stream
+            for side, b in ((0, h["s_lo"]), (1, h["s_hi"])):
+                check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st), "lpa_halo_pack_current")
+            self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
+            done.record(self._side)
+        for i in range(len(self.species)):
+            self.push_deposit(i, dt, part=_lib.LPA_PART_INTERIOR, edge_cols=cols)
+        main.wait_event(done)
+        st = self.stream
+        if self.comm.has_left:
+            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "lpa_halo_unpack_current")
+        if self.comm.has_right:
+            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "lpa_halo_unpack_current")
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        return True
 
     def step(self, dt, laser=None):
         """``laser``: optional callable ``laser(engine, dt)`` run at the reference's '_laser' stage
@@ -396,9 +438,10 @@ class PicEngine3D:
         self.update_bfield(0.5 * dt)
         self.sync_guard_fields(2)
         self.reset_current()
-        for i in range(len(self.species)):
-            self.push_deposit(i, dt)
-        self.sync_currents()
+        if not (self.overlap and self.push_deposit_overlapped(dt)):
+            for i in range(len(self.species)):
+                self.push_deposit(i, dt)
+            self.sync_currents()
         for i in range(len(self.species)):
             self.sync_particles(i)
         self.update_bfield(0.5 * dt)
