@@ -434,6 +434,7 @@ class Simulation:
                 self.ispec = ispec
                 if unified:
                     self.pusher[ispec](self.dt, unified=True)
+                    self.current_synced = False      # simulation.py:991: every deposit un-syncs the currents
                 else:
                     self.pusher[ispec].push_position(0.5 * self.dt)
                     self._run_stage(table, "_push_position_1")
@@ -445,6 +446,7 @@ class Simulation:
                     self.pusher[ispec].push_position(0.5 * self.dt)
                     self._run_stage(table, "_push_position_2")
                     self.current_depositor(ispec, self.dt)
+                    self.current_synced = False      # simulation.py:1038
                 self._run_stage(table, "current_deposition")
             self.sync_currents()
             self.ispec = None

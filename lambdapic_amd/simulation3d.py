@@ -299,6 +299,7 @@ class Simulation3D:
             for ispec in range(len(self.species)):
                 self.ispec = ispec
                 self.pusher[ispec](self.dt, unified=True)
+                self.current_synced = False          # simulation.py:991: every deposit un-syncs the currents
                 self._run_stage(table, "current_deposition")
             self.sync_currents()
             self.ispec = None

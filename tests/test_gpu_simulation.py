@@ -140,3 +140,33 @@ def test_mirror_round_trip_is_lossless():
     assert (sim.engine.grid.view("ex") - ex0).abs().max().item() == 0.0
     sim.run(3)                                    # and the run continues from the uploaded state
     assert sim.itime == 8
+
+
+def test_extract_species_density_on_device():
+    """ExtractSpeciesDensity (callback/utils.py:240-293): the density of each species from the rho it adds
+    at its 'current_deposition' stage; the currents of every species still reach the interior (the
+    callback syncs in the middle of the species loop, simulation.py:991 un-syncs after each deposit)"""
+    from lambdapic_amd.callbacks import ExtractSpeciesDensity
+    from lambdapic_amd.simulation import Simulation, Species
+    nx = ny = 64
+    dx = dy = 4e-8
+    bc = {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")}
+    sim = Simulation(nx, ny, dx, dy, boundary_conditions=bc, random_seed=2)
+    n1 = lambda x, y: np.where(x < 32 * dx, 1.0e25, 3.0e25)
+    n2 = lambda x, y: np.full_like(x, 2.0e25)
+    e = Species("e", charge=-1, mass=1, density=n1, ppc=8, momentum_sigma=0.01)
+    p = Species("p", charge=2, mass=3672.0, density=n2, ppc=4)
+    sim.add_species([e, p])
+    sim.initialize()
+    de, dp = ExtractSpeciesDensity(sim, e, interval=1), ExtractSpeciesDensity(sim, p, interval=1)
+    sim.run(3, callbacks=[de, dp])
+    ne, np_ = de.density, dp.density
+    assert ne.shape == (nx, ny)
+    # TSC-smoothed loading: means per half box, total particle number exact
+    assert ne[4:28].mean() == pytest.approx(1.0e25, rel=0.05) and ne[36:60].mean() == pytest.approx(3.0e25, rel=0.05)
+    assert np_.mean() == pytest.approx(2.0e25, rel=1e-9)
+    assert ne.sum() * dx * dy == pytest.approx(2.0e25 * nx * ny * dx * dy, rel=1e-9)
+    # total charge on the grid = sum over species (nothing was lost in the guards)
+    d = sim.engine.diagnostics()
+    want = (-1 * ne.sum() + 2 * np_.sum()) * dx * dy * 1.602176634e-19
+    assert d["charge"] == pytest.approx(want, rel=1e-9)
