@@ -530,6 +530,8 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     LPA_REQUIRE(LPA_C * pp->dt <= g->dx && LPA_C * pp->dt <= g->dy,
                 "lpa_push_deposit_tiled_2d: c*dt exceeds a cell (CFL); use lpa_push_deposit_2d");
     if (t->n_sorted == 0) return LPA_OK;
+    // particle attributes are addressed with 32-bit byte offsets inside the kernel
+    LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_2d: more than 2^29 particles in one store");
     GridV gv = make_gridv(g, 2);
     PartV pv = make_partv(p);
     PushK k = make_pushk(pp);

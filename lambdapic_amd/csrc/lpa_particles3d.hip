@@ -523,6 +523,7 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
     LPA_REQUIRE(p->is_dead == nullptr,
                 "lpa_push_deposit_tiled_3d: tile-binned stores carry no is_dead array (dead = NaN x)");
     if (t->n_sorted == 0) return LPA_OK;
+    LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_3d: more than 2^29 particles in one store");
     hipLaunchKernelGGL(k_push_deposit_tiled_3d, dim3(t->max_blocks), dim3(K13_THREADS), 0, (hipStream_t)stream,
                        make_gridv(g, 3), make_partv(p), make_pushk3(pp), t->blk_tile, t->blk_begin, t->blk_end,
                        t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols);
