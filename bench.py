@@ -154,6 +154,7 @@ def main():
                     help="gloo = rehearsal of the multi-rank path with ranks sharing GPUs (buffers staged "
                          "through the host); the driver's runs use nccl (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--no-defer", action="store_true", help="A/B: deposit cell-crossers' tail cells inline")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -175,6 +176,7 @@ def main():
     assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     eng, dt, n_local = build_engine(args, comm, device)
+    eng.defer_crossers = not args.no_defer
     for _ in range(args.warmup):
         eng.step(dt)
     # timed region: EXACTLY --steps steps between barrier + synchronize on both sides

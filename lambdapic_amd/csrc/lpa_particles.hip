@@ -202,7 +202,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 constexpr int WR_MIN_GROUP = 12;
 constexpr int WR_MAX_ROUNDS = 2;
 
-template <bool WRITE_EB, bool WAVE_REDUCE>
+// Window row 3 / column 3 only receive something from a particle that changed cell during the step (a few
+// per cent of the lanes), yet a wave has to issue those 28 ds_add_f64 whenever ANY of its 64 lanes did.
+// With DEFER such lanes park their advanced state (7 doubles) in a scratch store (the idle half of the
+// ping-pong sort buffers), the main loop deposits the 3x3 core only, and the workgroup deposits the
+// parked particles' tail cells afterwards with every lane busy.
+struct Scratch7 { double *a[7]; };
+
+template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER>
 __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
@@ -210,9 +217,10 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                                               const int32_t *__restrict__ n_blocks,
                                                               int tiles_y, uint32_t *overflow,
                                                               uint32_t *overflow_count, int part,
-                                                              int tiles_x, int edge_cols) {
+                                                              int tiles_x, int edge_cols, Scratch7 sc) {
     __shared__ double s_eb[RSZ];
     __shared__ double s_j[4][RSZJ];
+    __shared__ int s_ncross;
     if ((int)blockIdx.x >= *n_blocks) return;  // block-uniform
     const int tile = blk_tile[blockIdx.x];
     if (part) {  // LPA_PART_EDGE: the edge_cols tile columns at each x face; LPA_PART_INTERIOR: the others
@@ -224,6 +232,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     const int tx0 = (tile / tiles_y) * TX, ty0 = (tile % tiles_y) * TY;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
+    if (DEFER && threadIdx.x == 0) s_ncross = 0;
 
     // ---- stage E/B (nodes outside the padded array are never touched by a fast-path particle)
     {
@@ -351,6 +360,12 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
             // ds_add_f64 below hits 32 different bank pairs.
             if (valid) {
+                if (DEFER && (!ax.tail_zero || !ay.tail_zero)) {
+                    const int slot = atomicAdd(&s_ncross, 1);
+                    const uint32_t o = (uint32_t)(begin + slot) * 8u;
+                    st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
+                    st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
+                }
                 esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                    [&](int kk, int ll, double djx, double djy, double djz, double drho) {
                                        int o = b0 + kk * RSJ + ll;
@@ -362,6 +377,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                        // (one exec-mask region per run of cells) instead of testing 64
                                        // values -- crossers are ~3 % of the lanes
                                        bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
+                                       if (DEFER) on = kk < 3 && ll < 3;   // the tails come later
 #ifdef LPA_ABLATE_NO_TAIL  // diagnostic build: drop window row 3 / column 3 (wrong for cell crossers)
                                        on = kk < 3 && ll < 3;
 #endif
@@ -423,6 +439,35 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                 }
                 todo = 0;
             }
+        }
+    }
+    if (DEFER) {
+        // ---- tail cells of the particles that changed cell: same inputs, same code as in the loop above
+        // (axis_window / esirkepov_2d are deterministic), every lane busy
+        __syncthreads();
+        const int ncross = s_ncross;
+        for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
+            const uint32_t o = (uint32_t)(begin + i) * 8u;
+            const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
+                         uz = ld(sc.a[4], o), ig = ld(sc.a[5], o), w = ld(sc.a[6], o);
+            const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+            AxisW ax, ay;
+            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
+            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
+            const int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
+            const int b0 = bx * RSJ + by;
+            esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
+                               [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                   if (kk < 3 && ll < 3) return;
+                                   bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
+                                   if (on) {
+                                       int oo = b0 + kk * RSJ + ll;
+                                       atomicAdd(&s_j[0][oo], djx);
+                                       atomicAdd(&s_j[1][oo], djy);
+                                       atomicAdd(&s_j[2][oo], djz);
+                                       atomicAdd(&s_j[3][oo], drho);
+                                   }
+                               });
         }
     }
     __syncthreads();
@@ -537,14 +582,22 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     PushK k = make_pushk(pp);
     // CELL_MAJOR stores use the wave reduce-scatter deposit, STRIPED stores the conflict-free atomics
     const bool eb = p->part_eb[0] != nullptr, wr = t->order == LPA_ORDER_CELL_MAJOR;
-#define LPA_LAUNCH_TILED(E, W)                                                                          \
-    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W>), dim3(t->max_blocks), dim3(K1_THREADS), 0,      \
+    Scratch7 sc;
+    bool defer = !wr;
+    for (int c = 0; c < 7; c++) {
+        sc.a[c] = t->scratch[c];
+        defer = defer && sc.a[c] != nullptr;
+    }
+#define LPA_LAUNCH_TILED(E, W, D)                                                                       \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D>), dim3(t->max_blocks), dim3(K1_THREADS), 0,   \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
-                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols)
-    if (eb && wr) LPA_LAUNCH_TILED(true, true);
-    else if (eb) LPA_LAUNCH_TILED(true, false);
-    else if (wr) LPA_LAUNCH_TILED(false, true);
-    else LPA_LAUNCH_TILED(false, false);
+                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc)
+    if (eb && wr) LPA_LAUNCH_TILED(true, true, false);
+    else if (wr) LPA_LAUNCH_TILED(false, true, false);
+    else if (eb && defer) LPA_LAUNCH_TILED(true, false, true);
+    else if (eb) LPA_LAUNCH_TILED(true, false, false);
+    else if (defer) LPA_LAUNCH_TILED(false, false, true);
+    else LPA_LAUNCH_TILED(false, false, false);
 #undef LPA_LAUNCH_TILED
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_2d");
     return LPA_OK;

@@ -150,6 +150,7 @@ class PicEngine2D:
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
+        self.defer_crossers = True
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every
         # launch of the tiled push+deposit kernel on the stream it runs on
@@ -304,6 +305,11 @@ class PicEngine2D:
         sp.n = n_live + area
         ws["counters"].zero_()
         ws["tiling"].n_sorted = n_live
+        # the set that was just sorted FROM is idle until the next sort: scratch for the dense second
+        # pass of the tiled kernel (particles that changed cell)
+        idle = sp.other()
+        for c, a in enumerate(("x", "y", "ux", "uy", "uz", "inv_gamma", "w")):
+            ws["tiling"].scratch[c] = idle.arr(a).data_ptr() if self.defer_crossers else None
         sp.tiling = ws["tiling"]
         sp.steps_since_sort = 0
 
