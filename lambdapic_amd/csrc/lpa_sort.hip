@@ -389,7 +389,12 @@ __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
     return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
 }
 
-constexpr int ST_THREADS = 1024, ST_PT = 16, ST_W = 8192;   // particles per thread and chunk; window slots
+#ifndef LPA_ST_THREADS
+#define LPA_ST_THREADS 1024
+#define LPA_ST_PT 16
+#define LPA_ST_W 8192
+#endif
+constexpr int ST_THREADS = LPA_ST_THREADS, ST_PT = LPA_ST_PT, ST_W = LPA_ST_W;   // threads, particles per thread and chunk, window slots
 constexpr int ST_BITS = 65536;                               // destination slots covered by one bitmap pass
 
 __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
