@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     __syncthreads();
 
     const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy;
-    double abl = 0.0;  // only used by the LPA_ABLATE_* diagnostic builds
+    [[maybe_unused]] double abl = 0.0;  // only used by the LPA_ABLATE_* diagnostic builds
     // wave-uniform trip count: every lane of a wave runs the same iterations (the deposit below uses
     // wave-wide DPP / permlane operations)
     // software pipeline: the seven attribute loads of the NEXT iteration are issued before the current
