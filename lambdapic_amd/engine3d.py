@@ -360,6 +360,105 @@ class PicEngine3D:
                                          ez.data_ptr(), self.stream), "lpa_laser_inject_3d")
         self._keep = (ey, ez)
 
+    # ---- moving window (MovingWindow callback, callback/utils.py:471-648; 3-D patch relabelling :705-730) ----
+    def remove_x_pml(self):
+        """the reference drops the x layers when the window starts moving (callback/utils.py:547-553)"""
+        if self.pml is None:
+            return
+        old = self.pml
+        sides = [s_ for s_ in old.sides if s_[0] != "x"]
+        if len(sides) == len(old.sides):
+            return
+        new = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device) if sides else None
+        if new is not None:      # the y / z layers keep their psi history
+            keep = {(l["e"], l["axis"], l["start"]): l for l in old.layers}
+            for l in new.layers:
+                o = keep.get((l["e"], l["axis"], l["start"]))
+                if o is not None:
+                    l["psi_a"], l["psi_b"] = o["psi_a"], o["psi_b"]
+        self.pml = new
+        ntot = self.n[0] * self.comm.size
+        xg = self.x0 - self.comm.rank * self.n[0] * self.d[0]          # current global origin
+        self.alo[0] = xg - self.d[0] / 2
+        self.ahi[0] = xg + (ntot - 1) * self.d[0] + self.d[0] / 2
+
+    def shift_window(self, ncells):
+        """move every slab ``ncells`` to the right (see PicEngine2D.shift_window): field columns and the
+        psi rows of the y / z layers that leave through a low face travel to the left neighbour; the last
+        rank's new columns start from zero; particles left of the new lower bound follow or are dropped"""
+        n, ng, nx = int(ncells), self.ng, self.n[0]
+        if not 0 < n <= nx - ng:
+            raise _lib.LpaError("window shift must be between 1 and nx - n_guard cells")
+        keep = ng + nx - n
+        lay = [l for l in self.pml.layers if l["axis"] != 0] if self.pml is not None else []
+
+        def rows(l, k):          # psi array of a y / z layer as [nx][...]
+            return l[k].view(nx, -1)
+
+        parts = [self.buf[:, ng:ng + n + ng].reshape(-1)]
+        for l in lay:
+            for k in ("psi_a", "psi_b"):
+                parts.append(rows(l, k)[:n].reshape(-1))
+        send = torch.cat(parts)
+        recv = torch.zeros_like(send)
+        if self.comm.size > 1:
+            one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+            self.comm.exchange(send, one(), one(), recv)
+        plane = self.N[1] * self.N[2]
+        nf = 10 * (n + ng) * plane
+        self.buf[:, :keep] = self.buf[:, n:n + keep].clone()
+        self.buf[:, keep:] = recv[:nf].view(10, n + ng, self.N[1], self.N[2])
+        off = nf
+        for l in lay:
+            for k in ("psi_a", "psi_b"):
+                v = rows(l, k)
+                w = v.shape[1]
+                v[: nx - n] = v[n:].clone()
+                v[nx - n:] = recv[off:off + n * w].view(n, w)
+                off += n * w
+        shift = n * self.d[0]
+        self.x0 += shift
+        self.c.x0 = self.x0
+        self.alo[0] += shift
+        self.ahi[0] += shift
+        xlo = self.x0 - self.d[0] / 2
+        for sp in self.species:
+            x = sp["data"][0, : sp["n"]]
+            if self.comm.size == 1:
+                x[x < xlo] = float("nan")
+                continue
+            idx = (x < xlo).nonzero().squeeze(1)          # host sync: a window shift is a rare event
+            cnt = torch.tensor([float(idx.numel())], dtype=torch.float64, device=self.device)
+            got = torch.zeros_like(cnt)
+            self.comm.exchange(cnt, torch.zeros_like(cnt), torch.zeros_like(cnt), got)
+            out = sp["data"][:, idx].contiguous()
+            x[idx] = float("nan")
+            k = int(got.item()) if self.comm.has_right else 0
+            inc = torch.empty((len(ATTRS3), k), dtype=torch.float64, device=self.device)
+            dummy = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+            self.comm.exchange(out.reshape(-1) if out.numel() else dummy(), dummy(), dummy(),
+                               inc.reshape(-1) if inc.numel() else dummy())
+            if k:
+                self.append_device(self.species.index(sp), inc)
+
+    def append_device(self, i, rows):
+        """append particles (device tensor [8][k], ATTRS3 order) behind the stored ones as loose particles
+        and force a re-sort; grows the store when needed"""
+        sp = self.species[i]
+        k = int(rows.shape[1])
+        if k == 0:
+            return
+        cap = sp["data"].shape[1]
+        if sp["n"] + k + self.arrival_area() > cap:
+            new = torch.full((len(ATTRS3), int(1.5 * (sp["n"] + k)) + self.arrival_area()), float("nan"),
+                             dtype=torch.float64, device=self.device)
+            new[:, : sp["n"]] = sp["data"][:, : sp["n"]]
+            sp["data"], sp["alt"], sp["ws"], sp["tiling"], sp["n_sorted"] = new, None, None, None, 0
+        sp["data"][:, sp["n"]:sp["n"] + k] = rows
+        sp["n"] += k
+        sp["c"] = self._cstruct(sp["data"], sp["n"])
+        sp["since"] = 1 << 30
+
     def reset_current(self):
         check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
 

@@ -186,6 +186,36 @@ class Simulation3D:
             q.inv_gamma[:] = 1.0 / np.sqrt(1 + q.ux ** 2 + q.uy ** 2 + q.uz ** 2)
         return n
 
+    @property
+    def nx_per_patch(self):
+        return self.n_per_patch[0]
+
+    def shift_window_right(self, inject):
+        """recycle the leftmost patch column (`callback/utils.py:594-620`, 3-D relabelling `:705-730`)"""
+        eng, n = self.engine, self.n_per_patch[0]
+        eng.shift_window(n)
+        self.window_shifts = getattr(self, "window_shifts", 0) + 1
+        for p in self.patches:
+            p.x0 += n * self.dx
+            p.fields.x0 = p.x0
+            p.fields.xaxis += n * self.dx
+        if not inject or self.comm.rank != self.comm.size - 1:
+            return
+        px, py, pz = self.npatch
+        npp, d = self.n_per_patch, (self.dx, self.dy, self.dz)
+        x_new = eng.x0 + (eng.n[0] - n) * self.dx
+        for s in self.species:
+            for k in range(pz):
+                for j in range(py):
+                    org = (x_new, j * npp[1] * self.dy, k * npp[2] * self.dz)
+                    tmp = Patch3D(0, (0, j, k), org, npp, d, self.n_guard, 0)
+                    q = ParticlesBase(ipatch=j + py * k, rank=self.comm.rank)
+                    seed = None if self.random_seed is None else \
+                        [self.random_seed, s.ispec] + [int(round(o / dd)) for o, dd in zip(org, d)]
+                    if self._fill(tmp, q, s, np.random.default_rng(seed)):
+                        rows = torch.from_numpy(np.stack([getattr(q, a) for a in ATTRS3])).to(self.device)
+                        eng.append_device(s.ispec, rows)
+
     # ---- host mirrors <-> device ----------------------------------------------------------------------------
     def _upload_particles(self, ispec):
         sp = self.engine.species[ispec]

@@ -399,3 +399,67 @@ def test_3d_laser_target_chain_matches_single_rank():
     for a in f1:
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
+
+
+# ---- 3-D moving window on a slab chain -------------------------------------------------------------------
+def _run_window_3d(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd import constants
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.laser import GaussianLaser3D
+    from lambdapic_amd.simulation import MovingWindow
+    from lambdapic_amd.simulation3d import Simulation3D, Species
+    lam = 0.8e-6
+    nx, ny, nz = 96, 16, 32
+    dx, dy, dz = lam / 10, lam / 5, lam / 5
+    comm = SlabComm(None, periodic=False, single=(world == 1))
+    sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=6 // world, cpml_thickness=4, random_seed=4, sort_interval=4,
+                       block_particles=1024, comm=comm)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
+    dens = lambda x, y, z: np.where((x > 70 * dx) & (abs(y - sim.Ly / 2) < 4 * dy) & (abs(z - sim.Lz / 2) < 8 * dz),
+                                    0.05 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=2, momentum_sigma=0.01))
+    laser = GaussianLaser3D(a0=1.5, l0=lam, w0=0.8e-6, ctau=0.5e-6, x0=1.2e-6)
+    mw = MovingWindow(velocity=C, start_time=0.7 * nx * dx / C)
+    trace = []
+    for it in range(170):
+        sim.run(1, callbacks=[laser, mw])
+        if it % 17 == 16:
+            d = sim.engine.diagnostics()
+            trace.append([d["field_energy"], d["charge"], sum(d["kinetic"]), sum(d["nalive"])])
+    nxl = nx // world
+    sl = (slice(3, 3 + nxl), slice(3, 3 + ny), slice(3, 3 + nz))
+    fields = {a: sim.engine.view(a)[sl].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    fields["_x0"] = np.full((1, ny, nz), (sim.engine.x0 - rank * nxl * dx) / dx)
+    q.put((rank, np.array(trace), fields))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_moving_window_3d_chain_matches_single_rank():
+    def launch(world):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_run_window_3d, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return sum(r[1] for r in res), {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
+
+    t1, f1 = launch(1)
+    t2, f2 = launch(2)
+    assert f1["_x0"][0, 0, 0] >= 3 * 16 and np.array_equal(f1["_x0"][0], f2["_x0"][0])
+    assert t1[-1, 3] > 200 and np.array_equal(t2[:, 3], t1[:, 3])
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a

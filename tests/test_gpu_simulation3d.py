@@ -77,3 +77,40 @@ def test_host_callback_writes_reach_the_device():
 
     with pytest.raises(NotImplementedError):
         sim.run(1, callbacks=[callback(stage="_interpolator")(lambda s: None)])
+
+
+def test_moving_window_3d_matches_long_static_box():
+    """MovingWindow on Simulation3D (parity unpinned, as in 2-D): translation invariance -- a 96-cell window
+    following a pulse through vacuum and into a plasma block that is injected column by column, against a
+    static 224-cell box; compared ahead of the window's open left edge"""
+    from lambdapic_amd.simulation import MovingWindow
+    ny, nz, pw = 24, 32, 16
+    dx, dy, dz = LAM / 10, LAM / 5, LAM / 5
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / LAM) ** 2 / constants.E_CHARGE ** 2
+
+    def case(nx, cbs):
+        sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=nx // pw, cpml_thickness=4, random_seed=9, sort_interval=4,
+                           block_particles=1024)
+        dens = lambda x, y, z: np.where((x > 110 * dx) & (abs(y - sim.Ly / 2) < 5 * dy) & (abs(z - sim.Lz / 2) < 7 * dz),
+                                        0.05 * nc, 0.0)
+        sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=2))
+        laser = GaussianLaser3D(a0=1.0, l0=LAM, w0=0.8e-6, ctau=0.5e-6, x0=1.2e-6)
+        sim.run(200, callbacks=[laser] + cbs)
+        return sim
+
+    w = case(96, [MovingWindow(velocity=C, start_time=0.8 * 96 * dx / C)])
+    s = case(224, [])
+    shifts = w.window_shifts
+    assert shifts >= 4
+    off = shifts * pw
+    assert w.engine.x0 == pytest.approx(off * dx, rel=1e-12)
+    ng, margin = 3, 32
+    for a in ("ey", "bz", "ex", "jx", "rho"):
+        fw = w.engine.view(a)[ng + margin:ng + 96 - 4, ng:-ng, ng:-ng].cpu().numpy()
+        fs = s.engine.view(a)[ng + off + margin:ng + off + 96 - 4, ng:-ng, ng:-ng].cpu().numpy()
+        scale = np.abs(fs).max()
+        if a in ("ey", "bz"):
+            assert scale > 0
+        if scale > 0:
+            assert np.abs(fw - fs).max() <= 1e-8 * scale, a
+    assert w.engine.diagnostics()["nalive"][0] > 500
