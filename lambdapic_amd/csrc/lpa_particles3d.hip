@@ -1,6 +1,7 @@
-// lpa_particles3d.hip -- 3-D fused particle kernel, global-memory form (any particle order):
-// half push, 27-point TSC gather on the staggered Yee grid, Boris, half push, 3-D Esirkepov deposit
-// with FP64 global atomics on the torus.
+// lpa_particles3d.hip -- 3-D fused particle kernels: half push, 27-point TSC gather on the staggered Yee
+// grid, Boris, half push, 3-D Esirkepov deposit.  Two forms: global memory (any particle order, FP64
+// global atomics on the torus; also the overflow-list form) and LDS-tiled (tile-sorted particles, E / B and
+// J / rho of a 4 x 4 x 16-cell tile staged in LDS).
 // Restates unified_boris_pusher_cpu_3d (core/pusher/unified/unified_pusher_3d.c:219-436) and
 // current_deposit_3d_fast (core/current/current_deposit.h:275-440).
 #include "lpa_common.hpp"

@@ -14,8 +14,10 @@ facades perform on its patch lists, one call per reference call:
     mpi.sync_particles_* + patches.sync_particles                sync_particles
 
 Multi-GPU: the domain is split into 1-D slabs along x, one process per GPU (torch.distributed,
-backend nccl == RCCL); x faces are exchanged with the two ring neighbours (``SlabComm``), y is
-periodic inside the slab.  With one rank both axes are handled locally.
+backend nccl == RCCL); x faces are exchanged with the two ring (periodic x) or chain (open x) neighbours
+(``SlabComm``); the J / rho exchange runs on a second stream behind the interior tiles
+(``push_deposit_overlapped``).  Open faces carry CPML layers (``DevicePML2D``), absorb particles and
+take the laser (``laser_inject``); ``shift_window`` moves the slab chain (MovingWindow).
 """
 from __future__ import annotations
 
