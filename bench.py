@@ -130,7 +130,16 @@ def cpu_baseline(args):
         one_step()
         steps += 1
     el = time.perf_counter() - t0
+    # how the port compares with the reference's own compiled kernel: measured in the build container, where
+    # both exist (oracle/cpu_ratio.py -> profiles/r01_cpu_port_vs_reference.txt); the reference cannot travel
+    ratio = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_cpu_port_vs_reference.txt")) as fh:
+            ratio = float(fh.read().strip().split("=")[-1])
+    except (OSError, ValueError):
+        pass
     return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+            "port_over_reference_same_cores": ratio,
             "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
                       f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
                       f"-O3 -march=native, {threads} OpenMP threads"}
