@@ -371,8 +371,10 @@ class PicEngine2D:
     def edge_columns(self, dt):
         """tile columns at each x face whose particles (or anything that drifted out of them since the
         last sort, at < c) can reach the x guard planes: the rest is safe to push while those planes
-        travel.  0 = no overlap possible (slab too thin)."""
-        drift = constants.C_LIGHT * dt / self.dx * max(self.sort_interval, 1) + 2.0
+        travel.  Uses the actual age of the order (a disabled sorter makes it grow).  0 = no overlap
+        possible (slab too thin for that much drift)."""
+        age = max([sp.steps_since_sort for sp in self.species if sp.n] + [0]) + 1
+        drift = constants.C_LIGHT * dt / self.dx * age + 4.0     # + the 3 nodes a deposit window reaches, + 1
         cols = int(np.ceil(drift / _lib.LPA_TILE_X))
         return cols if 2 * cols < self.nx // _lib.LPA_TILE_X else 0
 

@@ -492,7 +492,9 @@ class PicEngine3D:
             sp["since"] += 1
 
     def edge_columns(self, dt):
-        drift = constants.C_LIGHT * dt / self.d[0] * max(self.sort_interval, 1) + 2.0
+        """see PicEngine2D.edge_columns (the sort, when due, runs inside the edge pass: age 0 then)"""
+        age = max([0 if sp["since"] >= self.sort_interval else sp["since"] for sp in self.species] + [0]) + 1
+        drift = constants.C_LIGHT * dt / self.d[0] * age + 4.0   # + the 3 nodes a deposit window reaches, + 1
         cols = int(np.ceil(drift / _lib.LPA_TILE3_X))
         return cols if 2 * cols < self.n[0] // _lib.LPA_TILE3_X else 0
 
