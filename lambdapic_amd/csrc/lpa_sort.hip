@@ -62,7 +62,8 @@ static int tile_count(const lpa_grid *g) {
 
 static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
     int nt = tile_count(g);
-    int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1;
+    // + 8: the tiled kernels launch max_blocks workgroups and deal work blocks to them in XCD order
+    int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1 + 8;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return base ? base + o : nullptr; };
     char *p;
