@@ -430,7 +430,13 @@ class Simulation:
                 self.sorter[ispec]()
             self.current_depositor.reset()
             self.current_synced = False
-            for ispec in range(len(self.species)):
+            # no callback between the species' deposits: push the edge tiles first and hide the J / rho
+            # exchange behind the interior (the reference's sync_currents_start ... _wait bracket)
+            fused_all = unified and not table.get("current_deposition") and self.engine.overlap and \
+                all(p._enabled for p in self.pusher) and self.engine.push_deposit_overlapped(self.dt)
+            if fused_all:
+                self.current_synced = True
+            for ispec in range(len(self.species) if not fused_all else 0):
                 self.ispec = ispec
                 if unified:
                     self.pusher[ispec](self.dt, unified=True)

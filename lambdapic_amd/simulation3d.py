@@ -326,7 +326,11 @@ class Simulation3D:
                 self.sorter[ispec]()
             eng.reset_current()
             self.current_synced = False
-            for ispec in range(len(self.species)):
+            fused_all = not table.get("current_deposition") and eng.overlap and \
+                all(p._enabled for p in self.pusher) and eng.push_deposit_overlapped(self.dt)
+            if fused_all:
+                self.current_synced = True
+            for ispec in range(len(self.species) if not fused_all else 0):
                 self.ispec = ispec
                 self.pusher[ispec](self.dt, unified=True)
                 self.current_synced = False          # simulation.py:991: every deposit un-syncs the currents
