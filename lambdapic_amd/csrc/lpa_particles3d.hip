@@ -264,7 +264,12 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_3d(GridV g, PartV p, 
 constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
 constexpr int H3 = LPA_TILE3_MARGIN + 2;
 constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10 x 10 x 22
-constexpr int R3N = R3X * R3Y * R3Z;                                       // 2200
+#ifndef LPA_R3ZS
+#define LPA_R3ZS 24
+#endif
+constexpr int R3ZS = LPA_R3ZS;   // z stride of the J image (>= R3Z): 24 makes the x stride (240) a multiple of 16
+                                 // doubles, so a lane that drifted along x keeps its bank (-3 % against 22)
+constexpr int R3N = R3X * R3Y * R3ZS;
 constexpr int G3L = LPA_TILE3_MARGIN + 2, G3H = LPA_TILE3_MARGIN + 1;      // gather reach below / above the tile
 constexpr int E3X = T3X + G3L + G3H, E3Y = T3Y + G3L + G3H, E3Z = T3Z + G3L + G3H;  // 9 x 9 x 21
 constexpr int E3N = E3X * E3Y * E3Z;                                       // 1701
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             st(p.x, o, xs); st(p.y, o, ys); st(p.z, o, zs);
             st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
         }
-        const int b0 = (bx * R3Y + by) * R3Z + bz;
+        const int b0 = (bx * R3Y + by) * R3ZS + bz;
         // window plane 3 of an axis carries exact zeros unless the particle changed cell along that axis
         // (see the 2-D kernel)
         esirkepov_3d_lean(
@@ -441,7 +446,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #ifdef LPA_ABLATE_NO_TAIL
                 on = i < 3 && j < 3 && kk < 3;
 #endif
-                if (on) atomicAdd(&s_j[0][b0 + (i * R3Y + j) * R3Z + kk], djx);
+                if (on) atomicAdd(&s_j[0][b0 + (i * R3Y + j) * R3ZS + kk], djx);
             },
             [&](int i, int j, int kk, double djy, double djz, double dr) {
                 bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
@@ -449,7 +454,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                 on = i < 3 && j < 3 && kk < 3;
 #endif
                 if (on) {
-                    int o = b0 + (i * R3Y + j) * R3Z + kk;
+                    int o = b0 + (i * R3Y + j) * R3ZS + kk;
                     atomicAdd(&s_j[1][o], djy);
                     atomicAdd(&s_j[2][o], djz);
                     atomicAdd(&s_j[3][o], dr);
@@ -461,7 +466,8 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     {
         double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
         for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
-            int lz = t % R3Z, ly = (t / R3Z) % R3Y, lx = t / (R3Z * R3Y);
+            int lz = t % R3ZS, ly = (t / R3ZS) % R3Y, lx = t / (R3ZS * R3Y);
+            if (lz >= R3Z) continue;   // stride padding
             long gi = ((long)torus(r0[0] + lx + g.ng, g.NX) * g.NY + torus(r0[1] + ly + g.ng, g.NY)) * g.NZ +
                       torus(r0[2] + lz + g.ng, g.NZ);
 #pragma unroll
