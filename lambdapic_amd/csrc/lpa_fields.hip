@@ -460,6 +460,14 @@ extern "C" int lpa_reset_current(const lpa_grid *g, void *stream) {
     size_t n = (size_t)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) *
                (g->nz > 1 ? (size_t)(g->nz + 2 * g->ng) : 1) * sizeof(double);
     double *a[4] = {g->jx, g->jy, g->jz, g->rho};
+    const size_t cnt = n / sizeof(double);
+    if (a[1] == a[0] + cnt && a[2] == a[1] + cnt && a[3] == a[2] + cnt) {  // one allocation: one memset
+        if (hipMemsetAsync(a[0], 0, 4 * n, (hipStream_t)stream) != hipSuccess) {
+            lpa_set_error("lpa_reset_current: hipMemsetAsync failed");
+            return LPA_ERR_HIP;
+        }
+        return LPA_OK;
+    }
     for (int c = 0; c < 4; c++)
         if (hipMemsetAsync(a[c], 0, n, (hipStream_t)stream) != hipSuccess) {
             lpa_set_error("lpa_reset_current: hipMemsetAsync failed");
