@@ -140,6 +140,23 @@ int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int start, int stop
  *      rows iy in [iy_start, iy_end) are driven. */
 int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
                         int iy_end, const double *ey_source, const double *ez_source, void *stream);
+/* fused form: the kappa-scaled update and the psi recursions of all the layers a cell lies in, in one launch
+ * per field update (same operations, same order; the psi recursion of E reads only B and vice versa).
+ * One descriptor per axis: kappa [n]; the low / high layer's cell range ([x0, x1) empty = none), bcoeff /
+ * ccoeff_d [n] and the compact psi arrays of each layer (layouts as for lpa_cpml_psi_2d). */
+typedef struct {
+    const double *kappa, *bcoeff, *ccoeff_d;
+    int32_t lo0, lo1, hi0, hi1;
+    double *psi_a_lo, *psi_b_lo, *psi_a_hi, *psi_b_hi;
+} lpa_cpml_axis;
+int lpa_fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                             const lpa_cpml_axis *ay, void *stream);
+int lpa_fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay,
+                             void *stream);
+int lpa_fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                             const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream);
+int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay,
+                             const lpa_cpml_axis *az, void *stream);
 /* 3-D twins: update_efield/bfield_cpml_3d (core/boundary/cpml.py:431-475), update_psi_{x,y,z}_and_{e,b}_3d
  * (:609-729; psi arrays compact: axis 0 [layer][ny][nz], axis 1 [nx][layer][nz], axis 2 [nx][ny][layer]),
  * _update_laser_bfields_3d (callback/laser.py:63-92; sources [ny][nz] over the interior nodes) */

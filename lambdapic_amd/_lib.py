@@ -49,6 +49,13 @@ class lpa_tiling(C.Structure):
                 ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 7)]
 
 
+class lpa_cpml_axis(C.Structure):
+    _fields_ = [("kappa", C.c_void_p), ("bcoeff", C.c_void_p), ("ccoeff_d", C.c_void_p),
+                ("lo0", C.c_int32), ("lo1", C.c_int32), ("hi0", C.c_int32), ("hi1", C.c_int32),
+                ("psi_a_lo", C.c_void_p), ("psi_b_lo", C.c_void_p), ("psi_a_hi", C.c_void_p),
+                ("psi_b_hi", C.c_void_p)]
+
+
 class lpa_push_params(C.Structure):
     _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32),
                 ("lo", C.c_double * 3), ("hi", C.c_double * 3),
@@ -70,6 +77,10 @@ SIGNATURES = {
     "lpa_fdtd_b_cpml_2d": (_i, [_G, _d, _vp, _vp, _vp]),
     "lpa_cpml_psi_2d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "lpa_laser_inject_2d": (_i, [_G, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
+    "lpa_fdtd_e_cpml_fused_2d": (_i, [_G, _d, _d, C.POINTER(lpa_cpml_axis), C.POINTER(lpa_cpml_axis), _vp]),
+    "lpa_fdtd_b_cpml_fused_2d": (_i, [_G, _d, C.POINTER(lpa_cpml_axis), C.POINTER(lpa_cpml_axis), _vp]),
+    "lpa_fdtd_e_cpml_fused_3d": (_i, [_G, _d, _d] + [C.POINTER(lpa_cpml_axis)] * 3 + [_vp]),
+    "lpa_fdtd_b_cpml_fused_3d": (_i, [_G, _d] + [C.POINTER(lpa_cpml_axis)] * 3 + [_vp]),
     "lpa_fdtd_e_cpml_3d": (_i, [_G, _d, _d, _vp, _vp, _vp, _vp]),
     "lpa_fdtd_b_cpml_3d": (_i, [_G, _d, _vp, _vp, _vp, _vp]),
     "lpa_cpml_psi_3d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),

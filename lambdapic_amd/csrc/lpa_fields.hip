@@ -235,6 +235,242 @@ extern "C" int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int star
     return LPA_OK;
 }
 
+// ---- fused form: kappa-scaled update + the psi recursions of every layer the cell lies in, one launch per
+// field update instead of 1 + (number of layers).  Exact: a psi recursion of the E update reads only B (and
+// vice versa), so doing it right after the cell's own kappa update, x layer before y (before z), performs
+// the same operations in the same order as the separate launches.
+struct CpmlAxisV {
+    const double *kappa, *bco, *cco;
+    int lo0, lo1, hi0, hi1;          // the layers' cell ranges along this axis ([x0, x1) empty = no layer)
+    double *pa_lo, *pb_lo, *pa_hi, *pb_hi;
+};
+
+static CpmlAxisV make_axisv(const lpa_cpml_axis *a) {
+    CpmlAxisV v;
+    v.kappa = a->kappa; v.bco = a->bcoeff; v.cco = a->ccoeff_d;
+    v.lo0 = a->lo0; v.lo1 = a->lo1; v.hi0 = a->hi0; v.hi1 = a->hi1;
+    v.pa_lo = a->psi_a_lo; v.pb_lo = a->psi_b_lo; v.pa_hi = a->psi_a_hi; v.pb_hi = a->psi_b_hi;
+    return v;
+}
+
+static int cpml_axis_ok(const lpa_cpml_axis *a, int n) {
+    if (!a || !a->kappa) return 0;
+    if (a->lo1 > a->lo0 && !(a->lo0 >= 0 && a->lo1 <= n && a->bcoeff && a->ccoeff_d && a->psi_a_lo && a->psi_b_lo)) return 0;
+    if (a->hi1 > a->hi0 && !(a->hi0 >= 0 && a->hi1 <= n && a->bcoeff && a->ccoeff_d && a->psi_a_hi && a->psi_b_hi)) return 0;
+    return 1;
+}
+
+// which layer of the axis holds position `pos` (0 none, 1 low, 2 high) and the layer-local index
+__device__ __forceinline__ int cpml_layer(const CpmlAxisV &a, int pos, int &l, int &nl) {
+    if (pos >= a.lo0 && pos < a.lo1) { l = pos - a.lo0; nl = a.lo1 - a.lo0; return 1; }
+    if (pos >= a.hi0 && pos < a.hi1) { l = pos - a.hi0; nl = a.hi1 - a.hi0; return 2; }
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bfac, double jfac, double fac,
+                                                              CpmlAxisV ax, CpmlAxisV ay) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xm = c - g.NY, ym = c - 1;
+    double bfx = bfac / ax.kappa[i], bfy = bfac / ay.kappa[j];
+    double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
+    double bz_xm = g.bz[xm], bz_ym = g.bz[ym], by_xm = g.by[xm], bx_ym = g.bx[ym];
+    double ex = g.ex[c], ey = g.ey[c], ez = g.ez[c];
+    ex += bfy * ((bzc - bz_ym) / g.dy) - jfac * g.jx[c];
+    ey += bfx * (-(bzc - bz_xm) / g.dx) - jfac * g.jy[c];
+    ez += bfx * ((byc - by_xm) / g.dx) - bfy * ((bxc - bx_ym) / g.dy) - jfac * g.jz[c];
+    int l, nl;
+    if (int w = cpml_layer(ax, i, l, nl)) {          // cpml.py:531-548
+        double *pa_ = w == 1 ? ax.pa_lo : ax.pa_hi, *pb_ = w == 1 ? ax.pb_lo : ax.pb_hi;
+        long ps = (long)l * g.ny + j;
+        double b = ax.bco[i], cc = ax.cco[i];
+        double pa = b * pa_[ps] + cc * (bzc - bz_xm);
+        double pb = b * pb_[ps] + cc * (byc - by_xm);
+        pa_[ps] = pa; pb_[ps] = pb;
+        ey -= fac * pa; ez += fac * pb;
+    }
+    if (int w = cpml_layer(ay, j, l, nl)) {          // cpml.py:569-586
+        double *pa_ = w == 1 ? ay.pa_lo : ay.pa_hi, *pb_ = w == 1 ? ay.pb_lo : ay.pb_hi;
+        long ps = (long)i * nl + l;
+        double b = ay.bco[j], cc = ay.cco[j];
+        double pa = b * pa_[ps] + cc * (bzc - bz_ym);
+        double pb = b * pb_[ps] + cc * (bxc - bx_ym);
+        pa_[ps] = pa; pb_[ps] = pb;
+        ex += fac * pa; ez -= fac * pb;
+    }
+    g.ex[c] = ex; g.ey[c] = ey; g.ez[c] = ez;
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.ny) return;
+    long c = (long)(i + g.ng) * g.NY + (j + g.ng);
+    long xp = c + g.NY, yp = c + 1;
+    double efx = dt / ax.kappa[i], efy = dt / ay.kappa[j];
+    double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
+    double ez_xp = g.ez[xp], ez_yp = g.ez[yp], ey_xp = g.ey[xp], ex_yp = g.ex[yp];
+    double bx = g.bx[c], by = g.by[c], bz = g.bz[c];
+    bx -= efy * ((ez_yp - ezc) / g.dy);
+    by -= efx * (-(ez_xp - ezc) / g.dx);
+    bz -= efx * ((ey_xp - eyc) / g.dx) - efy * ((ex_yp - exc) / g.dy);
+    int l, nl;
+    if (int w = cpml_layer(ax, i, l, nl)) {          // cpml.py:550-567
+        double *pa_ = w == 1 ? ax.pa_lo : ax.pa_hi, *pb_ = w == 1 ? ax.pb_lo : ax.pb_hi;
+        long ps = (long)l * g.ny + j;
+        double b = ax.bco[i], cc = ax.cco[i];
+        double pa = b * pa_[ps] + cc * (ez_xp - ezc);
+        double pb = b * pb_[ps] + cc * (ey_xp - eyc);
+        pa_[ps] = pa; pb_[ps] = pb;
+        by += dt * pa; bz -= dt * pb;
+    }
+    if (int w = cpml_layer(ay, j, l, nl)) {          // cpml.py:588-606
+        double *pa_ = w == 1 ? ay.pa_lo : ay.pa_hi, *pb_ = w == 1 ? ay.pb_lo : ay.pb_hi;
+        long ps = (long)i * nl + l;
+        double b = ay.bco[j], cc = ay.cco[j];
+        double pa = b * pa_[ps] + cc * (ez_yp - ezc);
+        double pb = b * pb_[ps] + cc * (ex_yp - exc);
+        pa_[ps] = pa; pb_[ps] = pb;
+        bx -= dt * pa; bz += dt * pb;
+    }
+    g.bx[c] = bx; g.by[c] = by; g.bz[c] = bz;
+}
+
+extern "C" int lpa_fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 1) && eps0 > 0 && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
+                "lpa_fdtd_e_cpml_fused_2d: bad args");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
+                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay));
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_fused_2d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
+                "lpa_fdtd_b_cpml_fused_2d: bad args");
+    GridV v = make_gridv(g, 2);
+    dim3 grid((g->ny + 255) / 256, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
+                       make_axisv(ay));
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_2d");
+    return LPA_OK;
+}
+
+// 3-D fused twins.  psi layouts: axis 0 [layer][ny][nz], axis 1 [nx][layer][nz], axis 2 [nx][ny][layer].
+__device__ __forceinline__ long psi_index_3d(int axis, int i, int j, int k, int l, int nl, int ny, int nz) {
+    if (axis == 0) return ((long)l * ny + j) * nz + k;
+    if (axis == 1) return ((long)i * nl + l) * nz + k;
+    return ((long)i * ny + j) * nl + l;
+}
+
+// one layer's recursion for the cell: psi_{a,b} <- b psi + cc d{a,b}; returns the two psi values
+__device__ __forceinline__ void psi_step(const CpmlAxisV &a, int w, long ps, int pos, double da, double db,
+                                         double &pa, double &pb) {
+    double *pa_ = w == 1 ? a.pa_lo : a.pa_hi, *pb_ = w == 1 ? a.pb_lo : a.pb_hi;
+    double b = a.bco[pos], cc = a.cco[pos];
+    pa = b * pa_[ps] + cc * da;
+    pb = b * pb_[ps] + cc * db;
+    pa_[ps] = pa; pb_[ps] = pb;
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bfac, double jfac, double fac,
+                                                              CpmlAxisV ax, CpmlAxisV ay, CpmlAxisV az) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    double bfx = bfac / ax.kappa[i], bfy = bfac / ay.kappa[j], bfz = bfac / az.kappa[k];
+    double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
+    double dbz_x = bzc - g.bz[c - sx], dby_x = byc - g.by[c - sx];
+    double dbz_y = bzc - g.bz[c - sy], dbx_y = bxc - g.bx[c - sy];
+    double dby_z = byc - g.by[c - 1], dbx_z = bxc - g.bx[c - 1];
+    double ex = g.ex[c], ey = g.ey[c], ez = g.ez[c];
+    ex += (bfy * dbz_y / g.dy - bfz * dby_z / g.dz) - jfac * g.jx[c];
+    ey += (bfz * dbx_z / g.dz - bfx * dbz_x / g.dx) - jfac * g.jy[c];
+    ez += (bfx * dby_x / g.dx - bfy * dbx_y / g.dy) - jfac * g.jz[c];
+    int l, nl;
+    double pa, pb;
+    if (int w = cpml_layer(ax, i, l, nl)) {   // psi(ey,ez) <- (bz,by); ey -=, ez +=   (cpml.py:609-628)
+        psi_step(ax, w, psi_index_3d(0, i, j, k, l, nl, g.ny, g.nz), i, dbz_x, dby_x, pa, pb);
+        ey -= fac * pa; ez += fac * pb;
+    }
+    if (int w = cpml_layer(ay, j, l, nl)) {   // psi(ex,ez) <- (bz,bx); ex +=, ez -=   (:651-669)
+        psi_step(ay, w, psi_index_3d(1, i, j, k, l, nl, g.ny, g.nz), j, dbz_y, dbx_y, pa, pb);
+        ex += fac * pa; ez -= fac * pb;
+    }
+    if (int w = cpml_layer(az, k, l, nl)) {   // psi(ex,ey) <- (by,bx); ex -=, ey +=   (:691-710)
+        psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dby_z, dbx_z, pa, pb);
+        ex -= fac * pa; ey += fac * pb;
+    }
+    g.ex[c] = ex; g.ey[c] = ey; g.ez[c] = ez;
+}
+
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay,
+                                                              CpmlAxisV az) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y, i = blockIdx.z;
+    if (k >= g.nz) return;
+    long sy = g.NZ, sx = (long)g.NY * g.NZ;
+    long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
+    double efx = dt / ax.kappa[i], efy = dt / ay.kappa[j], efz = dt / az.kappa[k];
+    double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
+    double dez_x = g.ez[c + sx] - ezc, dey_x = g.ey[c + sx] - eyc;
+    double dez_y = g.ez[c + sy] - ezc, dex_y = g.ex[c + sy] - exc;
+    double dey_z = g.ey[c + 1] - eyc, dex_z = g.ex[c + 1] - exc;
+    double bx = g.bx[c], by = g.by[c], bz = g.bz[c];
+    bx -= (efy * dez_y / g.dy - efz * dey_z / g.dz);
+    by -= (efz * dex_z / g.dz - efx * dez_x / g.dx);
+    bz -= (efx * dey_x / g.dx - efy * dex_y / g.dy);
+    int l, nl;
+    double pa, pb;
+    if (int w = cpml_layer(ax, i, l, nl)) {   // psi(by,bz) <- (ez,ey); by +=, bz -=   (cpml.py:630-649)
+        psi_step(ax, w, psi_index_3d(0, i, j, k, l, nl, g.ny, g.nz), i, dez_x, dey_x, pa, pb);
+        by += dt * pa; bz -= dt * pb;
+    }
+    if (int w = cpml_layer(ay, j, l, nl)) {   // psi(bx,bz) <- (ez,ex); bx -=, bz +=   (:671-689)
+        psi_step(ay, w, psi_index_3d(1, i, j, k, l, nl, g.ny, g.nz), j, dez_y, dex_y, pa, pb);
+        bx -= dt * pa; bz += dt * pb;
+    }
+    if (int w = cpml_layer(az, k, l, nl)) {   // psi(bx,by) <- (ey,ex); bx +=, by -=   (:712-729)
+        psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dey_z, dex_z, pa, pb);
+        bx += dt * pa; by -= dt * pb;
+    }
+    g.bx[c] = bx; g.by[c] = by; g.bz[c] = bz;
+}
+
+extern "C" int lpa_fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1) && eps0 > 0 && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny) &&
+                    cpml_axis_ok(az, g->nz) && g->ny <= 65535 && g->nx <= 65535,
+                "lpa_fdtd_e_cpml_fused_3d: bad args");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_e_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
+                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay), make_axisv(az));
+    LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_fused_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny) && cpml_axis_ok(az, g->nz) &&
+                    g->ny <= 65535 && g->nx <= 65535,
+                "lpa_fdtd_b_cpml_fused_3d: bad args");
+    GridV v = make_gridv(g, 3);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    hipLaunchKernelGGL(k_fdtd_b_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
+                       make_axisv(ay), make_axisv(az));
+    LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_3d");
+    return LPA_OK;
+}
+
 // ---- 3-D CPML (cpml.py:431-475 kappa-scaled update, :609-729 psi recursions) ---------------------------
 __global__ void __launch_bounds__(256) k_fdtd_e_cpml_3d(GridV g, double bfac, double jfac,
                                                         const double *__restrict__ kx,

@@ -153,6 +153,8 @@ class PicEngine2D:
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
         self.defer_crossers = True
+        self.fused_cpml = True
+        self._axes = {}
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every
         # launch of the tiled push+deposit kernel on the stream it runs on
@@ -185,6 +187,11 @@ class PicEngine2D:
             check(self.L.lpa_fdtd_e_2d(self._g(), dt, self.eps0, self.stream), "lpa_fdtd_e_2d")
             return
         p, st = self.pml, self.stream
+        if self.fused_cpml:     # kappa sweep + every layer's psi recursion in one launch
+            ax, ay = self._cpml_axes(True, dt)
+            check(self.L.lpa_fdtd_e_cpml_fused_2d(self._g(), dt, self.eps0, C.byref(ax), C.byref(ay), st),
+                  "lpa_fdtd_e_cpml_fused_2d")
+            return
         check(self.L.lpa_fdtd_e_cpml_2d(self._g(), dt, self.eps0, p.kappa["ex"].data_ptr(),
                                         p.kappa["ey"].data_ptr(), st), "lpa_fdtd_e_cpml_2d")
         self._psi(True, dt)
@@ -194,9 +201,41 @@ class PicEngine2D:
             check(self.L.lpa_fdtd_b_2d(self._g(), dt, self.stream), "lpa_fdtd_b_2d")
             return
         p, st = self.pml, self.stream
+        if self.fused_cpml:
+            ax, ay = self._cpml_axes(False, dt)
+            check(self.L.lpa_fdtd_b_cpml_fused_2d(self._g(), dt, C.byref(ax), C.byref(ay), st),
+                  "lpa_fdtd_b_cpml_fused_2d")
+            return
         check(self.L.lpa_fdtd_b_cpml_2d(self._g(), dt, p.kappa["bx"].data_ptr(), p.kappa["by"].data_ptr(), st),
               "lpa_fdtd_b_cpml_2d")
         self._psi(False, dt)
+
+    def _cpml_axes(self, efield, dt):
+        """lpa_cpml_axis descriptors (x, y) of the E or B update for this dt, cached per PML object"""
+        key = (id(self.pml), bool(efield), dt)
+        if key not in self._axes:
+            out = []
+            for axis, ax in enumerate("xy"):
+                k = ("e" if efield else "b") + ax
+                d = _lib.lpa_cpml_axis()
+                d.kappa = self.pml.kappa[k].data_ptr()
+                b, cc = self.pml.coef(k, dt, self.dx if axis == 0 else self.dy)
+                d.bcoeff, d.ccoeff_d = b.data_ptr(), cc.data_ptr()
+                d.lo0 = d.lo1 = d.hi0 = d.hi1 = 0
+                for ly in self.pml.layers:
+                    if ly["e"] != bool(efield) or ly["axis"] != axis:
+                        continue
+                    if ly["start"] == 0:
+                        d.lo0, d.lo1 = ly["start"], ly["stop"]
+                        d.psi_a_lo, d.psi_b_lo = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                    else:
+                        d.hi0, d.hi1 = ly["start"], ly["stop"]
+                        d.psi_a_hi, d.psi_b_hi = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                out.append(d)
+            if len(self._axes) > 16:
+                self._axes.clear()
+            self._axes[key] = (tuple(out), self.pml)      # keeps the PML object (and its arrays) alive
+        return self._axes[key][0]
 
     def _psi(self, efield, dt):
         for ly in self.pml.layers:

@@ -158,6 +158,8 @@ class PicEngine3D:
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
+        self.fused_cpml = True
+        self._axes = {}
 
     @property
     def stream(self):
@@ -320,6 +322,11 @@ class PicEngine3D:
         if self.pml is None:
             check(self.L.lpa_fdtd_e_3d(g, dt, self.eps0, st), "lpa_fdtd_e_3d")
             return
+        if self.fused_cpml:     # kappa sweep + every layer's psi recursion in one launch
+            a = self._cpml_axes(True, dt)
+            check(self.L.lpa_fdtd_e_cpml_fused_3d(g, dt, self.eps0, C.byref(a[0]), C.byref(a[1]), C.byref(a[2]), st),
+                  "lpa_fdtd_e_cpml_fused_3d")
+            return
         k = self.pml.kappa
         check(self.L.lpa_fdtd_e_cpml_3d(g, dt, self.eps0, k["ex"].data_ptr(), k["ey"].data_ptr(),
                                         k["ez"].data_ptr(), st), "lpa_fdtd_e_cpml_3d")
@@ -330,10 +337,42 @@ class PicEngine3D:
         if self.pml is None:
             check(self.L.lpa_fdtd_b_3d(g, dt, st), "lpa_fdtd_b_3d")
             return
+        if self.fused_cpml:
+            a = self._cpml_axes(False, dt)
+            check(self.L.lpa_fdtd_b_cpml_fused_3d(g, dt, C.byref(a[0]), C.byref(a[1]), C.byref(a[2]), st),
+                  "lpa_fdtd_b_cpml_fused_3d")
+            return
         k = self.pml.kappa
         check(self.L.lpa_fdtd_b_cpml_3d(g, dt, k["bx"].data_ptr(), k["by"].data_ptr(), k["bz"].data_ptr(), st),
               "lpa_fdtd_b_cpml_3d")
         self._psi(False, dt)
+
+    def _cpml_axes(self, efield, dt):
+        """lpa_cpml_axis descriptors (x, y, z) of the E or B update for this dt, cached per PML object"""
+        key = (id(self.pml), bool(efield), dt)
+        if key not in self._axes:
+            out = []
+            for axis, ax in enumerate("xyz"):
+                k = ("e" if efield else "b") + ax
+                d = _lib.lpa_cpml_axis()
+                d.kappa = self.pml.kappa[k].data_ptr()
+                b, cc = self.pml.coef(k, dt, self.d[axis])
+                d.bcoeff, d.ccoeff_d = b.data_ptr(), cc.data_ptr()
+                d.lo0 = d.lo1 = d.hi0 = d.hi1 = 0
+                for ly in self.pml.layers:
+                    if ly["e"] != bool(efield) or ly["axis"] != axis:
+                        continue
+                    if ly["start"] == 0:
+                        d.lo0, d.lo1 = ly["start"], ly["stop"]
+                        d.psi_a_lo, d.psi_b_lo = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                    else:
+                        d.hi0, d.hi1 = ly["start"], ly["stop"]
+                        d.psi_a_hi, d.psi_b_hi = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                out.append(d)
+            if len(self._axes) > 16:
+                self._axes.clear()
+            self._axes[key] = (tuple(out), self.pml)
+        return self._axes[key][0]
 
     def _psi(self, efield, dt):
         for ly in self.pml.layers:

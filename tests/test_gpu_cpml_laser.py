@@ -17,12 +17,14 @@ C = 299792458.0
 PML = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")}
 
 
-def test_cpml_vs_reference_golden(golden):
+@pytest.mark.parametrize("fused", [True, False])
+def test_cpml_vs_reference_golden(golden, fused):
     """80 Maxwell stages, PML on all four sides, against the reference's per-patch PML objects
     (3x3 patches): fields 1e-12 of the max, energy trace 1e-12"""
     g = golden("g9_cpml_2d")
     nx, ny, dx, dy, dt = int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"]), float(g["dt"])
     eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", boundary_conditions=PML, cpml_thickness=int(g["thickness"]))
+    eng.fused_cpml = fused          # one launch per update, or kappa sweep + one psi launch per layer
     s = slice(3, 3 + nx), slice(3, 3 + ny)
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
         eng.grid.view(a)[s] = torch.from_numpy(g["in_" + a]).cuda()

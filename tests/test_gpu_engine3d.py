@@ -114,7 +114,8 @@ def test_3d_tiled_step_vs_oracle(uth, sort_interval):
 PML3 = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
 
 
-def test_cpml_and_laser_3d_vs_reference_golden(golden):
+@pytest.mark.parametrize("fused", [True, False])
+def test_cpml_and_laser_3d_vs_reference_golden(golden, fused):
     """device 3-D CPML (kappa-scaled sweeps + psi kernels of the six layers) and the 3-D laser boundary
     kernel against the reference's PML objects / kernel (g12): three E and B half steps on random
     fields with static guards, then one laser injection"""
@@ -122,6 +123,7 @@ def test_cpml_and_laser_3d_vs_reference_golden(golden):
     nx, ny, nz, ng, th = (int(g[k]) for k in ("nx", "ny", "nz", "ng", "thickness"))
     dx, dy, dz, dt = (float(g[k]) for k in ("dx", "dy", "dz", "dt"))
     eng = PicEngine3D(nx, ny, nz, dx, dy, dz, ng, boundary_conditions=PML3, cpml_thickness=th)
+    eng.fused_cpml = fused          # one launch per update, or kappa sweep + one psi launch per layer
     assert not eng.tiled and len(eng.pml.layers) == 12
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
         eng.upload_field(a, g["in_" + a])
