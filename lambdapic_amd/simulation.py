@@ -243,6 +243,7 @@ class Simulation:
         self.initialized = False
         self.current_synced = False
         self.stages = list(self.STAGES)
+        self.dimension = 2
 
     def add_species(self, species):
         for s in species if isinstance(species, (list, tuple)) else [species]:

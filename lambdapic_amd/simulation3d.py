@@ -190,6 +190,14 @@ class Simulation3D:
     def nx_per_patch(self):
         return self.n_per_patch[0]
 
+    @property
+    def ny_per_patch(self):
+        return self.n_per_patch[1]
+
+    @property
+    def nz_per_patch(self):
+        return self.n_per_patch[2]
+
     def shift_window_right(self, inject):
         """recycle the leftmost patch column (`callback/utils.py:594-620`, 3-D relabelling `:705-730`)"""
         eng, n = self.engine, self.n_per_patch[0]
