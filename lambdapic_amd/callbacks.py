@@ -33,7 +33,7 @@ class ExtractSpeciesDensity:
     def _rho(sim):
         eng = sim.engine
         g = eng.ng
-        if sim.__class__.__name__ == "Simulation3D":
+        if getattr(sim, "dimension", 2) == 3:
             return eng.view("rho")[g:-g, g:-g, g:-g]
         return eng.grid.view("rho")[g:-g, g:-g]
 
