@@ -280,6 +280,14 @@ constexpr int K13_THREADS = LPA_K13_THREADS;
 
 typedef const volatile __attribute__((address_space(3))) double *lds_ptr3;
 
+// padded index of region node `node` along an axis: its periodic image inside [0, n) when the axis is
+// locally periodic (a tile at a box edge, or the image of a particle folded through the face), else the
+// padded-array torus of the global kernels
+__device__ __forceinline__ int node_index(int node, int n, int ng, int N, bool periodic) {
+    if (periodic && (unsigned)node >= (unsigned)n) { node %= n; if (node < 0) node += n; }
+    return torus(node + ng, N);
+}
+
 // 27-point gather from the LDS image of one component; (lx, ly, lz) = local index of the stencil
 // centre; evaluation order of interp_field_fast_3d (unified_pusher_3d.c:111-143): z outermost
 // The TSC weights are rebuilt from the three offsets here (5 flops per axis) instead of keeping six
@@ -335,8 +343,9 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
         for (int t = threadIdx.x; t < E3N; t += blockDim.x) {
             int lz = t % E3Z, ly = (t / E3Z) % E3Y, lx = t / (E3Z * E3Y);
-            long gi = ((long)torus(e0[0] + lx + g.ng, g.NX) * g.NY + torus(e0[1] + ly + g.ng, g.NY)) * g.NZ +
-                      torus(e0[2] + lz + g.ng, g.NZ);
+            long gi = ((long)node_index(e0[0] + lx, g.nx, g.ng, g.NX, k.wrap & 1) * g.NY +
+                       node_index(e0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
+                      node_index(e0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
 #pragma unroll
             for (int c = 0; c < 6; c++) s_eb[c][t] = src[c][gi];
         }
@@ -375,6 +384,20 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         z += k.cdt_half * ig * uz;
         double eb[6];
         {
+            // a particle folded through a locally periodic face since the last sort: work on its periodic
+            // image next to the tile (see the 2-D kernel)
+            if (k.wrap & 7) {
+                const int n3[3] = {g.nx, g.ny, g.nz}, tt[3] = {T3X, T3Y, T3Z};
+                double *pos[3] = {&x, &y, &z};
+                const double org[3] = {g.x0, g.y0, g.z0}, inv[3] = {inv_dx, inv_dy, inv_dz};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    if (!((k.wrap >> a) & 1) || n3[a] < 2 * (tt[a] + 8)) continue;
+                    int dd = ifloor((*pos[a] - org[a]) * inv[a] + 0.5) - (t0[a] + tt[a] / 2);
+                    if (dd > (n3[a] >> 1)) *pos[a] -= k.hi[a] - k.lo[a];
+                    else if (dd < -(n3[a] >> 1)) *pos[a] += k.hi[a] - k.lo[a];
+                }
+            }
             double xo = (x - g.x0) * inv_dx, yo = (y - g.y0) * inv_dy, zo = (z - g.z0) * inv_dz;
             int ix1 = ifloor(xo + 0.5), ix2 = ifloor(xo);
             int iy1 = ifloor(yo + 0.5), iy2 = ifloor(yo);
@@ -468,8 +491,9 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
             int lz = t % R3ZS, ly = (t / R3ZS) % R3Y, lx = t / (R3ZS * R3Y);
             if (lz >= R3Z) continue;   // stride padding
-            long gi = ((long)torus(r0[0] + lx + g.ng, g.NX) * g.NY + torus(r0[1] + ly + g.ng, g.NY)) * g.NZ +
-                      torus(r0[2] + lz + g.ng, g.NZ);
+            long gi = ((long)node_index(r0[0] + lx, g.nx, g.ng, g.NX, k.wrap & 1) * g.NY +
+                       node_index(r0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
+                      node_index(r0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 double v = s_j[c][t];
