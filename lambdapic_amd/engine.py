@@ -620,6 +620,18 @@ class PicEngine2D:
         sp.n += k
         sp.steps_since_sort = 1 << 30
 
+    def append_particles_device(self, ispec, dev):
+        """``dev``: dict of device tensors (x y ux uy uz inv_gamma w id) -> loose particles + forced re-sort"""
+        sp = self.species[ispec]
+        k = int(dev["x"].numel())
+        if k == 0:
+            return
+        rows = torch.zeros((len(sp.cset.names), k), dtype=torch.float64, device=self.device)
+        for i, a in enumerate(sp.cset.names):
+            if a in dev:
+                rows[i] = dev[a]
+        self._append_device(sp, rows, dev["id"])
+
     def append_particles(self, ispec, host):
         """append host particles (dict of arrays: x y ux uy uz inv_gamma w [_id]) behind the stored
         ones as loose particles and force a re-sort"""

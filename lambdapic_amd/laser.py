@@ -10,10 +10,26 @@ trigger the host-mirror refresh that ordinary callbacks get.
 from __future__ import annotations
 
 import numpy as np
+import torch
 
 from . import constants
 
 C = constants.C_LIGHT
+
+
+def _xp(a):
+    """numpy for host arrays (tests, golden rows), torch for device tensors: the callbacks evaluate the
+    source rows ON THE DEVICE -- a host array would cost a blocking host-to-device copy per step, which
+    serialises the host with everything queued on the GPU"""
+    return torch if isinstance(a, torch.Tensor) else np
+
+
+def _polyval(coeffs, x):
+    """Horner evaluation of a polynomial (highest power first) for numpy arrays or torch tensors"""
+    acc = x * 0 + float(coeffs[0])
+    for c in coeffs[1:]:
+        acc = acc * x + float(c)
+    return acc
 
 
 class _LaserBase:
@@ -62,9 +78,17 @@ class Laser2D:
         if eng.bc["xmin"] != "pml" or (eng.comm.rank == 0 and (eng.pml is None or "xmin" not in eng.pml.sides)):
             self.disabled = True
             return
-        ey, ez = self.source_fields(sim, self.boundary_y(sim))
+        ey, ez = self.source_fields(sim, self.boundary_y_device(sim))
         if ey is not None:
             eng.laser_inject(ey, ez, sim.dt)
+
+    def boundary_y_device(self, sim):
+        key = (id(sim.engine), sim.Ly)
+        if getattr(self, "_ydev_key", None) != key:
+            y = self.boundary_y(sim)
+            self._ydev = None if y is None else torch.from_numpy(np.ascontiguousarray(y)).to(sim.engine.device)
+            self._ydev_key = key
+        return self._ydev
 
     def __add__(self, other):
         if not isinstance(other, Laser2D):
@@ -76,11 +100,12 @@ class Laser2D:
 
 def _polarise(amp, phase, pol_angle, ellipticity):
     """major/minor axis decomposition shared by both profiles (`callback/laser.py:372-383`)"""
-    norm = np.sqrt(1 + ellipticity ** 2)
+    xp = _xp(phase)
+    norm = float(np.sqrt(1 + ellipticity ** 2))
     major, minor = 1.0 / norm, ellipticity / norm
-    cp, sp = np.cos(pol_angle), np.sin(pol_angle)
-    return (amp * (major * cp * np.sin(phase) - minor * sp * np.cos(phase)),
-            amp * (major * sp * np.sin(phase) + minor * cp * np.cos(phase)))
+    cp, sp = float(np.cos(pol_angle)), float(np.sin(pol_angle))
+    return (amp * (major * cp * xp.sin(phase) - minor * sp * xp.cos(phase)),
+            amp * (major * sp * xp.sin(phase) + minor * cp * xp.cos(phase)))
 
 
 class CombinedLaser2D(Laser2D):
@@ -94,9 +119,13 @@ class CombinedLaser2D(Laser2D):
     def boundary_y(self, sim):
         return None
 
+    def boundary_y_device(self, sim):
+        return None
+
     def source_fields(self, sim, y):
-        a = self.laser1.source_fields(sim, self.laser1.boundary_y(sim))
-        b = self.laser2.source_fields(sim, self.laser2.boundary_y(sim))
+        dev = hasattr(sim, "engine")
+        a = self.laser1.source_fields(sim, self.laser1.boundary_y_device(sim) if dev else self.laser1.boundary_y(sim))
+        b = self.laser2.source_fields(sim, self.laser2.boundary_y_device(sim) if dev else self.laser2.boundary_y(sim))
         if a[0] is None:
             return b
         if b[0] is None:
@@ -128,14 +157,15 @@ class SimpleLaser2D(Laser2D):
         time = sim.time
         if C * time >= self.tstop:
             return None, None
-        r_rot = np.sqrt((y / np.cos(self.angle_y)) ** 2)
-        transverse_phase = -(self.ky * y)
-        t_rot = C * time - y * np.sin(self.angle_y)
-        tprof = np.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
-        amp = self.E0 * np.exp(-r_rot ** 2 / self.w0 ** 2) * tprof
-        phase = self.omega0 * time + self.cep + transverse_phase
+        xp = _xp(y)
+        r_rot = xp.sqrt((y / float(np.cos(self.angle_y))) ** 2)
+        transverse_phase = -(float(self.ky) * y)
+        t_rot = C * time - y * float(np.sin(self.angle_y))
+        tprof = xp.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
+        amp = float(self.E0) * xp.exp(-r_rot ** 2 / float(self.w0 ** 2)) * tprof
+        phase = float(self.omega0 * time + self.cep) + transverse_phase
         ey, ez = _polarise(amp, phase, self.pol_angle, self.ellipticity)
-        return ey * np.cos(self.angle_y), ez
+        return ey * float(np.cos(self.angle_y)), ez
 
 
 class GaussianLaser2D(Laser2D):
@@ -182,20 +212,21 @@ class GaussianLaser2D(Laser2D):
         time = sim.time
         if C * time >= self.tstop:
             return None, None
-        tprof = np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2)
+        tprof = float(np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2))
         x_rel = sim.cpml_thickness * sim.dx
         w, R, psi = self.beam_params(x_rel)
-        r = np.abs(y)
+        xp = _xp(y)
+        r = xp.abs(y)
         if self._is_lg:
-            phi = np.arctan2(0.0, y)             # 2-D: the azimuth is 0 or pi
-            u = np.sqrt(2) * r / w
-            amp_lg = self.lg_norm * u ** abs(self.l) * self.laguerre(u ** 2)
+            phi = xp.arctan2(y * 0, y)           # 2-D: the azimuth is 0 or pi
+            u = float(np.sqrt(2)) * r / float(w)
+            amp_lg = float(self.lg_norm) * u ** abs(self.l) * _polyval(self.laguerre.coeffs, u ** 2)
             phase_lg = self.l * phi
         else:
             amp_lg, phase_lg = 1.0, 0.0
-        amp = self.E0 * (self.w0 / w) * np.exp(-r ** 2 / w ** 2) * amp_lg * tprof
-        phase = (self.omega0 * time + self.cep - self.k0 * x_rel - self.k0 * r ** 2 / (2 * R)
-                 - (2 * self.p + abs(self.l) + 1) * psi - phase_lg)
+        amp = float(self.E0 * (self.w0 / w)) * xp.exp(-r ** 2 / float(w ** 2)) * amp_lg * tprof
+        phase = (float(self.omega0 * time + self.cep - self.k0 * x_rel - (2 * self.p + abs(self.l) + 1) * psi)
+                 - float(self.k0 / (2 * R)) * r ** 2 - phase_lg)
         return _polarise(amp, phase, self.pol_angle, self.ellipticity)
 
 
@@ -225,7 +256,11 @@ class Laser3D(_LaserBase):
         if eng.bc["xmin"] != "pml" or (eng.comm.rank == 0 and (eng.pml is None or "xmin" not in eng.pml.sides)):
             self.disabled = True
             return
-        ey, ez = self.source_fields(sim, *self.boundary_yz(sim))
+        key = (id(eng), sim.Ly, sim.Lz)
+        if getattr(self, "_yz_key", None) != key:      # boundary coordinates live on the device
+            self._yz = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(eng.device) for a in self.boundary_yz(sim))
+            self._yz_key = key
+        ey, ez = self.source_fields(sim, *self._yz)
         if ey is not None:
             eng.laser_inject(ey, ez, sim.dt)
 
@@ -245,14 +280,15 @@ class SimpleLaser3D(Laser3D):
         time = sim.time
         if C * time >= self.tstop:
             return None, None
-        r_rot = np.sqrt((y / np.cos(self.angle_y)) ** 2 + z ** 2)
-        transverse_phase = -(self.ky * y)
-        t_rot = C * time - y * np.sin(self.angle_y)
-        tprof = np.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
-        amp = self.E0 * np.exp(-r_rot ** 2 / self.w0 ** 2) * tprof
-        phase = self.omega0 * time + self.cep + transverse_phase
+        xp = _xp(y)
+        r_rot = xp.sqrt((y / float(np.cos(self.angle_y))) ** 2 + z ** 2)
+        transverse_phase = -(float(self.ky) * y)
+        t_rot = C * time - y * float(np.sin(self.angle_y))
+        tprof = xp.sin(t_rot / (2 * self.ctau) * np.pi) ** 2 * (t_rot < 2 * self.ctau)
+        amp = float(self.E0) * xp.exp(-r_rot ** 2 / float(self.w0 ** 2)) * tprof
+        phase = float(self.omega0 * time + self.cep) + transverse_phase
         ey, ez = _polarise(amp, phase, self.pol_angle, self.ellipticity)
-        return ey * np.cos(self.angle_y), ez
+        return ey * float(np.cos(self.angle_y)), ez
 
 
 class GaussianLaser3D(Laser3D):
@@ -271,17 +307,18 @@ class GaussianLaser3D(Laser3D):
         time = sim.time
         if C * time >= self.tstop:
             return None, None
-        tprof = np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2)
+        tprof = float(np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2))
         x_rel = sim.cpml_thickness * sim.dx
         w, R, psi = self.beam_params(x_rel)
+        xp = _xp(y)
         if self._is_lg:
-            phi = np.arctan2(z, y)
-            u = np.sqrt(2) * r / w
-            amp_lg = self.lg_norm * u ** abs(self.l) * self.laguerre(u ** 2)
+            phi = xp.arctan2(z, y)
+            u = float(np.sqrt(2)) * r / float(w)
+            amp_lg = float(self.lg_norm) * u ** abs(self.l) * _polyval(self.laguerre.coeffs, u ** 2)
             phase_lg = self.l * phi
         else:
             amp_lg, phase_lg = 1.0, 0.0
-        amp = self.E0 * (self.w0 / w) * np.exp(-r ** 2 / w ** 2) * amp_lg * tprof
-        phase = (self.omega0 * time + self.cep - self.k0 * x_rel - self.k0 * r ** 2 / (2 * R)
-                 - (2 * self.p + abs(self.l) + 1) * psi - phase_lg)
+        amp = float(self.E0 * (self.w0 / w)) * xp.exp(-r ** 2 / float(w ** 2)) * amp_lg * tprof
+        phase = (float(self.omega0 * time + self.cep - self.k0 * x_rel - (2 * self.p + abs(self.l) + 1) * psi)
+                 - float(self.k0 / (2 * R)) * r ** 2 - phase_lg)
         return _polarise(amp, phase, self.pol_angle, self.ellipticity)

@@ -24,6 +24,7 @@ import time as _time
 from dataclasses import dataclass, field
 
 import numpy as np
+import torch
 
 from . import constants
 from .dist import SlabComm
@@ -49,6 +50,47 @@ class Species:
     @property
     def m(self):
         return self.mass * constants.M_E
+
+
+def load_block_device(species, origin, n, d, seed, device, id_prefix=0):
+    """Uniform loading of one block of cells ON THE DEVICE: ``ppc`` particles in every cell whose density is
+    > 0, positions uniform inside the cell, weight ``n d^dim / ppc``, thermal momenta N(0, sigma)
+    (`core/patch/cpu.py:21-75`).  The density callable is user code written for numpy: it is evaluated on
+    the host on the CELL grid (small), everything per particle happens on the device (the reference loads on
+    the host; at 16 ppc a recycled window column is 5 x 10^5 particles, ~0.1 s of numpy per shift).
+    Returns a dict of device tensors x, y(, z), ux, uy, uz, inv_gamma, w, id (may be empty: None).
+    The generator is seeded from ``seed`` (a list of ints): the loading of a block is a function of its
+    origin, not of the decomposition or of the moment it enters a moving window."""
+    dim = len(n)
+    if not species.ppc or species.density is None:
+        return None
+    axes = [o + np.arange(m) * dd for o, m, dd in zip(origin, n, d)]
+    grids = np.meshgrid(*axes, indexing="ij")
+    dens = species.density(*grids) if callable(species.density) else np.full(grids[0].shape, float(species.density))
+    sel = np.nonzero(np.ravel(dens) > 0)[0]
+    if sel.size == 0:
+        return None
+    ppc = int(species.ppc)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(np.random.SeedSequence([int(v) & 0xFFFFFFFF for v in seed]).generate_state(1, np.uint64)[0] >> 1)
+                    if seed is not None else torch.seed())
+    out = {}
+    k = sel.size * ppc
+    for a, g_, dd in zip("xyz", grids, d):
+        c = torch.from_numpy(np.ascontiguousarray(np.ravel(g_)[sel])).to(device).repeat_interleave(ppc)
+        out[a] = c + (torch.rand(k, dtype=torch.float64, device=device, generator=gen) - 0.5) * dd
+    vol = float(np.prod(d))
+    out["w"] = torch.from_numpy(np.ascontiguousarray(np.ravel(dens)[sel] * vol / ppc)).to(device).repeat_interleave(ppc)
+    if species.momentum_sigma:
+        for a in ("ux", "uy", "uz"):
+            out[a] = torch.randn(k, dtype=torch.float64, device=device, generator=gen) * float(species.momentum_sigma)
+        out["inv_gamma"] = 1.0 / torch.sqrt(1 + out["ux"] ** 2 + out["uy"] ** 2 + out["uz"] ** 2)
+    else:
+        for a in ("ux", "uy", "uz"):
+            out[a] = torch.zeros(k, dtype=torch.float64, device=device)
+        out["inv_gamma"] = torch.ones(k, dtype=torch.float64, device=device)
+    out["id"] = torch.arange(k, dtype=torch.int64, device=device) + int(id_prefix)
+    return out
 
 
 def callback(stage="end", interval=1):
@@ -266,17 +308,28 @@ class Simulation:
         mirrors.xmin_global, mirrors.xmax_global = -self.dx / 2, self.Lx - self.dx / 2
         self.patches = DevicePatches(self, mirrors)
         for s in self.species:
-            n_tot = 0
+            blocks = []
             for p in mirrors:
-                q = p.particles[s.ispec]
                 # one generator per (species, patch origin): the same particles whatever the number
                 # of ranks (the reference spawns one generator per rank, simulation.py:700-716, so ITS
                 # loading depends on the decomposition; identical physics, different noise)
-                seed = None if self.random_seed is None else \
-                    [self.random_seed, s.ispec, int(round(p.x0 / self.dx)), int(round(p.y0 / self.dy))]
-                n_tot += self._fill(p, q, s, np.random.default_rng(seed))
+                b = load_block_device(s, (p.x0, p.y0), (p.nx, p.ny), (self.dx, self.dy), self._seed(s, p.x0, p.y0),
+                                      self.device, id_prefix=(self.comm.rank << 50) | (p.index << 32))
+                if b is not None:
+                    blocks.append(b)
+                p.particles[s.ispec].initialize(0)     # the mirrors fill at the first download()
+            n_tot = sum(b["x"].numel() for b in blocks)
             self.engine.add_species(s.q, s.m, capacity=int(n_tot * self.capacity_factor) + 65536, with_eb=True)
-            self.engine.species[s.ispec].upload([p.particles[s.ispec] for p in mirrors])
+            sp = self.engine.species[s.ispec]
+            o = 0
+            for b in blocks:
+                k = b["x"].numel()
+                for a in sp.cset.names:
+                    if a in b:
+                        sp.cset.arr(a)[o:o + k] = b[a]
+                sp.cset.id[o:o + k] = b["id"]
+                o += k
+            sp.n, sp.n_sorted, sp.tiling = n_tot, 0, None
         self.maxwell = MaxwellSolver2D(self)
         self.interpolator = FieldInterpolation2D(self)
         self.current_depositor = CurrentDeposition2D(self)
@@ -284,28 +337,9 @@ class Simulation:
         self.sorter = [ParticleSort2D(self, i) for i in range(len(self.species))]
         self.initialized = True
 
-    @staticmethod
-    def _fill(p, q, s, rng):
-        """uniform loading, ppc per cell with density > 0 (`core/patch/cpu.py:21-44`)"""
-        if not s.ppc or s.density is None:
-            q.initialize(0)
-            return 0
-        xs = p.x0 + np.arange(p.nx) * p.dx
-        ys = p.y0 + np.arange(p.ny) * p.dy
-        X, Y = np.meshgrid(xs, ys, indexing="ij")
-        dens = s.density(X, Y) if callable(s.density) else np.full(X.shape, float(s.density))
-        sel = np.nonzero(dens.ravel() > 0)[0]
-        n = sel.size * s.ppc
-        q.initialize(n)
-        cx, cy, d = np.repeat(X.ravel()[sel], s.ppc), np.repeat(Y.ravel()[sel], s.ppc), np.repeat(dens.ravel()[sel], s.ppc)
-        q.x[:] = cx + rng.uniform(-0.5, 0.5, n) * p.dx
-        q.y[:] = cy + rng.uniform(-0.5, 0.5, n) * p.dy
-        q.w[:] = d * p.dx * p.dy / s.ppc
-        if s.momentum_sigma:
-            for a in ("ux", "uy", "uz"):
-                getattr(q, a)[:] = rng.normal(0.0, s.momentum_sigma, n)
-            q.inv_gamma[:] = 1.0 / np.sqrt(1 + q.ux ** 2 + q.uy ** 2 + q.uz ** 2)
-        return n
+    def _seed(self, s, x0, y0):
+        return None if self.random_seed is None else \
+            [self.random_seed, s.ispec, int(round(x0 / self.dx)), int(round(y0 / self.dy))]
 
     def shift_window_right(self, inject):
         """recycle the leftmost patch column (`callback/utils.py:594-620`) on the device slab"""
@@ -321,21 +355,17 @@ class Simulation:
         self.patches._m.xmax_global += n * self.dx
         if not inject or self.comm.rank != self.comm.size - 1:
             return                      # only the last slab's tail is new ground
-        from .patch import Patch2D
-        from .particles import ParticlesBase
         x_new = eng.x0 + (eng.nx - n) * self.dx
         for s in self.species:
             for j in range(self.npatch_y):
-                tmp = Patch2D(0, 0, 0, j, x_new, j * self.ny_per_patch * self.dy, n, self.ny_per_patch,
-                              self.dx, self.dy)
-                q = ParticlesBase(ipatch=j, rank=self.comm.rank)
                 # same seed rule as initialize(): the loading of a column is a function of its origin,
                 # so a moving window reproduces what a long static box would have held there
-                seed = None if self.random_seed is None else \
-                    [self.random_seed, s.ispec, int(round(tmp.x0 / self.dx)), int(round(tmp.y0 / self.dy))]
-                if self._fill(tmp, q, s, np.random.default_rng(seed)):
-                    eng.append_particles(s.ispec, {a: getattr(q, a) for a in
-                                                   ("x", "y", "ux", "uy", "uz", "inv_gamma", "w", "_id")})
+                y0 = j * self.ny_per_patch * self.dy
+                b = load_block_device(s, (x_new, y0), (n, self.ny_per_patch), (self.dx, self.dy),
+                                      self._seed(s, x_new, y0), self.device,
+                                      id_prefix=(self.comm.rank << 50) | ((1 << 17) + j << 32) | (self.window_shifts << 20))
+                if b is not None:
+                    eng.append_particles_device(s.ispec, b)
 
     # ---- host mirrors <-> device --------------------------------------------------------------------
     def download(self):

@@ -17,7 +17,7 @@ from .dist import SlabComm
 from .engine3d import ATTRS3, SIDES3, PicEngine3D
 from .fields import FIELD_ATTRS, Fields3D, from_device_layout, to_device_layout
 from .particles import ParticlesBase
-from .simulation import Species, _Facade, callback  # noqa: F401  (same Species / decorator as 2-D)
+from .simulation import Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
 
 
 class Patch3D:
@@ -149,42 +149,32 @@ class Simulation3D:
                     idx += 1
         self.patches = DevicePatches3D(self, mirrors)
         for s in self.species:
-            n_tot = 0
+            blocks = []
             for p in mirrors:
-                seed = None if self.random_seed is None else \
-                    [self.random_seed, s.ispec] + [int(round(o / dd)) for o, dd in zip((p.x0, p.y0, p.z0), d)]
-                n_tot += self._fill(p, p.particles[s.ispec], s, np.random.default_rng(seed))
+                org = (p.x0, p.y0, p.z0)
+                b = load_block_device(s, org, npp, d, self._seed(s, org), self.device,
+                                      id_prefix=(self.comm.rank << 50) | (p.index << 32))
+                if b is not None:
+                    blocks.append(b)
+                p.particles[s.ispec].initialize(0)     # the mirrors fill at the first download()
+            n_tot = sum(b["x"].numel() for b in blocks)
             cap = int(n_tot * self.capacity_factor) + 65536 + self.engine.arrival_area()
             data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device=self.device)
-            self.engine.add_species_device(s.q, s.m, data, 0)
-            self._upload_particles(s.ispec)
+            o = 0
+            for b in blocks:
+                k = b["x"].numel()
+                for i, a in enumerate(ATTRS3):
+                    data[i, o:o + k] = b[a]
+                o += k
+            self.engine.add_species_device(s.q, s.m, data, n_tot)
         self.maxwell = MaxwellSolver3D(self)
         self.pusher = [BorisPusher3D(self, i) for i in range(len(self.species))]
         self.sorter = [ParticleSort3D(self, i) for i in range(len(self.species))]
         self.initialized = True
 
-    @staticmethod
-    def _fill(p, q, s, rng):
-        """uniform loading, ppc per cell with density > 0 (`core/patch/cpu.py:47-75`)"""
-        if not s.ppc or s.density is None:
-            q.initialize(0)
-            return 0
-        ax = [o + np.arange(n) * d for o, n, d in zip((p.x0, p.y0, p.z0), (p.nx, p.ny, p.nz), (p.dx, p.dy, p.dz))]
-        X, Y, Z = np.meshgrid(*ax, indexing="ij")
-        dens = s.density(X, Y, Z) if callable(s.density) else np.full(X.shape, float(s.density))
-        sel = np.nonzero(dens.ravel() > 0)[0]
-        n = sel.size * s.ppc
-        q.initialize(n)
-        rep = lambda a: np.repeat(a.ravel()[sel], s.ppc)
-        q.x[:] = rep(X) + rng.uniform(-0.5, 0.5, n) * p.dx
-        q.y[:] = rep(Y) + rng.uniform(-0.5, 0.5, n) * p.dy
-        q.z[:] = rep(Z) + rng.uniform(-0.5, 0.5, n) * p.dz
-        q.w[:] = rep(dens) * p.dx * p.dy * p.dz / s.ppc
-        if s.momentum_sigma:
-            for a in ("ux", "uy", "uz"):
-                getattr(q, a)[:] = rng.normal(0.0, s.momentum_sigma, n)
-            q.inv_gamma[:] = 1.0 / np.sqrt(1 + q.ux ** 2 + q.uy ** 2 + q.uz ** 2)
-        return n
+    def _seed(self, s, org):
+        return None if self.random_seed is None else \
+            [self.random_seed, s.ispec] + [int(round(o / dd)) for o, dd in zip(org, (self.dx, self.dy, self.dz))]
 
     @property
     def nx_per_patch(self):
@@ -216,13 +206,9 @@ class Simulation3D:
             for k in range(pz):
                 for j in range(py):
                     org = (x_new, j * npp[1] * self.dy, k * npp[2] * self.dz)
-                    tmp = Patch3D(0, (0, j, k), org, npp, d, self.n_guard, 0)
-                    q = ParticlesBase(ipatch=j + py * k, rank=self.comm.rank)
-                    seed = None if self.random_seed is None else \
-                        [self.random_seed, s.ispec] + [int(round(o / dd)) for o, dd in zip(org, d)]
-                    if self._fill(tmp, q, s, np.random.default_rng(seed)):
-                        rows = torch.from_numpy(np.stack([getattr(q, a) for a in ATTRS3])).to(self.device)
-                        eng.append_device(s.ispec, rows)
+                    b = load_block_device(s, org, npp, d, self._seed(s, org), self.device)
+                    if b is not None:
+                        eng.append_device(s.ispec, torch.stack([b[a] for a in ATTRS3]))
 
     # ---- host mirrors <-> device ----------------------------------------------------------------------------
     def _upload_particles(self, ispec):

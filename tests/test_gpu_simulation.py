@@ -90,6 +90,7 @@ def test_interpolator_callback_external_field_vs_oracle():
     exactly as in the CPU restatement of that path"""
     sim, nc = _sim(nx=32, ny=32, npx=2, npy=1, ppc=8, seed=11, sort_interval=4)
     sim.initialize()
+    sim.download()          # particles are loaded on the device; the mirrors fill on download
     # same initial particles for the oracle
     P = make_patches_2d(32, 32, sim.dx, sim.dy, 2, 1)
     for p, m in zip(P, sim.patches):
