@@ -263,6 +263,12 @@ int lpa_interpolate_2d(const lpa_grid *g, const lpa_particles *p, void *stream);
 int lpa_boris(const lpa_particles *p, double dt, double q, double m, void *stream);
 int lpa_push_position_2d(const lpa_particles *p, double dt, void *stream);
 int lpa_deposit_2d(const lpa_grid *g, const lpa_particles *p, double dt, double q, void *stream);
+/* 3-D standalone twins: interpolation_patches_3d (core/interpolation/cpu3d.c:99-169) and
+ * current_deposition_cpu_3d (core/current/cpu3d.c:118-183).  There is no lpa_push_position_3d: the
+ * reference's PusherBase.push_position (core/pusher/pusher.py:103-110) moves particles in 2-D only,
+ * so it has no working 3-D split step to mirror. */
+int lpa_interpolate_3d(const lpa_grid *g, const lpa_particles *p, void *stream);
+int lpa_deposit_3d(const lpa_grid *g, const lpa_particles *p, double dt, double q, void *stream);
 /* periodic fold of the positions into the global box (pp->wrap, lo, hi): what Patches.sync_particles
  * does for a patch that is its own neighbour (core/patch/sync_particles_2d.c:168-182); the fused
  * kernels apply it themselves, the split path calls this after the deposit */

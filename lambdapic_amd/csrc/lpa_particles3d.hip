@@ -538,6 +538,47 @@ extern "C" int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *
     return LPA_OK;
 }
 
+// ---- standalone 3-D kernels (the reference's non-unified twins: interpolation/cpu3d.c:99-169,
+//      current/cpu3d.c:118-183).  The reference has no 3-D push_position (PusherBase.push_position,
+//      core/pusher/pusher.py:103-110, moves particles in 2-D only), so there is no 3-D split step.
+__global__ void __launch_bounds__(256) k_interpolate_3d(GridV g, PartV p) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;  // interpolation/cpu3d.c skips is_dead only
+    double eb[6];
+    gather_global_3d(g, (p.x[ip] - g.x0) / g.dx, (p.y[ip] - g.y0) / g.dy, (p.z[ip] - g.z0) / g.dz, eb);
+#pragma unroll
+    for (int c = 0; c < 6; c++) p.eb[c][ip] = eb[c];
+}
+
+__global__ void __launch_bounds__(256) k_deposit_3d(GridV g, PartV p, double dt, double q) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    double x = p.x[ip], y = p.y[ip], z = p.z[ip];
+    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y) || isnan(z)) return;
+    deposit_global_3d(g, x, y, z, p.ux[ip], p.uy[ip], p.uz[ip], p.ig[ip], p.w[ip], q, dt);
+}
+
+extern "C" int lpa_interpolate_3d(const lpa_grid *g, const lpa_particles *p, void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && lpa_part_ok(p, 3) && (p->n == 0 || p->part_eb[0]),
+                "lpa_interpolate_3d: bad args (part_eb required)");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_interpolate_3d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_gridv(g, 3), make_partv(p));
+    LPA_CHECK_LAUNCH("lpa_interpolate_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_deposit_3d(const lpa_grid *g, const lpa_particles *p, double dt, double q,
+                              void *stream) {
+    LPA_REQUIRE(lpa_grid_ok(g, 3, 1) && lpa_part_ok(p, 3) && dt > 0, "lpa_deposit_3d: bad args");
+    if (p->n == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_deposit_3d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_gridv(g, 3), make_partv(p), dt, q);
+    LPA_CHECK_LAUNCH("lpa_deposit_3d");
+    return LPA_OK;
+}
+
 extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles *p,
                                          const lpa_push_params *pp, const lpa_tiling *t,
                                          uint32_t *overflow, uint32_t *overflow_count, void *stream) {

@@ -203,6 +203,24 @@ def current_deposition_cpu_2d(fields_list, particles_list, npatches, dt, q):
         g.download(["rho", "jx", "jy", "jz"])
 
 
+def interpolation_patches_3d(particles_list, fields_list, npatches):
+    """GPU drop-in for `core/interpolation/cpu3d.c:99-169`"""
+    L, dev = lib(), _device()
+    for p, f in zip(particles_list[:npatches], fields_list[:npatches]):
+        g, d = _GridOnDevice(f, dev), _PartsOnDevice(p, dev, dim=3)
+        check(L.lpa_interpolate_3d(g.ref(), d.ref(), _stream(dev)), "lpa_interpolate_3d")
+        d.download(list(PART_EB))
+
+
+def current_deposition_cpu_3d(fields_list, particles_list, npatches, dt, q):
+    """GPU drop-in for `core/current/cpu3d.c:118-183` (standalone deposit, accumulates into J/rho)"""
+    L, dev = lib(), _device()
+    for p, f in zip(particles_list[:npatches], fields_list[:npatches]):
+        g, d = _GridOnDevice(f, dev), _PartsOnDevice(p, dev, dim=3, with_eb=False)
+        check(L.lpa_deposit_3d(g.ref(), d.ref(), dt, q, _stream(dev)), "lpa_deposit_3d")
+        g.download(["rho", "jx", "jy", "jz"])
+
+
 def reset_current_cpu_2d(fields_list, npatches):
     """GPU drop-in for `core/current/cpu2d.c:19-72`"""
     L, dev = lib(), _device()

@@ -302,7 +302,11 @@ class Simulation3D:
             if st not in self.STAGES:
                 raise ValueError(f"unknown stage {st!r}")
             if st in self._PUSHER_STAGES:
-                raise NotImplementedError(f"3-D: no split pusher kernels, callback stage {st!r} is not available")
+                # the reference cannot take this path either: PusherBase.push_position
+                # (core/pusher/pusher.py:103-110) moves particles in 2-D only, so a 3-D run with a
+                # callback in a pusher stage would silently stop advancing positions
+                raise NotImplementedError(f"3-D: the reference has no split 3-D position push; "
+                                          f"callback stage {st!r} is not available")
         if nsteps is None:
             nsteps = int(sim_time / self.dt) if sim_time is not None else \
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))

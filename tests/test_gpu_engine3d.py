@@ -176,3 +176,55 @@ def test_3d_laser_crosses_vacuum_box_and_is_absorbed():
             peak = eng.view("ey").abs().max().item()
     assert peak == pytest.approx(E0, rel=0.12)          # coarse grid (lambda / 12, lambda / 6)
     assert hist[-1] < 5e-2 * max(hist)
+
+
+def test_3d_tiled_equals_global_and_continuity_at_c5_slab_size():
+    """size-independent properties at one GPU's share of config C5 (64x256x256 cells; 4 ppc here to
+    bound the time of the global-atomics comparison run): the LDS-tiled kernel and the global-memory
+    kernel agree; the deposited charge is N q w; the discrete continuity equation of the 3-D
+    Esirkepov deposit (`current_deposit.h:275-440`) holds to round-off on every node."""
+    import torch
+    nx, ny, nz, ppc = 64, 256, 256, 4
+    lam = 0.8e-6
+    dx, dy, dz = lam / 20, lam / 10, lam / 10
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
+    n = nx * ny * nz * ppc
+    q, m = -oracle.E_CHARGE, oracle.M_E
+    w = 1.742e27 * dx * dy * dz / ppc
+
+    def make(tiled):
+        eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=tiled, sort_interval=3)
+        dev = eng.device
+        g = torch.Generator(device=dev).manual_seed(5)
+        cell = torch.arange(n, device=dev) // ppc
+        r = lambda: torch.rand(n, device=dev, dtype=torch.float64, generator=g)
+        data = torch.empty((8, n), dtype=torch.float64, device=dev)
+        data[0] = ((cell // (ny * nz)).double() + r() - 0.5) * dx
+        data[1] = (((cell // nz) % ny).double() + r() - 0.5) * dy
+        data[2] = ((cell % nz).double() + r() - 0.5) * dz
+        for k in (3, 4, 5):
+            data[k] = torch.randn(n, device=dev, dtype=torch.float64, generator=g) * 0.1
+        data[6] = 1.0 / torch.sqrt(1 + data[3] ** 2 + data[4] ** 2 + data[5] ** 2)
+        data[7] = w
+        eng.add_species_device(q, m, data, n)
+        for _ in range(5):
+            eng.step(dt)
+        return eng
+
+    a, b = make(True), make(False)
+    da, db = a.diagnostics(), b.diagnostics()
+    assert da["nalive"][0] == n == db["nalive"][0]
+    assert da["charge"] == pytest.approx(n * q * w, rel=1e-12)
+    assert da["field_energy"] == pytest.approx(db["field_energy"], rel=1e-10)
+    assert da["kinetic"][0] == pytest.approx(db["kinetic"][0], rel=1e-12)
+    for name in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+        va, vb = a.view(name), b.view(name)
+        assert (va - vb).abs().max().item() <= 1e-9 * vb.abs().max().item(), name
+    del b
+    s = (slice(3, 3 + nx), slice(3, 3 + ny), slice(3, 3 + nz))
+    rho_prev = a.view("rho")[s].clone()
+    a.step(dt)
+    rho, jx, jy, jz = (a.view(c)[s] for c in ("rho", "jx", "jy", "jz"))
+    res = ((rho - rho_prev) / dt + (jx - torch.roll(jx, 1, 0)) / dx + (jy - torch.roll(jy, 1, 1)) / dy
+           + (jz - torch.roll(jz, 1, 2)) / dz)
+    assert res.abs().max().item() <= 1e-10 * rho.abs().max().item() / dt

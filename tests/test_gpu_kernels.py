@@ -76,6 +76,19 @@ def test_standalone_deposit_and_interpolation_vs_golden(golden):
     kernels.interpolation_patches_2d([p], [f], 1)
     for a in PEB:
         assert_close(getattr(p, a)[~p.is_dead], g[f"out_{a}"][~p.is_dead], 1e-11, what=a)
+    # the 3-D standalone twins (core/current/cpu3d.c:118-183, core/interpolation/cpu3d.c:99-169)
+    g = golden("g3_deposit_3d")
+    f = fields3d_from(g, "none_")
+    p = particles_from(g, "in_")
+    kernels.current_deposition_cpu_3d([f], [p], 1, float(g["dt"]), float(g["q"]))
+    for a in ["rho", "jx", "jy", "jz"]:
+        assert_close(getattr(f, a), g[f"out_{a}"], 1e-12, what=a)
+    g = golden("g4_interp_3d")
+    f = fields3d_from(g, "in_")
+    p = particles_from(g, "in_", ["x", "y", "z"])
+    kernels.interpolation_patches_3d([p], [f], 1)
+    for a in PEB:
+        assert_close(getattr(p, a)[~p.is_dead], g[f"out_{a}"][~p.is_dead], 1e-11, what=a)
 
 
 def test_fdtd_vs_golden(golden):
