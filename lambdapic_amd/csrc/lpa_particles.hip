@@ -163,13 +163,21 @@ constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;  // 8 x 32 cells
 constexpr int HALO = LPA_TILE_MARGIN + 3;  // margin + (1 cell of motion + 2 cells of stencil), see DESIGN.md
 constexpr int RWX = TX + 2 * HALO;         // 16: staged region, nodes along x
 constexpr int RWY = TY + 2 * HALO;         // 40: staged region, nodes along y
-// LDS image of E/B: one row of RS doubles per x-node holding the six components back to back
-// (component c at c * CS).  RS is a multiple of 32 doubles, so the bank pair of a node depends on its
-// column only: the 32 lanes of a half-wave (32 different y-cells, but two or three different x-rows
-// because the nearest node depends on the sub-cell position) never collide.  With one padded array per
-// component (stride 41) 30 % of the LDS cycles of this kernel were bank conflicts of the gather.
-constexpr int CS = RWY;                    // 40
-constexpr int RS = 256;                    // 6 * 40 = 240, padded to 8 * 32
+// LDS image of E/B: one row of RS doubles per x-node.  ey and bx are gathered with the same stencil
+// (gx, hy), ex and by with (hx, gy): each pair is stored interleaved, so one 16-byte ds_read_b128 serves
+// both -- measured (tools/ubench/lds_atomic.hip) a ds_read_b128 wave instruction costs 1.16 x a
+// ds_read_b64, i.e. 0.58 x per double; the address must be 16-byte aligned (8-byte aligned: 13 x slower).
+// Row = [ey bx] x CS | [ex by] x CS | ez x CS | bz x CS.  RS is a multiple of 32 doubles, so the bank of
+// a node depends on its column only: the 32 lanes of a half-wave (32 different y-cells, but two or
+// three different x-rows because the nearest node depends on the sub-cell position) never collide.
+// With one padded array per component (stride 41) 30 % of the LDS cycles of this kernel were bank
+// conflicts of the gather.
+constexpr int CS = RWY;                    // 42
+constexpr int RS = 256;                    // 6 * 42 = 252, padded to 8 * 32
+constexpr int EB_PAIR_A = 0;               // [ey, bx]
+constexpr int EB_PAIR_B = 2 * CS;          // [ex, by]
+constexpr int EB_EZ = 4 * CS, EB_BZ = 5 * CS;
+static_assert((EB_PAIR_B * 8) % 16 == 0 && (RS * 8) % 16 == 0 && 6 * CS <= RS, "E/B image layout");
 constexpr int RSZ = RWX * RS;              // 4096 doubles = 32 KiB
 // LDS row stride of the J/rho accumulators: a multiple of 32 doubles, so that consecutive y-cells map to
 // consecutive bank pairs ACROSS a row wrap too -- a half-wave whose lanes run from the end of one grid
@@ -195,6 +203,24 @@ __device__ __forceinline__ double gather9_l(const double *f, int lx, int ly, con
            fy[2] * (fx[0] * p0 + fx[1] * p1 + fx[2] * p2);
 }
 
+// the same stencil on an interleaved pair: nine ds_read_b128, two results
+typedef double lpa_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gather9_pair_l(const double *f, int lx, int ly, const double fx[3],
+                                               const double fy[3], double &r0, double &r1) {
+    typedef const volatile __attribute__((address_space(3))) lpa_d2 *lds_ptr2;
+    lds_ptr2 c = (lds_ptr2)(f + lx * RS + 2 * ly);
+    constexpr int R2 = RS / 2;
+    lpa_d2 m0 = c[-R2 - 1], m1 = c[-1], m2 = c[R2 - 1];
+    lpa_d2 z0 = c[-R2], z1 = c[0], z2 = c[R2];
+    lpa_d2 p0 = c[-R2 + 1], p1 = c[1], p2 = c[R2 + 1];
+    r0 = fy[0] * (fx[0] * m0.x + fx[1] * m1.x + fx[2] * m2.x) +
+         fy[1] * (fx[0] * z0.x + fx[1] * z1.x + fx[2] * z2.x) +
+         fy[2] * (fx[0] * p0.x + fx[1] * p1.x + fx[2] * p2.x);
+    r1 = fy[0] * (fx[0] * m0.y + fx[1] * m1.y + fx[2] * m2.y) +
+         fy[1] * (fx[0] * z0.y + fx[1] * z1.y + fx[2] * z2.y) +
+         fy[2] * (fx[0] * p0.y + fx[1] * p1.y + fx[2] * p2.y);
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // minimum number of lanes sharing one deposit window for the wave reduction to pay; smaller groups go
@@ -205,10 +231,14 @@ constexpr int WR_MAX_ROUNDS = 2;
 // Window row 3 / column 3 only receive something from a particle that changed cell during the step (a few
 // per cent of the lanes), yet a wave has to issue those 28 ds_add_f64 whenever ANY of its 64 lanes did.
 // With DEFER such lanes park their advanced state (7 doubles) in a scratch store (the idle half of the
-// ping-pong sort buffers), the main loop deposits the 3x3 core only, and the workgroup deposits the
-// parked particles' tail cells afterwards with every lane busy.
+// ping-pong sort buffers) and deposit nothing in the main loop, which then handles only particles that
+// stay in their cell: 3 x 3 window, old shape = the gather weights, no window re-basing.  The workgroup
+// deposits the parked particles afterwards on the general 4 x 4 window with every lane busy.
 struct Scratch7 { double *a[7]; };
 
+#ifndef LPA_SKIP_NULL_RUN
+#define LPA_SKIP_NULL_RUN 1
+#endif
 template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER>
 __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
@@ -218,7 +248,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                                               int tiles_y, uint32_t *overflow,
                                                               uint32_t *overflow_count, int part,
                                                               int tiles_x, int edge_cols, Scratch7 sc) {
-    __shared__ double s_eb[RSZ];
+    __shared__ __attribute__((aligned(16))) double s_eb[RSZ];
     __shared__ double s_j[4][RSZJ];
     __shared__ int s_ncross;
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), work blocks
@@ -254,8 +284,14 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             int cx = nxn + g.ng, cy = nyn + g.ng;
             bool in = (unsigned)cx < (unsigned)g.NX && (unsigned)cy < (unsigned)g.NY;
             long gi = (long)cx * g.NY + cy;
+            double v[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) s_eb[lx * RS + c * CS + ly] = in ? src[c][gi] : 0.0;
+            for (int c = 0; c < 6; c++) v[c] = in ? src[c][gi] : 0.0;
+            double *row = s_eb + lx * RS;
+            *(lpa_d2 *)(row + EB_PAIR_A + 2 * ly) = lpa_d2{v[1], v[3]};   // ey, bx
+            *(lpa_d2 *)(row + EB_PAIR_B + 2 * ly) = lpa_d2{v[0], v[4]};   // ex, by
+            row[EB_EZ + ly] = v[2];
+            row[EB_BZ + ly] = v[5];
 #pragma unroll
             for (int c = 0; c < 4; c++) s_j[c][lx * RSJ + ly] = 0.0;
         }
@@ -333,11 +369,13 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         AxisW ax, ay;
         double vz = 0.0;
         int b0 = 0;
+        bool cross = false;   // DEFER: changed cell during the step, deposited by the second pass
         if (valid) {
             double eb[6];
+            double gx[3], gy[3];
             {
                 int ix2 = ifloor(xo), iy2 = ifloor(yo);
-                double gx[3], hx[3], gy[3], hy[3];
+                double hx[3], hy[3];
                 tsc3(ix1 - xo, gx);
                 tsc3(ix2 - xo + 0.5, hx);
                 tsc3(iy1 - yo, gy);
@@ -349,12 +387,10 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                 eb[3] = gx[0] * hy[1] + ly1; eb[4] = hx[1] * gy[2]; eb[5] = hx[2] * hy[0];
                 abl += eb[0];
 #else
-                eb[0] = gather9_l(s_eb + 0 * CS, lx2, ly1, hx, gy);
-                eb[1] = gather9_l(s_eb + 1 * CS, lx1, ly2, gx, hy);
-                eb[2] = gather9_l(s_eb + 2 * CS, lx1, ly1, gx, gy);
-                eb[3] = gather9_l(s_eb + 3 * CS, lx1, ly2, gx, hy);
-                eb[4] = gather9_l(s_eb + 4 * CS, lx2, ly1, hx, gy);
-                eb[5] = gather9_l(s_eb + 5 * CS, lx2, ly2, hx, hy);
+                gather9_pair_l(s_eb + EB_PAIR_B, lx2, ly1, hx, gy, eb[0], eb[4]);   // ex, by
+                gather9_pair_l(s_eb + EB_PAIR_A, lx1, ly2, gx, hy, eb[1], eb[3]);   // ey, bx
+                eb[2] = gather9_l(s_eb + EB_EZ, lx1, ly1, gx, gy);
+                eb[5] = gather9_l(s_eb + EB_BZ, lx2, ly2, hx, hy);
 #endif
             }
             if (WRITE_EB) {
@@ -366,8 +402,32 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             y += k.cdt_half * ig * uy;
             double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig;
             vz = uz * LPA_C * ig;
-            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
-            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
+            if (DEFER) {
+                // The deposit runs from x - v dt/2 -- the mid-step position the fields were gathered at, up
+                // to rounding -- to x + v dt/2: the old shape S0 IS the node-centred gather weights (gx, gy)
+                // around (ix1, iy1).  A particle whose advanced position has the same nearest node needs
+                // only the new weights on the same three cells; the others (~6 %) are parked and get the
+                // general 4 x 4 window in the second pass.  (Taking the old cell from the gather position
+                // instead of re-deriving it moves a particle that sits within an ulp of a cell boundary to
+                // the neighbouring window, where the shape values agree to that ulp.)
+                const double d1x = ix1 - (x + vx * 0.5 * k.dt - g.x0) * inv_dx;
+                const double d1y = iy1 - (y + vy * 0.5 * k.dt - g.y0) * inv_dy;
+                cross = !(d1x > -0.5 && d1x <= 0.5 && d1y > -0.5 && d1y <= 0.5);
+                tsc3(d1x, ax.S1);
+                tsc3(d1y, ay.S1);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    ax.S0[c] = gx[c]; ay.S0[c] = gy[c];
+                    ax.DS[c] = ax.S1[c] - gx[c]; ay.DS[c] = ay.S1[c] - gy[c];
+                }
+                ax.S0[3] = ax.S1[3] = ax.DS[3] = 0.0;
+                ay.S0[3] = ay.S1[3] = ay.DS[3] = 0.0;
+                ax.base = ix1 - 1; ay.base = iy1 - 1;
+                ax.tail_zero = ay.tail_zero = true;
+            } else {
+                axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
+                axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
+            }
             int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
@@ -389,7 +449,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
             // ds_add_f64 below hits 32 different bank pairs.
             if (valid) {
-                if (DEFER && (!ax.tail_zero || !ay.tail_zero)) {
+                if (DEFER && cross) {
                     const int slot = atomicAdd(&s_ncross, 1);
                     const uint32_t o = (uint32_t)(begin + slot) * 8u;
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
@@ -406,13 +466,20 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                        // (one exec-mask region per run of cells) instead of testing 64
                                        // values -- crossers are ~3 % of the lanes
                                        bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
-                                       if (DEFER) on = kk < 3 && ll < 3;   // the tails come later
+                                       if (DEFER) on = kk < 3 && ll < 3 && !cross;   // cell-crossers come later
 #ifdef LPA_ABLATE_NO_TAIL  // diagnostic build: drop window row 3 / column 3 (wrong for cell crossers)
                                        on = kk < 3 && ll < 3;
 #endif
+                                       // the running sum of jx over the 3 window rows of a particle that
+                                       // stayed in its x-cell is (sum of DS) * b = 0 up to rounding (the
+                                       // reference adds that 1e-16-relative residue): row 2 of jx and column
+                                       // 2 of jy carry nothing unless the particle crossed along that axis,
+                                       // and the crossers' values go with their tails
+                                       bool on_x = on && (!LPA_SKIP_NULL_RUN || kk < 2 || (!DEFER && !ax.tail_zero));
+                                       bool on_y = on && (!LPA_SKIP_NULL_RUN || ll < 2 || (!DEFER && !ay.tail_zero));
+                                       if (on_x) atomicAdd(&s_j[0][o], djx);
+                                       if (on_y) atomicAdd(&s_j[1][o], djy);
                                        if (on) {
-                                           atomicAdd(&s_j[0][o], djx);
-                                           atomicAdd(&s_j[1][o], djy);
                                            atomicAdd(&s_j[2][o], djz);
                                            atomicAdd(&s_j[3][o], drho);
                                        }
@@ -471,8 +538,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         }
     }
     if (DEFER) {
-        // ---- tail cells of the particles that changed cell: same inputs, same code as in the loop above
-        // (axis_window / esirkepov_2d are deterministic), every lane busy
+        // ---- the particles that changed cell: the general 4 x 4 window, every lane busy
         __syncthreads();
         const int ncross = s_ncross;
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
@@ -487,7 +553,6 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             const int b0 = bx * RSJ + by;
             esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                [&](int kk, int ll, double djx, double djy, double djz, double drho) {
-                                   if (kk < 3 && ll < 3) return;
                                    bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
                                    if (on) {
                                        int oo = b0 + kk * RSJ + ll;

@@ -261,6 +261,9 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_3d(GridV g, PartV p, 
 // (Gathering E / B from global memory instead -- 162 cached 8-byte loads per particle -- was bound by
 // the address rate of the texture path: 11.8 ms per step on C5's slab against 13.2 ms total.)
 // =====================================================================================================
+#ifndef LPA_SKIP_NULL_RUN
+#define LPA_SKIP_NULL_RUN 1
+#endif
 constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
 constexpr int H3 = LPA_TILE3_MARGIN + 2;
 constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10 x 10 x 22
@@ -465,7 +468,12 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         esirkepov_3d_lean(
             ax, ay, az, w, k.q, g.dx, g.dy, g.dz, k.dt,
             [&](int i, int j, int kk, double djx) {
-                bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
+                // a running sum over the 3 window planes of a particle that stayed in its cell along
+                // that axis ends at (sum of DS) * (...) = 0 up to rounding (the reference adds that
+                // 1e-16-relative residue): plane 2 of jx / jy / jz carries nothing unless the particle
+                // crossed along x / y / z
+                bool on = (i < (LPA_SKIP_NULL_RUN ? 2 : 3) || !ax.tail_zero) && (j < 3 || !ay.tail_zero) &&
+                          (kk < 3 || !az.tail_zero);
 #ifdef LPA_ABLATE_NO_TAIL
                 on = i < 3 && j < 3 && kk < 3;
 #endif
@@ -478,8 +486,8 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #endif
                 if (on) {
                     int o = b0 + (i * R3Y + j) * R3ZS + kk;
-                    atomicAdd(&s_j[1][o], djy);
-                    atomicAdd(&s_j[2][o], djz);
+                    if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][o], djy);
+                    if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][o], djz);
                     atomicAdd(&s_j[3][o], dr);
                 }
             });

@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(512) k(const int *idx, double *out, long long 
     int lane = threadIdx.x & 63;
     int a = idx[threadIdx.x];
     double v = 1.0 + lane;
-    bool act = lane < nactive;
+    bool act = nactive < 0 ? ((lane & 1) == 0) : lane < nactive;   // nactive < 0: even lanes only
     long long t0 = __builtin_amdgcn_s_memtime();
     double acc = 0.0;
     // immediate offsets only: no address arithmetic between the LDS instructions
@@ -25,6 +25,24 @@ __global__ void __launch_bounds__(512) k(const int *idx, double *out, long long 
 #pragma unroll
                 for (int c = 0; c < 32; c++) atomicAdd(base + c * 64, v);
             }
+        } else if (MODE == 3) {   // ds_read_b128 at an address that is 8- but not 16-byte aligned
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 t[16];
+            unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(s + 2 * a + 1);
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t[c]) : "v"(addr), "n"(c * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc += t[c].x + t[c].y;
+        } else if (MODE == 2) {   // 16 bytes per lane: ds_read_b128
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 t[16];
+            const d2 *b2 = (const d2 *)(s + 2 * a);
+#pragma unroll
+            for (int c = 0; c < 16; c++) t[c] = b2[c * 64];
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc += t[c].x + t[c].y;
         } else {
             double t[32];
 #pragma unroll
@@ -59,19 +77,22 @@ int main() {
             if (pat == 5) h[t] = (lane & 15) + 64 * (lane >> 4) + 256 * w;
         }
         hipMemcpy(d, h, T * sizeof(int), hipMemcpyHostToDevice);
-        for (int mode = 0; mode < 2; mode++)
-            for (int na : {64, 32, 8, 2}) {
-                if (mode == 1 && na != 64) continue;
+        for (int mode = 0; mode < 4; mode++)
+            for (int na : {64, 32, -32, 8, 2}) {
+                if (mode >= 1 && na != 64) continue;
+                if (mode >= 2 && pat != 0 && pat != 1) continue;   // b128: 2 * a must stay inside the array
                 for (int it = 0; it < 2; it++) {
                     if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(B), dim3(T), 0, 0, d, o, c, na);
-                    else hipLaunchKernelGGL(k<1>, dim3(B), dim3(T), 0, 0, d, o, c, na);
+                    else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(B), dim3(T), 0, 0, d, o, c, na);
+                    else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(B), dim3(T), 0, 0, d, o, c, na);
+                    else hipLaunchKernelGGL(k<3>, dim3(B), dim3(T), 0, 0, d, o, c, na);
                     hipDeviceSynchronize();
                 }
                 hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost);
                 double m = 0; for (int b = 0; b < B; b++) m += hc[b]; m /= B;
                 // 8 waves per block, 2 blocks per CU co-resident: cycles per wave instruction seen by the CU
                 printf("%-42s %s active=%2d : %8.1f cyc/block -> %6.2f cyc per wave-instr per CU (16 waves = 2 blocks/CU)\n",
-                       names[pat], mode ? "ds_read_b64" : "ds_add_f64 ", na, m, m / (REP * 16.0));
+                       names[pat], mode == 3 ? "ds_read_b128 +8B misaligned (per 2 doubles /2)" : mode == 2 ? "ds_read_b128 (16 instr = 32 doubles)" : mode ? "ds_read_b64" : "ds_add_f64 ", na, m, m / (REP * 16.0));
             }
     }
     return 0;
