@@ -175,13 +175,38 @@ def main():
         raise SystemExit("bench.py needs a GPU: lambdapic_amd has no CPU path")
     device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    p2p, comm_note = None, "single rank"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane (barrier, max of the elapsed time) on gloo; the halo / migration messages of the
+        # step travel device-to-device on an RCCL group.  A pre-flight ring exchange checks that group; if
+        # RCCL cannot serve it the faces are staged through the host on gloo instead and the line says so.
+        dist.init_process_group("gloo")
+        comm_note = "gloo (host-staged faces)"
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
-    comm = SlabComm(None)
+            ok = 1
+            try:
+                import datetime
+                try:
+                    p2p = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=device)
+                except TypeError:
+                    p2p = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                probe = SlabComm(None, p2p_group=p2p)
+                t = [torch.full((16,), float(probe.rank), dtype=torch.float64, device=device) for _ in range(4)]
+                probe.exchange(t[0], t[1], t[2], t[3])
+                torch.cuda.synchronize(device)
+                if t[2][0].item() != probe.left or t[3][0].item() != probe.right:
+                    ok = 0
+            except Exception as e:   # noqa: BLE001 -- any RCCL failure: fall back, visibly
+                print(f"[bench] rank {os.environ.get('RANK')}: RCCL face exchange unavailable ({e!r})", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm_note = "rccl p2p (batch_isend_irecv), gloo control"
+            else:
+                p2p = None
+    comm = SlabComm(None, p2p_group=p2p)
     assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     eng, dt, n_local = build_engine(args, comm, device)
@@ -201,7 +226,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -234,6 +259,7 @@ def main():
                                f"+guards, tile sort every {args.sort_interval} steps",
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
+                   "comm": comm_note,
                    "part_eb_writeback": False},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

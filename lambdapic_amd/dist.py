@@ -15,13 +15,17 @@ import torch.distributed as dist
 
 
 class SlabComm:
-    def __init__(self, group=None, periodic=True, single=False):
+    def __init__(self, group=None, periodic=True, single=False, p2p_group=None):
+        """``group``: control plane (barrier, diagnostics); ``p2p_group``: the group the face messages
+        travel on (default: ``group``) -- e.g. a gloo default group for CPU-side control next to an RCCL
+        group for the device-to-device halo traffic"""
         if not single and dist.is_available() and dist.is_initialized():
             self.group = group
             self.rank = dist.get_rank(group)
             self.size = dist.get_world_size(group)
         else:
             self.group, self.rank, self.size = None, 0, 1
+        self.p2p_group = p2p_group if p2p_group is not None else self.group
         self.periodic = periodic
         # ring (periodic x) or chain (open / PML x edges: the end ranks have one neighbour)
         self.left = (self.rank - 1) % self.size if (periodic or self.rank > 0) else -1
@@ -50,7 +54,8 @@ class SlabComm:
                 recv_lo.copy_(send_hi)   # my own high edge is my low guard's periodic source
                 recv_hi.copy_(send_lo)
             return []
-        staged = send_lo.is_cuda and dist.get_backend(self.group) == "gloo"
+        grp = self.p2p_group
+        staged = send_lo.is_cuda and dist.get_backend(grp) == "gloo"
         if staged:
             s_lo, s_hi = send_lo.cpu(), send_hi.cpu()
             r_lo, r_hi = torch.empty_like(recv_lo, device="cpu"), torch.empty_like(recv_hi, device="cpu")
@@ -58,12 +63,12 @@ class SlabComm:
             s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
         ops = []
         if self.has_right:
-            ops.append(dist.P2POp(dist.isend, s_hi, self.right, self.group, tag=1))
+            ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp, tag=1))
         if self.has_left:
-            ops.append(dist.P2POp(dist.isend, s_lo, self.left, self.group, tag=0))
-            ops.append(dist.P2POp(dist.irecv, r_lo, self.left, self.group, tag=1))
+            ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp, tag=0))
+            ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp, tag=1))
         if self.has_right:
-            ops.append(dist.P2POp(dist.irecv, r_hi, self.right, self.group, tag=0))
+            ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp, tag=0))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if wait or staged:
             for r in reqs:
