@@ -307,6 +307,12 @@ const int32_t *lpa_sort_live_count(void *workspace);
 #define LPA_MIG_NATTR 9 /* x y z ux uy uz inv_gamma w id */
 int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
                        double *buf_hi, int64_t capacity, void *stream);
+/* the same scan restricted to the particles that can have left a tile-ordered store since its sort: the
+ * `edge_cols` tile columns next to each x face (tile index is x-slowest) and the loose particles behind
+ * t->n_sorted.  The caller chooses edge_cols from the age of the order (c*dt*age / tile width, rounded
+ * up); the ranges are read from t->tile_off on the device.  2-D and 3-D tilings. */
+int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo,
+                             double xhi, double *buf_lo, double *buf_hi, int64_t capacity, void *stream);
 int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_capacity,
                        int32_t *cursor, const double *buf, int64_t capacity, double shift_x,
                        void *stream);

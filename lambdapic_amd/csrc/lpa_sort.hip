@@ -580,10 +580,8 @@ extern "C" int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, co
 // its own count.  Buffer layout (doubles): [0] = count (int64 bit pattern), then
 // [LPA_MIG_NATTR][capacity] SoA, attribute order x y z ux uy uz inv_gamma w id.
 // =====================================================================================================
-__global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, double xhi, double *buf_lo,
-                                                        double *buf_hi, long cap) {
-    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ip >= p.n) return;
+__device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double xlo, double xhi,
+                                                 double *buf_lo, double *buf_hi, long cap) {
     double x = p.x[ip];
     if ((p.dead && p.dead[ip]) || isnan(x)) return;
     int side = x < xlo ? 0 : (x > xhi ? 1 : -1);
@@ -608,6 +606,30 @@ __global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, dou
     }
     // slot >= cap: the particle is NOT lost -- it stays where it is (outside the slab, handled by the
     // torus path) and leaves at the next step; count > cap is visible to the host at the next sort.
+}
+
+__global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, double xhi, double *buf_lo,
+                                                        double *buf_hi, long cap) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap);
+}
+
+// the same over the only particles that can have left a tile-ordered store: the first / last `edge_tiles`
+// tiles (x is the slowest tile index, so these are the tile columns next to the two x faces) and the
+// loose particles behind the ordered range.  The ranges come from the device-side tile offsets: no host
+// round trip, fixed grid.
+__global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int32_t *__restrict__ tile_off,
+                                                              int ntiles, int edge_tiles, long n_sorted,
+                                                              double xlo, double xhi, double *buf_lo,
+                                                              double *buf_hi, long cap) {
+    const long a1 = tile_off[edge_tiles], b0 = tile_off[ntiles - edge_tiles], b1 = tile_off[ntiles];
+    const long nb = b1 - b0, nl = p.n > n_sorted ? p.n - n_sorted : 0;
+    const long total = a1 + nb + nl;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long ip = t < a1 ? t : (t < a1 + nb ? b0 + (t - a1) : n_sorted + (t - a1 - nb));
+        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_migrate_unpack(PartV p, long first_slot, long area_cap,
@@ -647,6 +669,29 @@ extern "C" int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi
     hipLaunchKernelGGL(k_migrate_pack_x, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st,
                        make_partv(p), xlo, xhi, buf_lo, buf_hi, (long)capacity);
     LPA_CHECK_LAUNCH("lpa_migrate_pack_x");
+    return LPA_OK;
+}
+
+extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols,
+                                        double xlo, double xhi, double *buf_lo, double *buf_hi,
+                                        int64_t capacity, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 2) && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
+                "lpa_migrate_pack_edges_x: bad args");
+    LPA_REQUIRE(t && t->tile_off && t->tiles_x > 0 && t->tiles_y > 0 && t->n_sorted >= 0 && t->n_sorted <= p->n,
+                "lpa_migrate_pack_edges_x: bad tiling");
+    LPA_REQUIRE(edge_cols >= 1 && 2 * edge_cols <= t->tiles_x, "lpa_migrate_pack_edges_x: bad edge_cols");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(buf_lo, 0, sizeof(double), st) != hipSuccess ||
+        hipMemsetAsync(buf_hi, 0, sizeof(double), st) != hipSuccess) {
+        lpa_set_error("lpa_migrate_pack_edges_x: memset failed");
+        return LPA_ERR_HIP;
+    }
+    if (p->n == 0) return LPA_OK;
+    const int per_col = t->tiles_y * (t->tiles_z > 0 ? t->tiles_z : 1);
+    const int ntiles = t->tiles_x * per_col;
+    hipLaunchKernelGGL(k_migrate_pack_edges_x, dim3(1024), dim3(256), 0, st, make_partv(p), t->tile_off, ntiles,
+                       edge_cols * per_col, (long)t->n_sorted, xlo, xhi, buf_lo, buf_hi, (long)capacity);
+    LPA_CHECK_LAUNCH("lpa_migrate_pack_edges_x");
     return LPA_OK;
 }
 

@@ -417,6 +417,13 @@ class PicEngine2D:
         cols = int(np.ceil(drift / _lib.LPA_TILE_X))
         return cols if 2 * cols < self.nx // _lib.LPA_TILE_X else 0
 
+    def leaver_columns(self, age):
+        """tile columns at each x face that can hold particles which left the slab during the ``age`` steps
+        since the sort (each step moves a particle less than one cell: the tiled push requires
+        c dt <= dx); 0 = scan everything"""
+        cols = int(np.ceil((age + 1) / _lib.LPA_TILE_X))
+        return cols if 2 * cols <= self.nx // _lib.LPA_TILE_X else 0
+
     def push_deposit_overlapped(self, dt):
         """push + deposit of all species with the J / rho guard-plane exchange hidden behind the interior
         tiles: edge tile columns (+ overflow + arrivals) first, then the exchange runs on a second
@@ -500,8 +507,15 @@ class PicEngine2D:
         pc = sp.cset.cstruct(sp.n)
         xlo = self.x0 - self.dx / 2
         xhi = self.x0 + (self.nx - 1) * self.dx + self.dx / 2
-        check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
-                                        cap, st), "lpa_migrate_pack_x")
+        # only the tile columns within drift range of an x face (and the loose particles) can hold leavers
+        cols = self.leaver_columns(sp.steps_since_sort)
+        if cols:
+            check(self.L.lpa_migrate_pack_edges_x(C.byref(pc), C.byref(sp.tiling), cols, xlo, xhi,
+                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap, st),
+                  "lpa_migrate_pack_edges_x")
+        else:
+            check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
+                                            cap, st), "lpa_migrate_pack_x")
         if not self.comm.has_left:
             m["r_lo"][:1].zero_()    # open face: nothing arrives (count = 0)
         if not self.comm.has_right:

@@ -300,8 +300,14 @@ class PicEngine3D:
         m = ws["mig"]
         xlo = self.x0 - self.d[0] / 2
         xhi = self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
-        check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
-                                        cap, st), "lpa_migrate_pack_x")
+        cols = int(np.ceil((sp["since"] + 1) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
+        if cols and 2 * cols <= self.n[0] // _lib.LPA_TILE3_X:   # only the edge tile columns + loose particles
+            check(self.L.lpa_migrate_pack_edges_x(C.byref(sp["c"]), C.byref(sp["tiling"]), cols, xlo, xhi,
+                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap, st),
+                  "lpa_migrate_pack_edges_x")
+        else:
+            check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
+                                            cap, st), "lpa_migrate_pack_x")
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         cur = ws["counters"][1:2].data_ptr()
         area = self.arrival_area()
