@@ -390,9 +390,12 @@ __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
     return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
 }
 
+#ifndef LPA_ST_PREFETCH
+#define LPA_ST_PREFETCH 1
+#endif
 #ifndef LPA_ST_THREADS
 #define LPA_ST_THREADS 1024
-#define LPA_ST_PT 16
+#define LPA_ST_PT 8
 #define LPA_ST_W 8192
 #endif
 constexpr int ST_THREADS = LPA_ST_THREADS, ST_PT = LPA_ST_PT, ST_W = LPA_ST_W;   // threads, particles per thread and chunk, window slots
@@ -430,6 +433,14 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                 if (dest[j] >= db && dest[j] < de) atomicOr(&s_bits[(dest[j] - db) >> 5], 1u << ((dest[j] - db) & 31));
             __syncthreads();
             int phase = 0;
+            // the loads of attribute a + 1 are issued before the window phases of attribute a: with one
+            // workgroup per CU nothing else hides their latency behind the barriers
+            double vn[ST_PT];
+#pragma unroll
+            for (int j = 0; j < ST_PT; j++) {
+                int ip = c0 + j * ST_THREADS + (int)threadIdx.x;
+                vn[j] = (LPA_ST_PREFETCH && dest[j] >= 0) ? al.src[0][ip] : 0.0;
+            }
             for (int a = 0; a < al.n; a++) {
                 const double *__restrict__ src = al.src[a];
                 double *__restrict__ dst = al.dst[a];
@@ -437,7 +448,12 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
 #pragma unroll
                 for (int j = 0; j < ST_PT; j++) {
                     int ip = c0 + j * ST_THREADS + (int)threadIdx.x;
-                    v[j] = dest[j] >= 0 ? src[ip] : 0.0;
+                    if (LPA_ST_PREFETCH) {
+                        v[j] = vn[j];
+                        if (a + 1 < al.n && dest[j] >= 0) vn[j] = al.src[a + 1][ip];
+                    } else {
+                        v[j] = dest[j] >= 0 ? src[ip] : 0.0;
+                    }
                     // changed tile: the scattered store (a few per cent of the particles), first pass only
                     if (db == db0 && dest[j] >= 0 && (dest[j] < db0 || dest[j] >= de0)) dst[dest[j]] = v[j];
                 }
