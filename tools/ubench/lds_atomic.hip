@@ -64,8 +64,10 @@ int main() {
     int *h = (int *)malloc(T * sizeof(int)), *d;
     double *o; long long *c, hc[B];
     hipMalloc(&d, T * sizeof(int)); hipMalloc(&o, sizeof(double) * T * B); hipMalloc(&c, sizeof(long long) * B);
-    const char *names[] = {"consecutive (lane -> lane)", "consecutive, wave offset 64*w", "random in 16x64 tile", "stride 2", "all lanes same address", "16-lane groups same row, rows 64 apart"};
-    for (int pat = 0; pat < 6; pat++) {
+    const char *names[] = {"consecutive (lane -> lane)", "consecutive, wave offset 64*w", "random in 16x64 tile", "stride 2", "all lanes same address", "16-lane groups same row, rows 64 apart",
+        "consecutive, every 4th lane drifted +1 column", "quarters = even / odd columns, every 4th lane drifted +1",
+        "quarters = even / odd columns, no drift", "consecutive, every 4th lane drifted +1 ROW (64 doubles)"};
+    for (int pat = 0; pat < 10; pat++) {
         srand(1);
         for (int t = 0; t < T; t++) {
             int lane = t & 63, w = t >> 6;
@@ -75,6 +77,14 @@ int main() {
             if (pat == 3) h[t] = 2 * lane + 128 * w;
             if (pat == 4) h[t] = 5;
             if (pat == 5) h[t] = (lane & 15) + 64 * (lane >> 4) + 256 * w;
+            if (pat == 6) h[t] = lane + ((lane & 3) == 1 ? 1 : 0);
+            if (pat == 7 || pat == 8) {   // lanes 0-15: even columns of row 0, 16-31: odd columns, 32-63: row 1
+                int q = lane >> 4, i = lane & 15;
+                int col = 2 * i + (q & 1), row = q >> 1;
+                if (pat == 7 && (lane & 3) == 1) col += 1;
+                h[t] = row * 64 + col;
+            }
+            if (pat == 9) h[t] = lane + ((lane & 3) == 1 ? 64 : 0);
         }
         hipMemcpy(d, h, T * sizeof(int), hipMemcpyHostToDevice);
         for (int mode = 0; mode < 4; mode++)
