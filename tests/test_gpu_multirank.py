@@ -146,6 +146,18 @@ def _run_laser_target(rank, world, port, q):
     g = sim.engine.grid
     nxl = nx // world
     fields = {a: g.view(a)[3:3 + nxl, 3:3 + ny].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    # get_fields (callback/utils.py:26-123): the whole box on rank 0, None elsewhere
+    from lambdapic_amd.callbacks import get_fields
+    whole = get_fields(sim, ["ey", "rho"])
+    if world > 1:
+        slabs = [None] * world if rank == 0 else None
+        dist.gather_object(fields["ey"], slabs, dst=0)          # an independent (pickled) path
+        if rank == 0:
+            assert whole[0].shape == (nx, ny) and np.array_equal(whole[0], np.concatenate(slabs, axis=0))
+        else:
+            assert whole == [None, None]
+    else:
+        assert np.array_equal(whole[0], fields["ey"]) and np.array_equal(whole[1], fields["rho"])
     q.put((rank, np.array(trace), fields))
     if world > 1:
         dist.barrier()

@@ -49,6 +49,24 @@ def test_laser_target_3d_through_the_callback_api():
     e_dev = float((sim.engine.view("ey")[3:-3, 3:-3, 3:-3] ** 2).sum().item())
     assert e_dev > 0
 
+    # get_fields (callback/utils.py:125-237): the z = Lz / 2 plane of the whole box, assembled from the mirrors
+    # the way the reference does it (patch interiors, plane index int((Lz / 2 + dz / 2) / dz))
+    from lambdapic_amd.callbacks import get_fields
+    ey_plane, = get_fields(sim, ["ey"])
+    sim.download()
+    iz = int((sim.Lz / 2 + sim.dz / 2) / sim.dz)
+    want = np.zeros((sim.nx, sim.ny))
+    for p in sim.patches:
+        f = p.fields
+        k0 = int(round((f.z0 - 0.0) / sim.dz))
+        if k0 <= iz < k0 + f.nz:
+            i0, j0 = int(round(f.x0 / sim.dx)), int(round(f.y0 / sim.dy))
+            want[i0:i0 + f.nx, j0:j0 + f.ny] = f.ey[:f.nx, :f.ny, iz - k0]
+    assert ey_plane.shape == (sim.nx, sim.ny) and np.abs(ey_plane).max() > 0
+    assert np.array_equal(ey_plane, want)
+    with pytest.raises(ValueError):
+        get_fields(sim, ["ey"], slice_at=2 * sim.Lz)
+
     # the mirrored path: the same run with a do-nothing host callback at every step gives the same state
     sim2 = _sim(npatch_x=2, npatch_y=1, npatch_z=2)
     laser2 = GaussianLaser3D(a0=3.0, l0=LAM, w0=1.0e-6, ctau=0.8e-6, x0=1.6e-6)
