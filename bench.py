@@ -70,6 +70,38 @@ def build_engine(args, comm, device):
     return eng, dt, n
 
 
+def parity_c1(nsteps=30):
+    """SURVEY 8(d)'s accuracy figures on config C1 (256 x 256 cells, 16 ppc, periodic thermal plasma): the
+    same seeded particles through the CPU port and through the GPU engine; relative error of the field
+    energy, the kinetic energy and the total charge after ``nsteps`` steps (the CPU port is the checker)."""
+    import oracle
+    from oracle import driver
+    from lambdapic_amd.engine import PicEngine2D
+    from lambdapic_amd.patch import make_patches_2d
+
+    nx = ny = 256
+    dx = dy = LAMBDA0 / 20
+    dt = 0.95 / (C_LIGHT * np.sqrt(dx ** -2 + dy ** -2))
+    q, m = -oracle.E_CHARGE, oracle.M_E
+    n_c = oracle.EPSILON_0 * m * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / q ** 2
+    P = make_patches_2d(nx, ny, dx, dy, 8, 8)
+    driver.load_uniform_plasma(P, 0, 16, n_c, 0.0442, np.random.default_rng(20260722))
+    eng = PicEngine2D(nx, ny, dx, dy, n_guard=3, device="cuda:0", sort_interval=8)
+    n = sum(p.particles[0].npart for p in P)
+    eng.add_species(q, m, capacity=int(1.2 * n) + 1024)
+    eng.species[0].upload([p.particles[0] for p in P])
+    ks = driver.oracle_kernels()
+    for _ in range(nsteps):
+        driver.step(P, ks, dt, [(q, m)], do_sort=False)
+        eng.step(dt)
+    d = eng.diagnostics()
+    rel = lambda a, b: abs(a - b) / abs(b) if b else abs(a - b)
+    return {"config": "C1: 256x256 cells, 16 ppc, periodic", "steps": nsteps,
+            "field_energy_rel_err": rel(d["field_energy"], driver.field_energy(P)),
+            "kinetic_energy_rel_err": rel(d["kinetic"][0], driver.kinetic_energy(P, 0, m)),
+            "charge_rel_err": rel(d["charge"], driver.total_charge(P))}
+
+
 def cpu_baseline(args):
     """oracle port (oracle/picoracle.c, rebuilt -O3 -march=native on this host) on a bounded sample:
     same physics and cell size, smaller box; fused push+deposit (OpenMP over patches) + the four
@@ -139,7 +171,7 @@ def cpu_baseline(args):
     except (OSError, ValueError):
         pass
     return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "port_over_reference_same_cores": ratio,
+            "port_over_reference_same_cores": ratio, "parity_c1": parity_c1(),
             "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
                       f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
                       f"-O3 -march=native, {threads} OpenMP threads"}
