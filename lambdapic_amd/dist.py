@@ -10,6 +10,7 @@ all-reduces inside the step).  With one rank nothing is sent (the engine wraps l
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -81,10 +82,35 @@ class SlabComm:
         return reqs
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
-        """diagnostics only (never inside the step)"""
+        """diagnostics only (never inside the step): the reference's scalar reductions (energy, charge, live
+        count); a device tensor is staged through the host when the control group is gloo"""
         if self.size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def reduce_diagnostics(self, d: dict) -> dict:
+        """sum a diagnostics() dict (floats, ints and lists of them) over the ranks: one all-reduce"""
+        if self.size == 1:
+            return d
+        keys, flat = [], []
+        for k, v in d.items():
+            vals = v if isinstance(v, list) else [v]
+            keys.append((k, len(vals), isinstance(v, list), all(isinstance(x, (int, np.integer)) for x in vals)))
+            flat += [float(x) for x in vals]
+        on_host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor(flat, dtype=torch.float64, device="cpu" if on_host else torch.cuda.current_device())
+        t = self.allreduce_sum(t)
+        out, i = {}, 0
+        for k, n, is_list, is_int in keys:
+            vals = [int(round(x)) if is_int else float(x) for x in t[i:i + n].tolist()]
+            out[k] = vals if is_list else vals[0]
+            i += n
+        return out
 
     def barrier(self):
         if self.size > 1:

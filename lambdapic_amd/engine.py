@@ -686,9 +686,9 @@ class PicEngine2D:
         self.sync_guard_fields(E)
 
     # ---- diagnostics ------------------------------------------------------------------------------
-    def diagnostics(self):
+    def diagnostics(self, reduce=False):
         """dict of field energy (E, B parts), total charge, current sums, kinetic energy and live
-        count per species -- local to this rank (sum over ranks for the global value)."""
+        count per species -- local to this rank; ``reduce=True`` sums over the ranks (one all-reduce)."""
         st = self.stream
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), st), "diag")
@@ -703,4 +703,4 @@ class PicEngine2D:
             d = d.cpu().numpy()
             out["kinetic"].append(float(d[0]))
             out["nalive"].append(int(round(d[1])))
-        return out
+        return self.comm.reduce_diagnostics(out) if reduce else out

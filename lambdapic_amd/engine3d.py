@@ -597,8 +597,8 @@ class PicEngine3D:
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)
 
-    def diagnostics(self):
-        """this rank's share (sum over ranks = the box)"""
+    def diagnostics(self, reduce=False):
+        """this rank's share; ``reduce=True`` sums over the ranks (one all-reduce)"""
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), self.stream), "diag")
         f = self._diag.cpu().numpy().copy()
@@ -609,4 +609,4 @@ class PicEngine3D:
             d = d.cpu().numpy()
             out["kinetic"].append(float(d[0]))
             out["nalive"].append(int(round(d[1])))
-        return out
+        return self.comm.reduce_diagnostics(out) if reduce else out

@@ -85,7 +85,14 @@ def _worker(rank, world, port, nx_loc, ny, q):
                 and not J[:NG].any() and not J[NG + nx_loc:].any()
         else:
             ok_fold = True
-        q.put((rank, bool(ok_guard), bool(ok_fold)))
+        # scalar diagnostics: one all-reduce over the ranks (floats, ints and per-species lists)
+        d = comm.reduce_diagnostics({"field_energy": 1.5 + rank, "charge": -2.0, "kinetic": [0.25 * rank, 1.0],
+                                     "nalive": [10 + rank, 7]})
+        w = world
+        ok_diag = d == {"field_energy": 1.5 * w + w * (w - 1) / 2, "charge": -2.0 * w,
+                        "kinetic": [0.25 * w * (w - 1) / 2, 1.0 * w], "nalive": [10 * w + w * (w - 1) // 2, 7 * w]} \
+            and all(isinstance(v, int) for v in d["nalive"])
+        q.put((rank, bool(ok_guard), bool(ok_fold) and bool(ok_diag)))
     finally:
         dist.destroy_process_group()
 
