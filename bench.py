@@ -219,10 +219,13 @@ def main():
             ok = 1
             try:
                 import datetime
-                try:
-                    p2p = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=device)
-                except TypeError:
-                    p2p = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                # (no device_id: with a gloo default group there is no parent communicator to split from;
+                # the communicators are created by the first exchange below, on the device set above)
+                p2p = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                one = torch.ones(1, dtype=torch.float64, device=device)
+                dist.all_reduce(one, group=p2p)          # creates the group-wide communicator collectively
+                if int(one.item()) != world:
+                    raise RuntimeError("RCCL all-reduce returned a wrong sum")
                 probe = SlabComm(None, p2p_group=p2p)
                 t = [torch.full((16,), float(probe.rank), dtype=torch.float64, device=device) for _ in range(4)]
                 probe.exchange(t[0], t[1], t[2], t[3])
