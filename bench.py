@@ -107,7 +107,7 @@ def cpu_baseline(args):
     same physics and cell size, smaller box; fused push+deposit (OpenMP over patches) + the four
     FDTD half steps + guard copies / current fold; no sort, no particle migration."""
     import oracle
-    from oracle import driver, sync
+    from oracle import driver
     from lambdapic_amd.patch import make_patches_2d
 
     # the box gives one GPU a share of the host cores: use the cores this process may run on,

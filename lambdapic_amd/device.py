@@ -14,7 +14,6 @@ HBM layout
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 import torch

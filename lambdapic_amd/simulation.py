@@ -20,7 +20,6 @@ laser injection (``lambdapic_amd.laser``) and the moving window are device nativ
 """
 from __future__ import annotations
 
-import time as _time
 from dataclasses import dataclass, field
 
 import numpy as np
