@@ -194,6 +194,14 @@ int lpa_halo_pack_guard_src(const lpa_grid *g, int which, int side, double *buf,
 int lpa_halo_unpack_guard(const lpa_grid *g, int which, int side, const double *buf, void *stream);
 int lpa_halo_pack_current(const lpa_grid *g, int side, double *buf, void *stream);
 int lpa_halo_unpack_current(const lpa_grid *g, int side, const double *buf, void *stream);
+/* the same four operations on BOTH x faces in one launch (half the launches of a halo step):
+ * op = LPA_HALO_PACK_GUARD_SRC / _UNPACK_GUARD (E and / or B, `which` as above) or _PACK_CURRENT /
+ * _UNPACK_CURRENT (`which` ignored); a NULL buffer skips its face (open end of a slab chain). */
+#define LPA_HALO_PACK_GUARD_SRC 0
+#define LPA_HALO_UNPACK_GUARD 1
+#define LPA_HALO_PACK_CURRENT 2
+#define LPA_HALO_UNPACK_CURRENT 3
+int lpa_halo_faces(const lpa_grid *g, int op, int which, double *buf_lo, double *buf_hi, void *stream);
 
 /* ---- fused particle kernel (replaces unified_boris_pusher_cpu_2d(particles_list, fields_list,
  *      npatches, dt, q, m), core/pusher/unified/unified_pusher_2d.c:157-365): half push, TSC

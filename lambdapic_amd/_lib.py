@@ -20,6 +20,7 @@ LPA_ORDER_STRIPED = 1
 LPA_TILE_MARGIN = 2
 LPA_TILE3_X, LPA_TILE3_Y, LPA_TILE3_Z, LPA_TILE3_MARGIN = 4, 4, 16, 1
 LPA_MIG_NATTR = 9
+LPA_HALO_PACK_GUARD_SRC, LPA_HALO_UNPACK_GUARD, LPA_HALO_PACK_CURRENT, LPA_HALO_UNPACK_CURRENT = 0, 1, 2, 3
 LPA_PART_ALL, LPA_PART_EDGE, LPA_PART_INTERIOR = 0, 1, 2
 LPA_ABSORB_X = 16
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "lpa_halo_unpack_guard": (_i, [_G, _i, _i, _vp, _vp]),
     "lpa_halo_pack_current": (_i, [_G, _i, _vp, _vp]),
     "lpa_halo_unpack_current": (_i, [_G, _i, _vp, _vp]),
+    "lpa_halo_faces": (_i, [_G, _i, _i, _vp, _vp, _vp]),
     "lpa_push_deposit_2d": (_i, [_G, _P, _PP, _i64, _i64, _vp]),
     "lpa_push_deposit_tiled_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
     "lpa_push_deposit_tiled_part_2d": (_i, [_G, _P, _PP, _T, _vp, _vp, _i, _i, _vp]),

@@ -865,6 +865,23 @@ static int halo_launch(const lpa_grid *g, Ptr6 f, long first_row, double *buf, i
     return LPA_OK;
 }
 
+// both faces in one launch (blockIdx.z = face); a null buffer skips its face
+__global__ void __launch_bounds__(256) k_halo2(Ptr6 f, double *buf_lo, double *buf_hi, long plane, long first_lo,
+                                               long first_hi, int ng, int mode) {
+    long n = (long)ng * plane;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double *buf = blockIdx.z == 0 ? buf_lo : buf_hi;
+    if (!buf) return;
+    int c = blockIdx.y;
+    double *a = f.p[c] + (blockIdx.z == 0 ? first_lo : first_hi) * plane + t;
+    double *b = buf + (long)c * n + t;
+    if (mode == HALO_PACK_SRC) *b = *a;
+    else if (mode == HALO_UNPACK_GUARD) *a = *b;
+    else if (mode == HALO_PACK_CUR) { *b = *a; *a = 0.0; }
+    else *a += *b;
+}
+
 static Ptr6 eb_ptrs(const lpa_grid *g, int which) {
     Ptr6 f;
     f.n = 0;
@@ -913,6 +930,34 @@ extern "C" int lpa_halo_unpack_current(const lpa_grid *g, int side, const double
     long first = side == 0 ? g->ng : g->nx;  // interior edge planes
     return halo_launch(g, cur_ptrs(g), first, (double *)buf, HALO_UNPACK_CUR, stream,
                        "lpa_halo_unpack_current");
+}
+
+extern "C" int lpa_halo_faces(const lpa_grid *g, int op, int which, double *buf_lo, double *buf_hi,
+                              void *stream) {
+    LPA_REQUIRE(g && op >= HALO_PACK_SRC && op <= HALO_UNPACK_CUR && g->nx >= g->ng, "lpa_halo_faces: bad args");
+    if (!buf_lo && !buf_hi) return LPA_OK;
+    Ptr6 f;
+    long first_lo, first_hi;
+    if (op == HALO_PACK_CUR || op == HALO_UNPACK_CUR) {
+        LPA_REQUIRE(g->jx && g->jy && g->jz && g->rho, "lpa_halo_faces: current arrays missing");
+        f = cur_ptrs(g);
+        // pack: my guard planes; unpack: added into my interior edge
+        first_lo = op == HALO_PACK_CUR ? 0 : g->ng;
+        first_hi = op == HALO_PACK_CUR ? g->nx + g->ng : g->nx;
+    } else {
+        f = eb_ptrs(g, which);
+        if (!f.n) return LPA_OK;
+        // pack: my interior edge rows; unpack: my guard rows
+        first_lo = op == HALO_PACK_SRC ? g->ng : 0;
+        first_hi = op == HALO_PACK_SRC ? g->nx : g->nx + g->ng;
+    }
+    long plane = (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1);
+    long n = (long)g->ng * plane;
+    dim3 grid((unsigned)((n + 255) / 256), f.n, 2);
+    hipLaunchKernelGGL(k_halo2, grid, dim3(256), 0, (hipStream_t)stream, f, buf_lo, buf_hi, plane, first_lo,
+                       first_hi, g->ng, op);
+    LPA_CHECK_LAUNCH("lpa_halo_faces");
+    return LPA_OK;
 }
 
 // =====================================================================================================

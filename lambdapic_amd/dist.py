@@ -117,7 +117,7 @@ class SlabComm:
             dist.barrier(group=self.group)
 
 
-def exchange_faces(comm: SlabComm, pack, unpack, bufs):
+def exchange_faces(comm: SlabComm, pack, unpack, bufs, pack2=None, unpack2=None):
     """One nearest-neighbour halo step of the slab decomposition, shared by guard copies, current
     folds and particle migration:
 
@@ -126,13 +126,21 @@ def exchange_faces(comm: SlabComm, pack, unpack, bufs):
 
     What leaves my low face arrives at the LEFT neighbour's high face and vice versa (the ring is
     periodic, `core/patch/patch.py:446-507` neighbour tables for periodic x).  ``bufs`` is a dict
-    with tensors ``s_lo s_hi r_lo r_hi``.
+    with tensors ``s_lo s_hi r_lo r_hi``.  ``pack2(buf_lo, buf_hi)`` / ``unpack2(buf_lo | None, buf_hi | None)``
+    do both faces in one call (one kernel launch instead of two) and replace ``pack`` / ``unpack`` when given.
     """
-    pack(0, bufs["s_lo"])
-    pack(1, bufs["s_hi"])
-    comm.exchange(bufs["s_lo"], bufs["s_hi"], bufs["r_lo"], bufs["r_hi"])
     single = comm.size == 1 and comm.periodic
-    if comm.has_left or single:      # nothing arrives through an open (PML) face
+    got_lo, got_hi = comm.has_left or single, comm.has_right or single   # nothing arrives through an open face
+    if pack2 is not None:
+        pack2(bufs["s_lo"], bufs["s_hi"])
+    else:
+        pack(0, bufs["s_lo"])
+        pack(1, bufs["s_hi"])
+    comm.exchange(bufs["s_lo"], bufs["s_hi"], bufs["r_lo"], bufs["r_hi"])
+    if unpack2 is not None:
+        unpack2(bufs["r_lo"] if got_lo else None, bufs["r_hi"] if got_hi else None)
+        return
+    if got_lo:
         unpack(0, bufs["r_lo"])
-    if comm.has_right or single:
+    if got_hi:
         unpack(1, bufs["r_hi"])

@@ -151,7 +151,10 @@ class PicEngine2D:
         self._ws = {}
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
-        self.overlap = True
+        # hide the J / rho guard exchange behind the interior tiles?  Off by default in 2-D: without a wire the
+        # split step costs 2.61 ms against 2.44 ms unsplit on C2 (tools/bench_mirror.py), so it only pays when a
+        # 100 KB face message takes longer than ~0.15 ms; the 3-D engine (6.6 MB per face) keeps it on
+        self.overlap = False
         self.defer_crossers = True
         self.fused_cpml = True
         self._axes = {}
@@ -270,6 +273,13 @@ class PicEngine2D:
             self._halo = {"s_lo": mk(4), "s_hi": mk(4), "r_lo": mk(4), "r_hi": mk(4)}
         return self._halo
 
+    def _faces(self, op, which=0):
+        """both x faces in one launch (lpa_halo_faces); a missing buffer (open chain end) is skipped"""
+        def run(b_lo, b_hi):
+            check(self.L.lpa_halo_faces(self._g(), op, which, b_lo.data_ptr() if b_lo is not None else None,
+                                        b_hi.data_ptr() if b_hi is not None else None, self.stream), "lpa_halo_faces")
+        return run
+
     def sync_guard_fields(self, attrs):
         which = (1 if any(a in attrs for a in ("ex", "ey", "ez")) else 0) | \
                 (2 if any(a in attrs for a in ("bx", "by", "bz")) else 0)
@@ -285,7 +295,8 @@ class PicEngine2D:
                                       "lpa_halo_pack_guard_src"),
                 lambda side, b: check(self.L.lpa_halo_unpack_guard(self._g(), which, side, b.data_ptr(), st),
                                       "lpa_halo_unpack_guard"),
-                h)
+                h, pack2=self._faces(_lib.LPA_HALO_PACK_GUARD_SRC, which),
+                unpack2=self._faces(_lib.LPA_HALO_UNPACK_GUARD, which))
 
     # ---- currents (CurrentDeposition2D.reset, Patches.sync_currents + MPIManager.sync_currents_*) --
     def reset_current(self):
@@ -303,7 +314,7 @@ class PicEngine2D:
                                       "lpa_halo_pack_current"),
                 lambda side, b: check(self.L.lpa_halo_unpack_current(self._g(), side, b.data_ptr(), st),
                                       "lpa_halo_unpack_current"),
-                h)
+                h, pack2=self._faces(_lib.LPA_HALO_PACK_CURRENT), unpack2=self._faces(_lib.LPA_HALO_UNPACK_CURRENT))
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
 
     # ---- sort (ParticleSort2D.__call__, core/sort/particle_sort.py:196-211) ------------------------
@@ -384,20 +395,27 @@ class PicEngine2D:
         pc = sp.cset.cstruct(sp.n, eb=self.write_part_eb)
         if tiled and sp.tiling is not None and sp.n_sorted > 0:
             ws = self._sort_ws(sp)
-            ws["counters"][0:1].zero_()
-            cnt = ws["counters"].data_ptr()
+            # the edge part may run on a second stream beside the interior part: own overflow list + counter
+            if part == _lib.LPA_PART_EDGE:
+                if "overflow_edge" not in ws:
+                    ws["overflow_edge"] = torch.empty(sp.capacity, dtype=torch.int32, device=self.device)
+                ovf, cslot = ws["overflow_edge"], 2
+            else:
+                ovf, cslot = ws["overflow"], 0
+            ws["counters"][cslot:cslot + 1].zero_()
+            cnt = ws["counters"][cslot:cslot + 1].data_ptr()
             timed = self.kernel_events is not None
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
             check(self.L.lpa_push_deposit_tiled_part_2d(self._g(), C.byref(pc), C.byref(pp), C.byref(sp.tiling),
-                                                        ws["overflow"].data_ptr(), cnt, part, edge_cols, st),
+                                                        ovf.data_ptr(), cnt, part, edge_cols, st),
                   "tiled")
             if timed:
                 e1.record(torch.cuda.current_stream(self.device))
                 self.kernel_events.append((e0, e1))
             check(self.L.lpa_push_deposit_list_2d(self._g(), C.byref(pc), C.byref(pp),
-                                                  ws["overflow"].data_ptr(), cnt, sp.n_sorted, st), "list")
+                                                  ovf.data_ptr(), cnt, sp.n_sorted, st), "list")
             loose = sp.n - sp.n_sorted
             if loose > 0 and part != _lib.LPA_PART_INTERIOR:
                 check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), sp.n_sorted, loose, st),
@@ -435,28 +453,26 @@ class PicEngine2D:
             return False
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        for i in range(len(self.species)):
-            self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: the edge goes first
         ready, done = torch.cuda.Event(), torch.cuda.Event()
         ready.record(main)
         h = self._halo_bufs()
+        # edge tiles + pack + exchange on the high-priority side stream, the interior tiles on the main stream AT
+        # THE SAME TIME (they touch disjoint particles and never the x guard planes; both add into J with
+        # atomics): a separate edge launch in front of the interior one cost a whole extra round of workgroups
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
-            st = self.stream
-            for side, b in ((0, h["s_lo"]), (1, h["s_hi"])):
-                check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st), "lpa_halo_pack_current")
+            for i in range(len(self.species)):
+                self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
+            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
             self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
             done.record(self._side)
         for i in range(len(self.species)):
             self.push_deposit(i, dt, part=_lib.LPA_PART_INTERIOR, edge_cols=cols)
         main.wait_event(done)
-        st = self.stream
-        if self.comm.has_left:
-            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "lpa_halo_unpack_current")
-        if self.comm.has_right:
-            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "lpa_halo_unpack_current")
-        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
+                                                  h["r_hi"] if self.comm.has_right else None)
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
         return True
 
     # ---- split kernels: the path the reference takes when a callback sits in a pusher stage --------

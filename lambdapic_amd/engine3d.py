@@ -260,6 +260,13 @@ class PicEngine3D:
             self._halo = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
         return self._halo
 
+    def _faces(self, op, which=0):
+        """both x faces in one launch (lpa_halo_faces); a missing buffer (open chain end) is skipped"""
+        def run(b_lo, b_hi):
+            check(self.L.lpa_halo_faces(self._g(), op, which, b_lo.data_ptr() if b_lo is not None else None,
+                                        b_hi.data_ptr() if b_hi is not None else None, self.stream), "lpa_halo_faces")
+        return run
+
     def sync_guard_fields(self, which):
         """``which``: 1 = E, 2 = B"""
         st = self.stream
@@ -273,7 +280,8 @@ class PicEngine3D:
                                       "lpa_halo_pack_guard_src"),
                 lambda side, b: check(self.L.lpa_halo_unpack_guard(self._g(), which, side, b.data_ptr(), st),
                                       "lpa_halo_unpack_guard"),
-                h)      # whole planes travel: the sender wrapped their y / z guard strips already
+                h, pack2=self._faces(_lib.LPA_HALO_PACK_GUARD_SRC, which),
+                unpack2=self._faces(_lib.LPA_HALO_UNPACK_GUARD, which))      # whole planes travel: the sender wrapped their y / z guard strips already
 
     def sync_currents(self):
         st = self.stream
@@ -285,7 +293,7 @@ class PicEngine3D:
                                       "lpa_halo_pack_current"),
                 lambda side, b: check(self.L.lpa_halo_unpack_current(self._g(), side, b.data_ptr(), st),
                                       "lpa_halo_unpack_current"),
-                h)
+                h, pack2=self._faces(_lib.LPA_HALO_PACK_CURRENT), unpack2=self._faces(_lib.LPA_HALO_UNPACK_CURRENT))
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
 
     def sync_particles(self, i):
@@ -559,20 +567,15 @@ class PicEngine3D:
         h = self._halo_bufs()
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
-            st = self.stream
-            for side, b in ((0, h["s_lo"]), (1, h["s_hi"])):
-                check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st), "lpa_halo_pack_current")
+            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
             self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
             done.record(self._side)
         for i in range(len(self.species)):
             self.push_deposit(i, dt, part=_lib.LPA_PART_INTERIOR, edge_cols=cols)
         main.wait_event(done)
-        st = self.stream
-        if self.comm.has_left:
-            check(self.L.lpa_halo_unpack_current(self._g(), 0, h["r_lo"].data_ptr(), st), "lpa_halo_unpack_current")
-        if self.comm.has_right:
-            check(self.L.lpa_halo_unpack_current(self._g(), 1, h["r_hi"].data_ptr(), st), "lpa_halo_unpack_current")
-        check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
+                                                  h["r_hi"] if self.comm.has_right else None)
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
         return True
 
     def step(self, dt, laser=None):

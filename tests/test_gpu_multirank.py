@@ -55,6 +55,7 @@ def _run(rank, world, port, q):
     nx = NXG // world
     eng = PicEngine2D(nx, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
                       migrate_capacity=4096)
+    eng.overlap = world == 2       # 2 ranks: J / rho guard exchange behind the interior tiles; 3 ranks: in line
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
     mine = (x >= lo) & (x < hi)
     n = int(mine.sum())

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Compute-side cost of the slab (multi-rank) code path without a network: ONE process plays rank 0 of a
+periodic 2-slab ring whose other slab is an exact translated copy of itself, so what a neighbour would send
+through a face is what this rank sends through the opposite one (particle messages are translated by one
+slab width first).  Everything the N > 1 path does on the device runs -- edge / interior split of K1, halo and
+current pack / unpack, leaver scan, migration unpack, arrival area -- only the wire is replaced by a device
+copy.  Compare ms/step with bench.py at N = 1: the difference is what weak scaling loses before any
+communication cost.  (A tool: not part of the product path.)"""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from lambdapic_amd._lib import LPA_MIG_NATTR
+from lambdapic_amd.dist import SlabComm
+
+
+class MirrorComm(SlabComm):
+    def __init__(self, slab_width, migrate_capacity):
+        super().__init__(None, periodic=True, single=True)
+        self.size, self.rank, self.left, self.right = 2, 0, 1, 1
+        self.shift = float(slab_width)
+        self.mig_numel = 1 + LPA_MIG_NATTR * migrate_capacity
+        self.cap = migrate_capacity
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
+        recv_lo.copy_(send_hi)          # the left neighbour's high face == my own high face
+        recv_hi.copy_(send_lo)
+        if send_lo.numel() == self.mig_numel:      # particle message: the neighbour lives one slab further
+            recv_lo[1:1 + self.cap] += self.shift
+            recv_hi[1:1 + self.cap] += self.shift
+        return []
+
+    def barrier(self):
+        pass
+
+    def reduce_diagnostics(self, d):
+        return d
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nx", type=int, default=1024); ap.add_argument("--ny", type=int, default=1024)
+ap.add_argument("--ppc", type=int, default=64); ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--warmup", type=int, default=8); ap.add_argument("--sort-interval", type=int, default=20)
+ap.add_argument("--block-particles", type=int, default=8192)
+ap.add_argument("--overlap", action="store_true", help="edge tiles + J exchange on a second stream beside the interior")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dx = bench.LAMBDA0 / 20
+comm = MirrorComm(a.nx * dx, 32768)
+eng, dt, n = bench.build_engine(a, comm, dev)
+assert eng.migrate_capacity == 32768
+eng.overlap = a.overlap
+for _ in range(a.warmup):
+    eng.step(dt)
+eng.kernel_events = []
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    eng.step(dt)
+torch.cuda.synchronize(); el = time.perf_counter() - t0
+k_ms = float(np.sum([x.elapsed_time(y) for x, y in eng.kernel_events])) / a.steps
+d = eng.diagnostics()
+w = float(eng.species[0].cset.arr("w")[0].item())
+print(json.dumps({"what": "rank 0 of a mirrored 2-slab ring, no wire", "ms_per_step": 1e3 * el / a.steps,
+                  "particle_updates_per_s_per_gpu": n * a.steps / el, "k1_edge_plus_interior_ms": k_ms,
+                  "alive": d["nalive"][0], "particles": n,
+                  "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * w * -1.602176634e-19) - 1)}))
