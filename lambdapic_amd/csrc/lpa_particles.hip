@@ -256,7 +256,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     // share halo rows of E / B and flush into the same J lines -- meet in one L2 (measured effect on C2:
     // none, the staging is 4 % of the kernel's reads and the kernel is not HBM bound)
     const int nb = *n_blocks, chunk = (nb + 7) >> 3;
-    const int wb = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    // (an edge / interior part launch keeps the plain order: a run of tile columns per XCD would leave the
+    // XCDs that own the other part's columns idle -- measured 2x on the 3-D slab)
+    const int wb = part ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
     if ((int)blockIdx.x >= 8 * chunk || wb >= nb) return;  // block-uniform
     const int tile = blk_tile[wb];
     if (part) {  // LPA_PART_EDGE: the edge_cols tile columns at each x face; LPA_PART_INTERIOR: the others

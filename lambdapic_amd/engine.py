@@ -152,8 +152,8 @@ class PicEngine2D:
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         # hide the J / rho guard exchange behind the interior tiles?  Off by default in 2-D: without a wire the
-        # split step costs 2.61 ms against 2.44 ms unsplit on C2 (tools/bench_mirror.py), so it only pays when a
-        # 100 KB face message takes longer than ~0.15 ms; the 3-D engine (6.6 MB per face) keeps it on
+        # split step costs 2.45 ms against 2.40 ms unsplit on C2 (tools/bench_mirror.py), so it only pays when a
+        # 100 KB face message takes longer than ~0.05 ms; the 3-D engine (6.6 MB per face) keeps it on
         self.overlap = False
         self.defer_crossers = True
         self.fused_cpml = True

@@ -1,0 +1,28 @@
+"""the loop-back communicator of tools/bench_mirror*.py (see bench_mirror.py)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lambdapic_amd._lib import LPA_MIG_NATTR
+from lambdapic_amd.dist import SlabComm
+
+
+class MirrorComm(SlabComm):
+    def __init__(self, slab_width, migrate_capacity):
+        super().__init__(None, periodic=True, single=True)
+        self.size, self.rank, self.left, self.right = 2, 0, 1, 1
+        self.shift = float(slab_width)
+        self.mig_numel = 1 + LPA_MIG_NATTR * migrate_capacity
+        self.cap = migrate_capacity
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
+        recv_lo.copy_(send_hi)          # the left neighbour's high face == my own high face
+        recv_hi.copy_(send_lo)
+        if send_lo.numel() == self.mig_numel:      # particle message: the neighbour lives one slab further
+            recv_lo[1:1 + self.cap] += self.shift
+            recv_hi[1:1 + self.cap] += self.shift
+        return []
+
+    def barrier(self):
+        pass
+
+    def reduce_diagnostics(self, d):
+        return d
