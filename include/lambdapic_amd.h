@@ -312,15 +312,34 @@ const int32_t *lpa_sort_live_count(void *workspace);
  *      unpack: append the received particles to the arrival area [first_slot, first_slot +
  *              area_capacity) at the device-side cursor, adding shift_x to x (periodic wrap at
  *              the global edge, sync_particles_2d.c:168-182).  cursor > area_capacity = overflow. */
+/* Free-slot stacks of a tile-ordered store (optional): lpa_migrate_pack_edges_x records the slots its
+ * leavers free, per edge tile; lpa_migrate_unpack_tiled hands them to the arrivals of the same tile.  `count`
+ * has 2 * edge_cols * tiles_y (* tiles_z) entries (the tiles of the edge_cols columns at the low face, then
+ * those at the high face), `slot` `depth` entries per tile.  The caller zeroes `count` after every sort;
+ * edge_cols must cover every column a leaver can come from until the next sort. */
+typedef struct {
+    int32_t *count;
+    int32_t *slot;
+    int32_t edge_cols, depth;
+} lpa_free_slots;
+
 #define LPA_MIG_NATTR 9 /* x y z ux uy uz inv_gamma w id */
 int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
                        double *buf_hi, int64_t capacity, void *stream);
 /* the same scan restricted to the particles that can have left a tile-ordered store since its sort: the
  * `edge_cols` tile columns next to each x face (tile index is x-slowest) and the loose particles behind
  * t->n_sorted.  The caller chooses edge_cols from the age of the order (c*dt*age / tile width, rounded
- * up); the ranges are read from t->tile_off on the device.  2-D and 3-D tilings. */
+ * up); the ranges are read from t->tile_off on the device.  2-D and 3-D tilings.  `fs` (may be NULL): record
+ * the freed slots, see lpa_free_slots. */
 int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo,
-                             double xhi, double *buf_lo, double *buf_hi, int64_t capacity, void *stream);
+                             double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
+                             const lpa_free_slots *fs, void *stream);
+/* unpack for a tile-ordered store with free-slot stacks: an arrival whose tile (from its position on grid
+ * `g`) has a recorded free slot takes it and is pushed by the tiled kernel from the next step on; the others are
+ * appended to the arrival area exactly like lpa_migrate_unpack. */
+int lpa_migrate_unpack_tiled(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t,
+                             const lpa_free_slots *fs, int64_t first_slot, int64_t area_capacity,
+                             int32_t *cursor, const double *buf, int64_t capacity, double shift_x, void *stream);
 int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_capacity,
                        int32_t *cursor, const double *buf, int64_t capacity, double shift_x,
                        void *stream);

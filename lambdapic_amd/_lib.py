@@ -63,7 +63,14 @@ class lpa_push_params(C.Structure):
                 ("alo", C.c_double * 3), ("ahi", C.c_double * 3)]
 
 
+
+
+class lpa_free_slots(C.Structure):
+    _fields_ = [("count", C.c_void_p), ("slot", C.c_void_p), ("edge_cols", C.c_int32), ("depth", C.c_int32)]
+
+
 _G, _P, _T, _PP = C.POINTER(lpa_grid), C.POINTER(lpa_particles), C.POINTER(lpa_tiling), C.POINTER(lpa_push_params)
+_FS = C.POINTER(lpa_free_slots)
 _vp, _d, _i, _i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
 
 # name -> (restype, argtypes); every symbol include/lambdapic_amd.h declares
@@ -114,7 +121,8 @@ SIGNATURES = {
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp]),
-    "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _vp]),
+    "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp]),
+    "lpa_migrate_unpack_tiled": (_i, [_P, _G, _T, _FS, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),

@@ -155,6 +155,7 @@ class PicEngine2D:
         # split step costs 2.45 ms against 2.40 ms unsplit on C2 (tools/bench_mirror.py), so it only pays when a
         # 100 KB face message takes longer than ~0.05 ms; the 3-D engine (6.6 MB per face) keeps it on
         self.overlap = False
+        self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.defer_crossers = True
         self.fused_cpml = True
         self._axes = {}
@@ -364,6 +365,29 @@ class PicEngine2D:
             ws["tiling"].scratch[c] = idle.arr(a).data_ptr() if self.defer_crossers else None
         sp.tiling = ws["tiling"]
         sp.steps_since_sort = 0
+        self._reset_free_slots(ws, ws["tiling"].tiles_x, ws["tiling"].tiles_y, _lib.LPA_TILE_X)
+
+    FREE_SLOT_DEPTH = 64
+
+    def _reset_free_slots(self, ws, tiles_x, tiles_per_col, tile_x):
+        """free-slot stacks of the edge tile columns (lpa_free_slots): emptied after every sort; the columns
+        cover what a particle can leave the slab from until the next sort (< 1 cell per step)"""
+        ws["fs"] = None
+        if self.comm.size == 1:
+            return
+        cols = int(np.ceil((self.sort_interval + 2) / tile_x))
+        if 2 * cols > tiles_x:
+            return
+        n = 2 * cols * tiles_per_col
+        if ws.get("fs_count") is None or ws["fs_count"].numel() != n:
+            ws["fs_count"] = torch.zeros(n, dtype=torch.int32, device=self.device)
+            ws["fs_slot"] = torch.empty(n * self.FREE_SLOT_DEPTH, dtype=torch.int32, device=self.device)
+        else:
+            ws["fs_count"].zero_()
+        fs = _lib.lpa_free_slots()
+        fs.count, fs.slot = ws["fs_count"].data_ptr(), ws["fs_slot"].data_ptr()
+        fs.edge_cols, fs.depth = cols, self.FREE_SLOT_DEPTH
+        ws["fs"] = fs
 
     def _ws_checked(self, sp):
         ws = self._sort_ws(sp)
@@ -525,9 +549,13 @@ class PicEngine2D:
         xhi = self.x0 + (self.nx - 1) * self.dx + self.dx / 2
         # only the tile columns within drift range of an x face (and the loose particles) can hold leavers
         cols = self.leaver_columns(sp.steps_since_sort)
+        fs = ws.get("fs") if self.reuse_slots else None
+        if fs is not None and (cols == 0 or cols > fs.edge_cols):
+            fs = None        # the order is older than the stacks were sized for
         if cols:
             check(self.L.lpa_migrate_pack_edges_x(C.byref(pc), C.byref(sp.tiling), cols, xlo, xhi,
-                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap, st),
+                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
+                                                  C.byref(fs) if fs is not None else None, st),
                   "lpa_migrate_pack_edges_x")
         else:
             check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
@@ -542,10 +570,14 @@ class PicEngine2D:
         # crossed the periodic boundary: x > xmax_global -> x - Lx (sync_particles_2d.c:168-182)
         shift_lo = -self.Lx if (self.comm.rank == 0 and self.periodic_x) else 0.0
         shift_hi = self.Lx if (self.comm.rank == self.comm.size - 1 and self.periodic_x) else 0.0
-        check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_lo"].data_ptr(), cap,
-                                        shift_lo, st), "unpack lo")
-        check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, m["r_hi"].data_ptr(), cap,
-                                        shift_hi, st), "unpack hi")
+        for buf, shift in ((m["r_lo"], shift_lo), (m["r_hi"], shift_hi)):
+            if fs is not None:   # arrivals take the slots the leavers of their tile freed, when there are any
+                check(self.L.lpa_migrate_unpack_tiled(C.byref(pc), self._g(), C.byref(sp.tiling), C.byref(fs),
+                                                      sp.n_sorted, ws["area"], cur, buf.data_ptr(), cap, shift, st),
+                      "lpa_migrate_unpack_tiled")
+            else:
+                check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, buf.data_ptr(), cap,
+                                                shift, st), "lpa_migrate_unpack")
 
     # ---- moving window (MovingWindow callback, callback/utils.py:471-648) ---------------------------
     def remove_x_pml(self):

@@ -158,6 +158,7 @@ class PicEngine3D:
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
+        self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
         self._axes = {}
 
@@ -251,6 +252,29 @@ class PicEngine3D:
         ws["tiling"].n_sorted = n_live
         sp["tiling"] = ws["tiling"]
         sp["since"] = 0
+        self._reset_free_slots(ws)
+
+    FREE_SLOT_DEPTH = 64
+
+    def _reset_free_slots(self, ws):
+        """see PicEngine2D._reset_free_slots"""
+        ws["fs"] = None
+        t = ws["tiling"]
+        if self.comm.size == 1:
+            return
+        cols = int(np.ceil((self.sort_interval + 2) / _lib.LPA_TILE3_X))
+        if 2 * cols > t.tiles_x:
+            return
+        n = 2 * cols * t.tiles_y * t.tiles_z
+        if ws.get("fs_count") is None or ws["fs_count"].numel() != n:
+            ws["fs_count"] = torch.zeros(n, dtype=torch.int32, device=self.device)
+            ws["fs_slot"] = torch.empty(n * self.FREE_SLOT_DEPTH, dtype=torch.int32, device=self.device)
+        else:
+            ws["fs_count"].zero_()
+        fs = _lib.lpa_free_slots()
+        fs.count, fs.slot = ws["fs_count"].data_ptr(), ws["fs_slot"].data_ptr()
+        fs.edge_cols, fs.depth = cols, self.FREE_SLOT_DEPTH
+        ws["fs"] = fs
 
     # ---- guards / currents between slabs (sync_guard_fields_3d, sync_currents_3d) -------------------
     def _halo_bufs(self):
@@ -309,9 +333,15 @@ class PicEngine3D:
         xlo = self.x0 - self.d[0] / 2
         xhi = self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
         cols = int(np.ceil((sp["since"] + 1) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
-        if cols and 2 * cols <= self.n[0] // _lib.LPA_TILE3_X:   # only the edge tile columns + loose particles
+        if not (cols and 2 * cols <= self.n[0] // _lib.LPA_TILE3_X):
+            cols = 0
+        fs = ws.get("fs") if (self.reuse_slots and cols) else None
+        if fs is not None and cols > fs.edge_cols:
+            fs = None
+        if cols:   # only the edge tile columns + loose particles
             check(self.L.lpa_migrate_pack_edges_x(C.byref(sp["c"]), C.byref(sp["tiling"]), cols, xlo, xhi,
-                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap, st),
+                                                  m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
+                                                  C.byref(fs) if fs is not None else None, st),
                   "lpa_migrate_pack_edges_x")
         else:
             check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
@@ -325,10 +355,14 @@ class PicEngine3D:
             m["r_hi"][:1].zero_()
         shift_lo = -self.Lbox[0] if (self.comm.rank == 0 and self.periodic[0]) else 0.0
         shift_hi = self.Lbox[0] if (self.comm.rank == self.comm.size - 1 and self.periodic[0]) else 0.0
-        check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_lo"].data_ptr(), cap,
-                                        shift_lo, st), "unpack lo")
-        check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, m["r_hi"].data_ptr(), cap,
-                                        shift_hi, st), "unpack hi")
+        for buf, shift in ((m["r_lo"], shift_lo), (m["r_hi"], shift_hi)):
+            if fs is not None:
+                check(self.L.lpa_migrate_unpack_tiled(C.byref(sp["c"]), self._g(), C.byref(sp["tiling"]), C.byref(fs),
+                                                      sp["n_sorted"], area, cur, buf.data_ptr(), cap, shift, st),
+                      "lpa_migrate_unpack_tiled")
+            else:
+                check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, buf.data_ptr(), cap,
+                                                shift, st), "lpa_migrate_unpack")
 
     # ---- Maxwell with CPML layers (update_e/bfield_cpml_patches_3d, cpml.py:477-530) --------------------
     def update_efield(self, dt):
