@@ -1,6 +1,7 @@
 """Device-native diagnostics callbacks (mirrors of the reference's, without the HDF5 / plotting parts).
 
 ``get_fields`` -- `callback/utils.py:26-237`: whole-box field arrays (a z-plane in 3-D) on rank 0.
+``SetMomentum`` / ``SetTemperature`` / ``SetMomentumAndTemperature`` -- `callback/utils.py:842-1049` on the device.
 
 ``ExtractSpeciesDensity`` -- `callback/utils.py:240-293` on top of `callback/hdf5.py:402-482`: at stage
 ``current_deposition`` (which runs once per species, right after that species' deposit) the currents are
@@ -14,6 +15,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import constants
 
 
 class ExtractSpeciesDensity:
@@ -103,3 +106,129 @@ def get_fields(sim, fields, slice_at=None):
         for name in fields:
             out.append(_gather_slabs(sim, eng.grid.view(name)[g:-g, g:-g]))
     return out
+
+
+# ---- momentum / temperature initialisers (`callback/utils.py:842-1049`), on the device ----------------------
+def _species_arrays(sim, species):
+    """(ux, uy, uz, inv_gamma, alive) device views of one species' store, 2-D or 3-D engine"""
+    eng = sim.engine
+    if getattr(sim, "dimension", 2) == 3:
+        sp = eng.species[species.ispec]
+        d = sp["data"][:, : sp["n"]]
+        return d[3], d[4], d[5], d[6], ~torch.isnan(d[0])
+    sp = eng.species[species.ispec]
+    a = sp.cset.arr
+    n = sp.n
+    return a("ux")[:n], a("uy")[:n], a("uz")[:n], a("inv_gamma")[:n], ~torch.isnan(a("x")[:n])
+
+
+class SetMomentum:
+    """`callback/utils.py:842-888`: set (or add to) the momenta ``u = gamma beta`` of every live particle of a
+    species; ``inv_gamma`` follows.  Stage 'init', by default once at the first step.  Device native."""
+    stage = "init"
+    device_native = True
+
+    def __init__(self, species, momentum, interval=None, add=False):
+        self.species, self.momentum, self.add = species, [float(v) for v in momentum], add
+        self.interval = (lambda sim: sim.itime == 0) if interval is None else interval
+
+    def __call__(self, sim):
+        ux, uy, uz, ig, alive = _species_arrays(sim, self.species)
+        for u, t in zip((ux, uy, uz), self.momentum):
+            u[alive] = (u[alive] + t) if self.add else t
+        ig[alive] = torch.rsqrt(1 + ux[alive] ** 2 + uy[alive] ** 2 + uz[alive] ** 2)
+
+
+def sample_maxwell_juttner(size, theta, generator, device):
+    """gamma ~ Maxwell-Juettner(theta = kT / mc^2), isotropic directions -> (ux, uy, uz) device tensors.  The
+    three regimes of the reference (`callback/utils.py:988-1049`): gamma - 1 ~ Gamma(3/2, theta) for theta <= 0.01,
+    uniform proposal + rejection on the exact pdf up to theta = 0.5, Gamma(3, theta) proposal accepted with
+    probability beta above.  Other random streams than numpy's: statistically equivalent, not bit-equal."""
+    f64 = dict(dtype=torch.float64, device=device)
+    rand = lambda n: torch.rand(n, generator=generator, **f64)
+
+    def gamma_rv(shape_k, n):      # Gamma(k, scale = theta) from the sum / Box-Muller forms of k = 3/2 and 3
+        e = lambda: -torch.log1p(-rand(n))
+        if shape_k == 3:
+            return theta * (e() + e() + e())
+        z = torch.randn(n, generator=generator, **f64)
+        return theta * (e() + 0.5 * z * z)          # Gamma(1) + Gamma(1/2)
+
+    if theta <= 0.01:
+        g = 1.0 + gamma_rv(1.5, size)
+    elif theta <= 0.5:
+        from scipy.optimize import minimize_scalar
+        from scipy.special import kn
+        k2 = float(kn(2, 1.0 / theta))
+        pdf_np = lambda gg: gg * np.sqrt(gg * gg - 1.0) / (theta * k2) * np.exp(-gg / theta)
+        gmax = 1.0 + 10.0 * theta
+        fmax = -minimize_scalar(lambda gg: -pdf_np(gg), bounds=(1.0, gmax), method="bounded").fun
+        M = 1.1 * fmax + 1e-10
+        g = torch.empty(size, **f64)
+        have = 0
+        while have < size:
+            n = max(int(1.3 * (size - have) * M * (gmax - 1.0)) + 1024, size - have)   # expected acceptance
+            prop = 1.0 + (gmax - 1.0) * rand(n)
+            f = prop * torch.sqrt(prop * prop - 1.0) / (theta * k2) * torch.exp(-prop / theta)
+            ok = prop[M * rand(n) < f][: size - have]
+            g[have:have + ok.numel()] = ok
+            have += ok.numel()
+    else:
+        g = torch.empty(size, **f64)
+        have = 0
+        while have < size:
+            n = 2 * (size - have) + 1024
+            prop = gamma_rv(3, n)
+            beta = torch.sqrt(torch.clamp(1.0 - 1.0 / (prop * prop), min=0.0))
+            ok = prop[(prop >= 1.0) & (rand(n) < beta)][: size - have]
+            g[have:have + ok.numel()] = ok
+            have += ok.numel()
+    u = torch.sqrt(g * g - 1.0)
+    phi = 2 * np.pi * rand(size)
+    ct = 2.0 * rand(size) - 1.0
+    st = torch.sqrt(1.0 - ct * ct)
+    return u * st * torch.cos(phi), u * st * torch.sin(phi), u * ct
+
+
+class SetTemperature:
+    """`callback/utils.py:922-972`: momenta of a species from a Maxwell-Juettner distribution of the given
+    temperature [eV] (a list = anisotropic: uy, uz stretched by T_y / T_x, T_z / T_x like the reference);
+    ``add=True`` puts the thermal spread on top of the existing momenta.  Stage 'init', once by default."""
+    stage = "init"
+    device_native = True
+
+    def __init__(self, species, temperature, interval=None, add=False, seed=None):
+        self.species, self.add, self.seed = species, add, seed
+        self.temperature = [float(temperature)] * 3 if isinstance(temperature, (int, float)) else \
+            [float(t) for t in temperature]
+        self.interval = (lambda sim: sim.itime == 0) if interval is None else interval
+
+    def __call__(self, sim):
+        ux, uy, uz, ig, alive = _species_arrays(sim, self.species)
+        n = int(alive.sum().item())
+        if n == 0:
+            return
+        gen = torch.Generator(device=ux.device)
+        base = self.seed if self.seed is not None else (getattr(sim, "random_seed", None) or 0)
+        gen.manual_seed((int(base) * 1000003 + 7919 * self.species.ispec + 104729 * sim.comm.rank + sim.itime) % (2 ** 63))
+        theta = self.temperature[0] * constants.E_CHARGE / (self.species.m * constants.C_LIGHT ** 2)
+        tx, ty, tz = sample_maxwell_juttner(n, theta, gen, ux.device)
+        ty, tz = ty * (self.temperature[1] / self.temperature[0]), tz * (self.temperature[2] / self.temperature[0])
+        for u, t in zip((ux, uy, uz), (tx, ty, tz)):
+            u[alive] = (u[alive] + t) if self.add else t
+        ig[alive] = torch.rsqrt(1 + ux[alive] ** 2 + uy[alive] ** 2 + uz[alive] ** 2)
+
+
+class SetMomentumAndTemperature:
+    """`callback/utils.py:891-920`: bulk momentum first, thermal spread on top"""
+    stage = "init"
+    device_native = True
+
+    def __init__(self, species, momentum, temperature, interval=None, add=False, seed=None):
+        self._m = SetMomentum(species, momentum, interval, add=add)
+        self._t = SetTemperature(species, temperature, interval, add=True, seed=seed)
+        self.interval = self._m.interval
+
+    def __call__(self, sim):
+        self._m(sim)
+        self._t(sim)

@@ -4,6 +4,7 @@ mirrors, no mocks (reference tests/test_numerical_heating.py, tests/test_callbac
 docs/source/write_callbacks.rst 'External fields')."""
 import numpy as np
 import pytest
+import torch
 
 import oracle
 from oracle import driver
@@ -171,3 +172,30 @@ def test_extract_species_density_on_device():
     d = sim.engine.diagnostics()
     want = (-1 * ne.sum() + 2 * np_.sum()) * dx * dy * 1.602176634e-19
     assert d["charge"] == pytest.approx(want, rel=1e-9)
+
+
+def test_set_momentum_and_temperature_on_device():
+    """SetMomentum / SetTemperature / SetMomentumAndTemperature (callback/utils.py:842-1049) at stage 'init':
+    bulk momentum exact, thermal spread with the Maxwell-Juettner mean energy, inv_gamma consistent"""
+    from scipy.special import kn
+    from lambdapic_amd.callbacks import SetMomentum, SetMomentumAndTemperature
+    sim, _ = _sim(nx=64, ny=64, npx=1, npy=1, ppc=16, seed=4)
+    e = sim.species[0]
+    e.momentum_sigma = 0.0
+    sim.run(0, callbacks=[SetMomentum(e, [0.5, 0.0, -0.25])])
+    sp = sim.engine.species[0]
+    a = sp.cset.arr
+    n = sp.n
+    assert torch.all(a("ux")[:n] == 0.5) and torch.all(a("uz")[:n] == -0.25) and torch.all(a("uy")[:n] == 0.0)
+    assert float((a("inv_gamma")[:n] - 1 / np.sqrt(1 + 0.25 + 0.0625)).abs().max()) < 1e-15
+    T_eV = 51099.895                                        # theta = 0.1
+    sim2, _ = _sim(nx=64, ny=64, npx=1, npy=1, ppc=16, seed=4)
+    e2 = sim2.species[0]
+    e2.momentum_sigma = 0.0
+    sim2.run(0, callbacks=[SetMomentumAndTemperature(e2, [0.0, 0.0, 0.0], T_eV, seed=9)])
+    b = sim2.engine.species[0].cset.arr
+    ux, uy, uz, ig = (b(k)[:n] for k in ("ux", "uy", "uz", "inv_gamma"))
+    gam = torch.sqrt(1 + ux * ux + uy * uy + uz * uz)
+    assert float((ig * gam - 1).abs().max()) < 1e-14
+    assert float(gam.mean()) - 1 == pytest.approx(3 * 0.1 + kn(1, 10.0) / kn(2, 10.0) - 1, rel=0.03)
+    assert abs(float(ux.mean())) < 0.01
