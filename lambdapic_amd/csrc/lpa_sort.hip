@@ -390,6 +390,9 @@ __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
     return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
 }
 
+#ifndef LPA_ST_NBUF
+#define LPA_ST_NBUF 2
+#endif
 #ifndef LPA_ST_PREFETCH
 #define LPA_ST_PREFETCH 1
 #endif
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ cell_base,
     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ cell_off,
     const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped) {
-    __shared__ double s_val[2][ST_W];           // double buffered: one barrier per (attribute, window)
+    __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
     if (!hdr->prev_valid) return;
     const int t = blockIdx.x;
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                     if (db == db0 && dest[j] >= 0 && (dest[j] < db0 || dest[j] >= de0)) dst[dest[j]] = v[j];
                 }
                 for (int wb = db; wb < de; wb += ST_W, phase++) {
-                    double *buf = s_val[phase & 1];
+                    double *buf = s_val[LPA_ST_NBUF == 2 ? (phase & 1) : 0];
 #pragma unroll
                     for (int j = 0; j < ST_PT; j++) {
                         unsigned o = (unsigned)(dest[j] - wb);
@@ -472,6 +475,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                         int bi = wb - db + i;
                         if ((s_bits[bi >> 5] >> (bi & 31)) & 1u) dst[wb + i] = buf[i];
                     }
+                    if (LPA_ST_NBUF == 1) __syncthreads();   // single buffer: drained before it is refilled
                 }
             }
             __syncthreads();   // before the bitmap / buffers are reused
