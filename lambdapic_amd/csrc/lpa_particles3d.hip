@@ -320,14 +320,15 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols) {
     __shared__ double s_j[4][R3N];
     __shared__ double s_eb[6][E3N];
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), work blocks
-    // are in tile order: give every XCD a contiguous run of them, so that neighbouring tiles -- which
-    // share halo rows of E / B and flush into the same J lines -- meet in one L2 (measured effect on C2:
-    // none, the staging is 4 % of the kernel's reads and the kernel is not HBM bound)
+    // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
+    // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
+    // 4.51 ms per step, tools/exp_k13.sh with LPA_XCD_ORDER_3D) and idles XCDs in an edge / interior part launch
     const int nb = *n_blocks, chunk = (nb + 7) >> 3;
-    // (an edge / interior part launch keeps the plain order: a run of tile columns per XCD would leave the
-    // XCDs that own the other part's columns idle -- measured 2x on the 3-D slab)
+#ifdef LPA_XCD_ORDER_3D
     const int wb = part ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+#else
+    const int wb = (int)blockIdx.x;
+#endif
     if ((int)blockIdx.x >= 8 * chunk || wb >= nb) return;  // block-uniform
     const int tile = blk_tile[wb];
     const int begin = blk_begin[wb], end = blk_end[wb];
