@@ -565,12 +565,19 @@ class PicEngine3D:
         if part != _lib.LPA_PART_INTERIOR and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
             self.sort(i)
         ws = sp["ws"]
-        ws["count"].zero_()
+        # the edge part may run on a second stream beside the interior part: own overflow list + counter
+        if part == _lib.LPA_PART_EDGE:
+            if "overflow_edge" not in ws:
+                ws["overflow_edge"] = torch.empty_like(ws["overflow"])
+            ovf, cnt = ws["overflow_edge"], ws["counters"][2:3]
+        else:
+            ovf, cnt = ws["overflow"], ws["count"]
+        cnt.zero_()
         check(L.lpa_push_deposit_tiled_part_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
-                                               ws["overflow"].data_ptr(), ws["count"].data_ptr(), part, edge_cols,
+                                               ovf.data_ptr(), cnt.data_ptr(), part, edge_cols,
                                                st), "lpa_push_deposit_tiled_3d")
-        check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ws["overflow"].data_ptr(),
-                                         ws["count"].data_ptr(), sp["n_sorted"], st), "lpa_push_deposit_list_3d")
+        check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ovf.data_ptr(),
+                                         cnt.data_ptr(), sp["n_sorted"], st), "lpa_push_deposit_list_3d")
         loose = sp["n"] - sp["n_sorted"]        # arrival area: pushed by the global kernel until the next sort
         if loose > 0 and part != _lib.LPA_PART_INTERIOR:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), sp["n_sorted"], loose, st),
@@ -593,14 +600,20 @@ class PicEngine3D:
             return False
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        for i in range(len(self.species)):
-            self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+        for i in range(len(self.species)):      # a sort that is due runs here, before the two parts split
+            sp = self.species[i]
+            if sp["tiling"] is None or sp["since"] >= self.sort_interval:
+                self.sort(i)
         ready, done = torch.cuda.Event(), torch.cuda.Event()
         ready.record(main)
         h = self._halo_bufs()
+        # edge tiles, pack and exchange on the high-priority side stream, the interior tiles on the main stream
+        # at the same time (disjoint particles; both add into J with atomics; see PicEngine2D)
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
+            for i in range(len(self.species)):
+                self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
             self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
             self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
             done.record(self._side)
