@@ -81,6 +81,42 @@ class SlabComm:
                     recv_hi.copy_(r_hi)
         return reqs
 
+    def exchange_many(self, sets):
+        """several face exchanges in ONE grouped send / recv round; ``sets`` = [(send_lo, send_hi, recv_lo,
+        recv_hi), ...].  Every rank lists its sets in the same order; per set the posting order is the one
+        of ``exchange`` (sends hi, lo -- receives lo, hi), so messages between one pair of ranks still match
+        in order when both neighbours are the same rank."""
+        if self.size == 1:
+            for s_ in sets:
+                self.exchange(*s_)
+            return []
+        grp = self.p2p_group
+        staged = sets[0][0].is_cuda and dist.get_backend(grp) == "gloo"
+        ops, back = [], []
+        for k, (send_lo, send_hi, recv_lo, recv_hi) in enumerate(sets):
+            if staged:
+                s_lo, s_hi = send_lo.cpu(), send_hi.cpu()
+                r_lo, r_hi = torch.empty_like(recv_lo, device="cpu"), torch.empty_like(recv_hi, device="cpu")
+                back.append((recv_lo, r_lo, recv_hi, r_hi))
+            else:
+                s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
+            if self.has_right:
+                ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp, tag=2 * k + 1))
+            if self.has_left:
+                ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp, tag=2 * k))
+                ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp, tag=2 * k + 1))
+            if self.has_right:
+                ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp, tag=2 * k))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        for r in reqs:
+            r.wait()
+        for recv_lo, r_lo, recv_hi, r_hi in back:
+            if self.has_left:
+                recv_lo.copy_(r_lo)
+            if self.has_right:
+                recv_hi.copy_(r_hi)
+        return reqs
+
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         """diagnostics only (never inside the step): the reference's scalar reductions (energy, charge, live
         count); a device tensor is staged through the host when the control group is gloo"""

@@ -535,6 +535,12 @@ class PicEngine2D:
         neighbours in one fixed-size message per face (count in band, no host sync)."""
         if self.comm.size == 1:
             return
+        m, fs = self._mig_pack(ispec)
+        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        self._mig_unpack(ispec, m, fs)
+
+    def _mig_pack(self, ispec):
+        """leavers of species ``ispec`` into its two face messages; returns (buffers, free-slot stacks)"""
         sp = self.species[ispec]
         ws = self._sort_ws(sp)
         cap = self.migrate_capacity
@@ -564,7 +570,12 @@ class PicEngine2D:
             m["r_lo"][:1].zero_()    # open face: nothing arrives (count = 0)
         if not self.comm.has_right:
             m["r_hi"][:1].zero_()
-        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        return m, fs
+
+    def _mig_unpack(self, ispec, m, fs):
+        sp = self.species[ispec]
+        ws, cap, st = self._sort_ws(sp), self.migrate_capacity, self.stream
+        pc = sp.cset.cstruct(sp.n)
         cur = ws["counters"][1:2].data_ptr()
         # arrivals through my low face come from the left neighbour; at the global low edge they
         # crossed the periodic boundary: x > xmax_global -> x - Lx (sync_particles_2d.c:168-182)
@@ -578,6 +589,27 @@ class PicEngine2D:
             else:
                 check(self.L.lpa_migrate_unpack(C.byref(pc), sp.n_sorted, ws["area"], cur, buf.data_ptr(), cap,
                                                 shift, st), "lpa_migrate_unpack")
+
+    def sync_currents_and_particles(self):
+        """the J / rho guard fold and the migration of every species in ONE message round (the reference
+        issues them back to back: sync_currents, then sync_particles, simulation.py:1155-1200): one grouped
+        send / recv instead of 1 + nspecies -- every round costs a launch and a handshake with both
+        neighbours"""
+        if self.comm.size == 1:
+            self.sync_currents()
+            return
+        n = 4 * self.ng * self.grid.NY
+        h = {k: v[:n] for k, v in self._halo_bufs().items()}
+        self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
+        packed = [self._mig_pack(i) for i in range(len(self.species)) if self.species[i].n]
+        idx = [i for i in range(len(self.species)) if self.species[i].n]
+        self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])] +
+                                [(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"]) for m, _ in packed])
+        self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
+                                                  h["r_hi"] if self.comm.has_right else None)
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
+        for i, (m, fs) in zip(idx, packed):
+            self._mig_unpack(i, m, fs)
 
     # ---- moving window (MovingWindow callback, callback/utils.py:471-648) ---------------------------
     def remove_x_pml(self):
@@ -722,12 +754,18 @@ class PicEngine2D:
                 if sp.tiling is None or sp.steps_since_sort >= self.sort_interval:
                     self.sort(i)
         self.reset_current()
-        if not (tiled and self.overlap and self.push_deposit_overlapped(dt)):
+        if tiled and self.overlap and self.push_deposit_overlapped(dt):
+            for i in range(len(self.species)):
+                self.sync_particles(i)
+        else:
             for i in range(len(self.species)):
                 self.push_deposit(i, dt, tiled=tiled)
-            self.sync_currents()
-        for i in range(len(self.species)):
-            self.sync_particles(i)
+            if tiled:
+                self.sync_currents_and_particles()
+            else:
+                self.sync_currents()
+                for i in range(len(self.species)):
+                    self.sync_particles(i)
         self.update_bfield(0.5 * dt)
         self.sync_guard_fields(B)
         self.update_efield(0.5 * dt)

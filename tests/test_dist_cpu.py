@@ -85,6 +85,16 @@ def _worker(rank, world, port, nx_loc, ny, q):
                 and not J[:NG].any() and not J[NG + nx_loc:].any()
         else:
             ok_fold = True
+        # several exchanges in one grouped round: set k carries 100 k + rank (lo face) / + 0.5 (hi face)
+        ok_many = True
+        bufs2 = [(torch.full((4 + k,), 100.0 * k + rank, dtype=torch.float64),
+                  torch.full((4 + k,), 100.0 * k + rank + 0.5, dtype=torch.float64),
+                  torch.zeros(4 + k, dtype=torch.float64), torch.zeros(4 + k, dtype=torch.float64)) for k in range(3)]
+        comm.exchange_many(bufs2)
+        lft, rgt = (rank - 1) % world, (rank + 1) % world
+        for k, (_, _, r_lo, r_hi) in enumerate(bufs2):
+            ok_many = ok_many and bool(torch.all(r_lo == 100.0 * k + lft + 0.5)) and \
+                bool(torch.all(r_hi == 100.0 * k + rgt))
         # scalar diagnostics: one all-reduce over the ranks (floats, ints and per-species lists)
         d = comm.reduce_diagnostics({"field_energy": 1.5 + rank, "charge": -2.0, "kinetic": [0.25 * rank, 1.0],
                                      "nalive": [10 + rank, 7]})
@@ -92,7 +102,7 @@ def _worker(rank, world, port, nx_loc, ny, q):
         ok_diag = d == {"field_energy": 1.5 * w + w * (w - 1) / 2, "charge": -2.0 * w,
                         "kinetic": [0.25 * w * (w - 1) / 2, 1.0 * w], "nalive": [10 * w + w * (w - 1) // 2, 7 * w]} \
             and all(isinstance(v, int) for v in d["nalive"])
-        q.put((rank, bool(ok_guard), bool(ok_fold) and bool(ok_diag)))
+        q.put((rank, bool(ok_guard), bool(ok_fold) and bool(ok_diag) and ok_many))
     finally:
         dist.destroy_process_group()
 

@@ -29,6 +29,11 @@ class _Mirror(SlabComm):
             recv_hi[1:1 + self.cap] += self.shift
         return []
 
+    def exchange_many(self, sets):
+        for s_ in sets:
+            self.exchange(*s_)
+        return []
+
 
 def _run(reuse, nsteps=18):
     nx, ny, ppc = 128, 64, 8

@@ -21,6 +21,11 @@ class MirrorComm(SlabComm):
             recv_hi[1:1 + self.cap] += self.shift
         return []
 
+    def exchange_many(self, sets):
+        for s_ in sets:
+            self.exchange(*s_)
+        return []
+
     def barrier(self):
         pass
 
