@@ -211,6 +211,125 @@ class DevicePatches:
             self.sim.engine.sync_particles(i)
 
 
+class _CommFacade:
+    """the handful of ``mpi4py`` communicator calls the reference's callbacks use (`sim.mpi.comm.gather`,
+    ``.Barrier``, ``.bcast``, ``.allreduce``, ``.Get_rank`` ...; `callback/utils.py:80,121`, `callback/hdf5.py`)
+    on top of ``torch.distributed`` object collectives -- control plane only, never inside the step"""
+
+    def __init__(self, comm):
+        self._c = comm
+
+    def Get_rank(self):
+        return self._c.rank
+
+    def Get_size(self):
+        return self._c.size
+
+    def Barrier(self):
+        self._c.barrier()
+
+    barrier = Barrier
+
+    def gather(self, obj, root=0):
+        if self._c.size == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self._c.size if self._c.rank == root else None
+        dist.gather_object(obj, out, dst=root, group=self._c.group)
+        return out
+
+    def bcast(self, obj, root=0):
+        if self._c.size == 1:
+            return obj
+        import torch.distributed as dist
+        box = [obj]
+        dist.broadcast_object_list(box, src=root, group=self._c.group)
+        return box[0]
+
+    def allgather(self, obj):
+        if self._c.size == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self._c.size
+        dist.all_gather_object(out, obj, group=self._c.group)
+        return out
+
+    def allreduce(self, value):
+        """sum of a python / numpy scalar or array over the ranks"""
+        parts = self.allgather(value)
+        total = parts[0]
+        for v in parts[1:]:
+            total = total + v
+        return total
+
+    def reduce(self, value, root=0):
+        parts = self.gather(value, root)
+        if parts is None:
+            return None
+        total = parts[0]
+        for v in parts[1:]:
+            total = total + v
+        return total
+
+
+class MPIFacade:
+    """``sim.mpi`` as callbacks see it (`core/mpi/mpi_manager.py:23-298`): ``rank``, ``size``, ``comm`` and the
+    split ``sync_*_start`` / ``_wait`` brackets.  On the device slab the exchange is issued by ``_start`` (it is
+    asynchronous on the stream anyway) and ``_wait`` has nothing left to do; the handle is ``None`` with one
+    rank, like the reference's (`mpi_manager.py:111-195`)."""
+
+    def __init__(self, sim):
+        self._sim = sim
+        self.comm = _CommFacade(sim.comm)
+
+    @property
+    def rank(self):
+        return self._sim.comm.rank
+
+    @property
+    def size(self):
+        return self._sim.comm.size
+
+    def sync_guard_fields(self, attrs=("ex", "ey", "ez", "bx", "by", "bz")):
+        self._sim.patches.sync_guard_fields(list(attrs))
+
+    def sync_guard_fields_start(self, attrs=("ex", "ey", "ez", "bx", "by", "bz")):
+        if self.size == 1:
+            return None
+        self.sync_guard_fields(attrs)
+        return ("guard_fields", tuple(attrs))
+
+    def sync_guard_fields_wait(self, handle):
+        return None
+
+    def sync_currents(self):
+        self._sim.patches.sync_currents()
+
+    def sync_currents_start(self):
+        if self.size == 1:
+            return None
+        self.sync_currents()
+        return ("currents",)
+
+    def sync_currents_wait(self, handle):
+        return None
+
+    def sync_particles(self, ispec=None):
+        if ispec is None:
+            self._sim.patches.sync_particles()
+        else:
+            self._sim.engine.sync_particles(ispec)
+
+    def sync_particles_start(self, ispec=None):
+        if self.size == 1:
+            return None
+        self.sync_particles(ispec)
+        return ("particles", ispec)
+
+    def sync_particles_wait(self, handle):
+        return None
+
+
 class MovingWindow:
     """Mirror of the reference's ``MovingWindow`` callback (`callback/utils.py:471-648`): stage
     ``start``; once ``sim.time >= start_time`` (default Lx / c) the x layers are removed and the
@@ -269,6 +388,7 @@ class Simulation:
             raise ValueError("dt_cfl must be <= 1")
         self.cpml_thickness = int(cpml_thickness)
         self.comm = comm or SlabComm(None, periodic=bc["xmin"] == "periodic")
+        self.mpi = MPIFacade(self)          # what callbacks know as sim.mpi (rank, size, comm, sync_*_start/_wait)
         self.nx, self.ny, self.dx, self.dy = int(nx), int(ny), float(dx), float(dy)
         if self.nx % self.comm.size or (self.nx // self.comm.size) % npatch_x or self.ny % npatch_y:
             raise ValueError("nx must split evenly over ranks and patches")

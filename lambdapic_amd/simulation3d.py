@@ -17,7 +17,7 @@ from .dist import SlabComm
 from .engine3d import ATTRS3, SIDES3, PicEngine3D
 from .fields import FIELD_ATTRS, Fields3D, from_device_layout, to_device_layout
 from .particles import ParticlesBase
-from .simulation import Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
+from .simulation import MPIFacade, Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
 
 
 class Patch3D:
@@ -109,6 +109,7 @@ class Simulation3D:
             raise ValueError("dt_cfl must be <= 1")
         self.boundary_conditions, self.cpml_thickness = bc, int(cpml_thickness)
         self.comm = comm or SlabComm(None, periodic=bc["xmin"] == "periodic")
+        self.mpi = MPIFacade(self)          # what callbacks know as sim.mpi (rank, size, comm, sync_*_start/_wait)
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.dx, self.dy, self.dz = float(dx), float(dy), float(dz)
         if self.nx % self.comm.size or (self.nx // self.comm.size) % npatch_x or self.ny % npatch_y or self.nz % npatch_z:

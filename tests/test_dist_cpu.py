@@ -114,11 +114,17 @@ def test_slab_ring_exchange(world):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, 8, 10, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:          # a worker stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), "guard exchange mismatch"
     assert all(r[2] for r in res), "current fold mismatch"

@@ -85,11 +85,17 @@ def _launch(world):
     port = _free_port()
     procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:          # a worker stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     trace = sum(r[1] for r in res)
     fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
     return trace, fields
@@ -159,6 +165,21 @@ def _run_laser_target(rank, world, port, q):
             assert whole == [None, None]
     else:
         assert np.array_equal(whole[0], fields["ey"]) and np.array_equal(whole[1], fields["rho"])
+    # sim.mpi as the reference's callbacks use it (rank / size / comm.gather / Barrier / split sync brackets)
+    assert (sim.mpi.rank, sim.mpi.size) == (rank, world) and sim.mpi.comm.Get_rank() == rank
+    got = sim.mpi.comm.gather({"rank": rank, "n": int(d["nalive"][0])})
+    everyone = sim.mpi.comm.allgather(int(d["nalive"][0]))        # (collectives: every rank calls them)
+    if rank == 0:
+        assert [g_["rank"] for g_ in got] == list(range(world))
+        assert sum(g_["n"] for g_ in got) == sum(everyone)
+    else:
+        assert got is None
+    assert sim.mpi.comm.bcast("hello" if rank == 0 else None) == "hello"
+    assert sim.mpi.comm.allreduce(np.array([1.0, rank])).tolist() == [world, sum(range(world))]
+    h = sim.mpi.sync_guard_fields_start(["ex", "ey", "ez"])
+    assert (h is None) == (world == 1)
+    sim.mpi.sync_guard_fields_wait(h)
+    sim.mpi.comm.Barrier()
     q.put((rank, np.array(trace), fields))
     if world > 1:
         dist.barrier()
@@ -171,11 +192,17 @@ def _launch_lt(world):
     port = _free_port()
     procs = [ctx.Process(target=_run_laser_target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:          # a worker stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     trace = sum(r[1] for r in res)
     fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
     return trace, fields
@@ -238,11 +265,17 @@ def _launch_window(world):
     port = _free_port()
     procs = [ctx.Process(target=_run_window, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
     trace = sum(r[1] for r in res)
     fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
     return trace, fields
@@ -308,11 +341,17 @@ def _launch_3d(world):
     port = _free_port()
     procs = [ctx.Process(target=_run_3d, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:          # a worker stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.terminate()
     trace = sum(r[1] for r in res)
     fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
     return trace, fields
@@ -396,11 +435,17 @@ def test_3d_laser_target_chain_matches_single_rank():
         port = _free_port()
         procs = [ctx.Process(target=_run_3d_open, args=(r, world, port, q)) for r in range(world)]
         for p in procs:
+            p.daemon = True
             p.start()
-        res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
+        try:
+            res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
         return sum(r[1] for r in res), {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
 
     t1, f1 = launch(1)
@@ -460,11 +505,17 @@ def test_moving_window_3d_chain_matches_single_rank():
         port = _free_port()
         procs = [ctx.Process(target=_run_window_3d, args=(r, world, port, q)) for r in range(world)]
         for p in procs:
+            p.daemon = True
             p.start()
-        res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
+        try:
+            res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
         return sum(r[1] for r in res), {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
 
     t1, f1 = launch(1)
