@@ -645,7 +645,32 @@ def g12_cpml_laser_3d():
     np.savez_compressed(OUT / "g12_cpml_laser_3d.npz", **out)
 
 
+def g13_sync_3d():
+    """3-D guard copy and current fold of ONE patch that is its own periodic neighbour through all 26
+    boundaries (`core/patch/sync_fields3d.c:84-348,350-612`): what a one-slab-per-GPU 3-D run does locally.
+    Pins the oracle's periodic_guard_fill / periodic_current_fold and the device's lpa_guard_wrap /
+    lpa_current_fold in 3-D."""
+    import types
+    from lambdapic_amd.fields import Fields3D
+    sf = oracle.ref_module("patch", "sync_fields3d")
+    rng = np.random.default_rng(SEED + 13)
+    nx, ny, nz, ng = 8, 6, 10, 3
+    f = Fields3D(nx, ny, nz, 1e-7, 1e-7, 1e-7, 0.0, 0.0, 0.0, ng)
+    out = dict(nx=nx, ny=ny, nz=nz, ng=ng)
+    for a in f.attrs:
+        getattr(f, a)[...] = rng.normal(size=f.shape)
+    out.update(snap(f, f.attrs, "in_"))
+    patch = types.SimpleNamespace(neighbor_ipatch=np.zeros(26, dtype=np.intp))
+    sf.sync_guard_fields_3d([f], [patch], ["ex", "ey", "ez", "bx", "by", "bz"], 1, nx, ny, nz, ng)
+    sf.sync_currents_3d([f], [patch], 1, nx, ny, nz, ng)
+    out.update(snap(f, f.attrs, "out_"))
+    np.savez_compressed(OUT / "g13_sync_3d.npz", **out)
+
+
 def main():
+    if "--only-g13" in sys.argv:
+        g13_sync_3d()
+        return
     if "--only-g11" in sys.argv:
         g11_laser_profiles()
         return
@@ -667,6 +692,7 @@ def main():
     g10_laser(np.random.default_rng(SEED + 10))
     g11_laser_profiles()
     g12_cpml_laser_3d()
+    g13_sync_3d()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

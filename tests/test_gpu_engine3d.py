@@ -228,3 +228,20 @@ def test_3d_tiled_equals_global_and_continuity_at_c5_slab_size():
     res = ((rho - rho_prev) / dt + (jx - torch.roll(jx, 1, 0)) / dx + (jy - torch.roll(jy, 1, 1)) / dy
            + (jz - torch.roll(jz, 1, 2)) / dz)
     assert res.abs().max().item() <= 1e-10 * rho.abs().max().item() / dt
+
+
+def test_guard_wrap_and_current_fold_3d_vs_reference_golden(golden):
+    """lpa_guard_wrap / lpa_current_fold on a 3-D slab that is its own periodic neighbour against the
+    reference's sync_guard_fields_3d / sync_currents_3d (g13: one patch, 26 self neighbours)"""
+    g = golden("g13_sync_3d")
+    nx, ny, nz, ng = (int(g[k]) for k in ("nx", "ny", "nz", "ng"))
+    eng = PicEngine3D(nx, ny, nz, 1e-7, 1e-7, 1e-7, ng, tiled=False)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+        eng.upload_field(a, g["in_" + a])
+    eng.sync_guard_fields(1)
+    eng.sync_guard_fields(2)
+    eng.sync_currents()
+    for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+        assert np.array_equal(eng.download_field(a), g["out_" + a]), a
+    for a in ("jx", "jy", "jz", "rho"):
+        assert_close(eng.download_field(a), g["out_" + a], 1e-14, what=a)

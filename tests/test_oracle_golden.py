@@ -309,3 +309,21 @@ def test_cpml_and_laser_3d_vs_reference(golden):
                          int(g["iz_end"]), g["ey_source"], g["ez_source"])
     for a in ("bx", "by", "bz"):
         assert_close(getattr(f, a), g["lout_" + a], 1e-13, what="laser " + a)
+
+
+def test_g13_sync_3d_single_periodic_patch(golden):
+    """the reference's sync_guard_fields_3d / sync_currents_3d on one patch that is its own neighbour through
+    all 26 boundaries (core/patch/sync_fields3d.c) against the oracle's periodic fill / fold"""
+    from lambdapic_amd.fields import Fields3D
+    from oracle import sync
+    g = golden("g13_sync_3d")
+    nx, ny, nz, ng = (int(g[k]) for k in ("nx", "ny", "nz", "ng"))
+    f = Fields3D(nx, ny, nz, 1e-7, 1e-7, 1e-7, 0.0, 0.0, 0.0, ng)
+    for a in f.attrs:
+        getattr(f, a)[...] = g["in_" + a]
+    sync.periodic_guard_fill(f, ["ex", "ey", "ez", "bx", "by", "bz"])
+    sync.periodic_current_fold(f)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+        assert np.array_equal(getattr(f, a), g["out_" + a]), a           # copies: bit exact
+    for a in ("jx", "jy", "jz", "rho"):
+        assert_close(getattr(f, a), g["out_" + a], 1e-14, what=a)        # sums of up to 8 terms
