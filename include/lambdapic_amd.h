@@ -281,6 +281,8 @@ int lpa_deposit_3d(const lpa_grid *g, const lpa_particles *p, double dt, double 
  * does for a patch that is its own neighbour (core/patch/sync_particles_2d.c:168-182); the fused
  * kernels apply it themselves, the split path calls this after the deposit */
 int lpa_wrap_positions_2d(const lpa_particles *p, const lpa_push_params *pp, void *stream);
+/* 3-D twin (core/patch/sync_particles_3d.c with a self neighbour; the fused 3-D kernels apply it themselves) */
+int lpa_wrap_positions_3d(const lpa_particles *p, const lpa_push_params *pp, void *stream);
 
 /* ---- cell-index sort (replaces sort_particles_patches_2d, core/sort/cpu2d.c:220-303, as driven
  *      by ParticleSort2D.__call__, core/sort/particle_sort.py:196-211).  Out of place: `src` is

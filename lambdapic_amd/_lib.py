@@ -114,6 +114,7 @@ SIGNATURES = {
     "lpa_push_position_2d": (_i, [_P, _d, _vp]),
     "lpa_deposit_2d": (_i, [_G, _P, _d, _d, _vp]),
     "lpa_wrap_positions_2d": (_i, [_P, _PP, _vp]),
+    "lpa_wrap_positions_3d": (_i, [_P, _PP, _vp]),
     "lpa_interpolate_3d": (_i, [_G, _P, _vp]),
     "lpa_deposit_3d": (_i, [_G, _P, _d, _d, _vp]),
     "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),

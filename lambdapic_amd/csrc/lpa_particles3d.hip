@@ -528,6 +528,28 @@ static PushK3 make_pushk3(const lpa_push_params *pp) {
     return k;
 }
 
+__global__ void __launch_bounds__(256) k_wrap_positions_3d(PartV p, PushK3 k) {
+    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ip >= p.n) return;
+    if (p.dead && p.dead[ip]) return;
+    double x = p.x[ip], y = p.y[ip], z = p.z[ip];
+    if (isnan(x) || isnan(y) || isnan(z)) return;
+    finish_position_3d(x, y, z, k);
+    p.x[ip] = x; p.y[ip] = y; p.z[ip] = z;
+}
+
+extern "C" int lpa_wrap_positions_3d(const lpa_particles *p, const lpa_push_params *pp, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 3) && pp, "lpa_wrap_positions_3d: bad args");
+    if (p->n == 0 || !pp->wrap) return LPA_OK;
+    lpa_push_params q = *pp;
+    if (!(q.dt > 0)) q.dt = 1.0;
+    if (!(q.m > 0)) q.m = 1.0;
+    hipLaunchKernelGGL(k_wrap_positions_3d, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, make_partv(p), make_pushk3(&q));
+    LPA_CHECK_LAUNCH("lpa_wrap_positions_3d");
+    return LPA_OK;
+}
+
 static int check_push3(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const char *name) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(p, 3), "%s: bad particle store", name);

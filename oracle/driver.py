@@ -150,11 +150,7 @@ def step_3d_periodic(f, parts, dt, species, box_lo, box_hi):
         oracle.unified_boris_pusher_cpu_3d([p], [f], 1, dt, q, m)
     sync.periodic_current_fold(f)
     for p in parts:   # Patches.sync_particles with a self neighbour: periodic shift of leavers
-        for a, lo, hi in zip(("x", "y", "z"), box_lo, box_hi):
-            v = getattr(p, a)
-            L = hi - lo
-            v[v > hi] -= L
-            v[v < lo] += L
+        sync.periodic_fold_positions(p, box_lo, box_hi)
     oracle.update_bfield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, B)
     oracle.update_efield_3d(f, 0.5 * dt); sync.periodic_guard_fill(f, E)
 

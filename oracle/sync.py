@@ -180,3 +180,17 @@ def periodic_current_fold(f):
         conv[...] = 0.0
         conv[tuple(slice(ng, -ng) for _ in range(nd))] = out
         arr[...] = np.roll(conv, -ng, axis=tuple(range(nd)))
+
+
+def periodic_fold_positions(p, lo, hi, axes=("x", "y", "z")):
+    """what Patches.sync_particles does to a particle that left a patch which is its own periodic neighbour
+    (`core/patch/sync_particles_2d.c:168-182`, `sync_particles_3d.c`: the copy that re-enters is shifted by the
+    box length): fold the coordinates of the live particles into [lo, hi] per axis.  Pinned by g7 (2-D) and
+    g14 (3-D, bit exact)."""
+    live = ~p.is_dead
+    for a, l, h in zip(axes, lo, hi):
+        v = getattr(p, a)
+        L = h - l
+        v[live & (v > h)] -= L
+        v[live & (v < l)] += L
+

@@ -667,7 +667,46 @@ def g13_sync_3d():
     np.savez_compressed(OUT / "g13_sync_3d.npz", **out)
 
 
+def g14_sync_particles_3d():
+    """3-D particle ownership on ONE patch that is its own periodic neighbour (`core/patch/sync_particles_3d.c`
+    get_npart_to_extend_3d :362-488, fill_particles_from_boundary_3d :490-...; orchestration
+    `core/patch/patch.py:739-763`): particles pushed out through faces, edges and corners come back shifted by
+    the box length; the leaver's old slot dies.  Pins the periodic fold the 3-D step applies."""
+    import types
+    from lambdapic_amd.particles import ParticlesBase
+    mod = oracle.ref_module("patch", "sync_particles_3d")
+    rng = np.random.default_rng(SEED + 14)
+    nx, ny, nz = 8, 6, 10
+    dx, dy, dz = 1.0e-7, 1.5e-7, 0.8e-7
+    n = 900
+    q = ParticlesBase(0, 0)
+    q.initialize(n)
+    shift = rng.uniform(-0.95, 0.95, (3, n))
+    q.x[:] = (rng.uniform(-0.5, nx - 0.5, n) + shift[0]) * dx
+    q.y[:] = (rng.uniform(-0.5, ny - 0.5, n) + shift[1]) * dy
+    q.z[:] = (rng.uniform(-0.5, nz - 0.5, n) + shift[2]) * dz
+    q.ux[:] = rng.normal(size=n)
+    q.w[:] = rng.uniform(1, 2, n)
+    q.is_dead[::11] = True
+    out = dict(nx=nx, ny=ny, nz=nz, dx=dx, dy=dy, dz=dz)
+    out.update(snap(q, ["x", "y", "z", "ux", "w", "_id", "is_dead"], "pin_"))
+    patch = types.SimpleNamespace(neighbor_ipatch=np.zeros(26, dtype=np.intp), xmin=0.0, xmax=(nx - 1) * dx,
+                                  ymin=0.0, ymax=(ny - 1) * dy, zmin=0.0, zmax=(nz - 1) * dz)
+    ext, inc, outg, alive = mod.get_npart_to_extend_3d([q], [patch], 1, dx, dy, dz)
+    if ext[0] > 0:
+        q.extend(int(ext[0]))
+    mod.fill_particles_from_boundary_3d([q], [patch], inc, outg, 1, dx, dy, dz,
+                                        -dx / 2, nx * dx - dx / 2, -dy / 2, ny * dy - dy / 2,
+                                        -dz / 2, nz * dz - dz / 2, q.attrs)
+    out["npart_alive"] = np.asarray(alive)
+    out.update(snap(q, ["x", "y", "z", "ux", "w", "_id", "is_dead"], "pout_"))
+    np.savez_compressed(OUT / "g14_sync_particles_3d.npz", **out)
+
+
 def main():
+    if "--only-g14" in sys.argv:
+        g14_sync_particles_3d()
+        return
     if "--only-g13" in sys.argv:
         g13_sync_3d()
         return
@@ -693,6 +732,7 @@ def main():
     g11_laser_profiles()
     g12_cpml_laser_3d()
     g13_sync_3d()
+    g14_sync_particles_3d()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

@@ -245,3 +245,37 @@ def test_guard_wrap_and_current_fold_3d_vs_reference_golden(golden):
         assert np.array_equal(eng.download_field(a), g["out_" + a]), a
     for a in ("jx", "jy", "jz", "rho"):
         assert_close(eng.download_field(a), g["out_" + a], 1e-14, what=a)
+
+
+def test_periodic_fold_3d_vs_reference_golden(golden):
+    """lpa_wrap_positions_3d (the fold the fused 3-D kernels apply after the deposit) against the reference's
+    3-D particle sync on a self-periodic patch (g14): bit exact"""
+    import ctypes as C
+    import torch
+    from lambdapic_amd import _lib
+    g = golden("g14_sync_particles_3d")
+    n3 = [int(g[k]) for k in ("nx", "ny", "nz")]
+    d3 = [float(g[k]) for k in ("dx", "dy", "dz")]
+    live = ~g["pin_is_dead"]
+    n = int(live.sum())
+    data = torch.from_numpy(np.stack([g["pin_" + a][live] for a in ("x", "y", "z")])).cuda().contiguous()
+    zeros = torch.zeros(n, dtype=torch.float64, device="cuda")
+    p = _lib.lpa_particles()
+    p.n = n
+    p.x, p.y, p.z = (data[k].data_ptr() for k in range(3))
+    p.ux = p.uy = p.uz = p.inv_gamma = p.w = zeros.data_ptr()
+    for k in range(6):
+        p.part_eb[k] = None
+    p.id, p.is_dead = None, None
+    pp = _lib.lpa_push_params()
+    pp.dt, pp.q, pp.m, pp.wrap = 1.0, 1.0, 1.0, 7
+    for a in range(3):
+        pp.lo[a], pp.hi[a] = -d3[a] / 2, n3[a] * d3[a] - d3[a] / 2
+    _lib.check(_lib.lib().lpa_wrap_positions_3d(C.byref(p), C.byref(pp), None), "lpa_wrap_positions_3d")
+    torch.cuda.synchronize()
+    got = data.cpu().numpy()
+    live_ref = ~g["pout_is_dead"]
+    o = np.argsort(g["pin__id"][live].view(np.uint64))
+    r = np.argsort(g["pout__id"][live_ref].view(np.uint64))
+    for k, a in enumerate(("x", "y", "z")):
+        assert np.array_equal(got[k][o], g["pout_" + a][live_ref][r]), a

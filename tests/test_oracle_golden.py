@@ -327,3 +327,27 @@ def test_g13_sync_3d_single_periodic_patch(golden):
         assert np.array_equal(getattr(f, a), g["out_" + a]), a           # copies: bit exact
     for a in ("jx", "jy", "jz", "rho"):
         assert_close(getattr(f, a), g["out_" + a], 1e-14, what=a)        # sums of up to 8 terms
+
+
+def test_g14_sync_particles_3d_single_periodic_patch(golden):
+    """the reference's get_npart_to_extend_3d + fill_particles_from_boundary_3d on one self-periodic patch
+    (core/patch/sync_particles_3d.c): the live particles afterwards are the live particles before with their
+    coordinates folded into the box -- the rule the 3-D step applies (oracle.sync.periodic_fold_positions)"""
+    from lambdapic_amd.particles import ParticlesBase
+    g = golden("g14_sync_particles_3d")
+    n3 = [int(g[k]) for k in ("nx", "ny", "nz")]
+    d3 = [float(g[k]) for k in ("dx", "dy", "dz")]
+    p = ParticlesBase(0, 0)
+    p.initialize(g["pin_x"].size)
+    for a in ("x", "y", "z", "ux", "w", "_id", "is_dead"):
+        getattr(p, a)[:] = g["pin_" + a]
+    sync.periodic_fold_positions(p, [-d / 2 for d in d3], [n * d - d / 2 for n, d in zip(n3, d3)])
+    live, live_ref = ~p.is_dead, ~g["pout_is_dead"]
+    assert live.sum() == live_ref.sum()
+    o, r = np.argsort(p._id[live].view(np.uint64)), np.argsort(g["pout__id"][live_ref].view(np.uint64))
+    assert np.array_equal(p._id[live].view(np.uint64)[o], g["pout__id"][live_ref].view(np.uint64)[r])
+    for a in ("x", "y", "z", "ux", "w"):
+        assert np.array_equal(getattr(p, a)[live][o], g["pout_" + a][live_ref][r]), a
+    moved = sum(int(np.sum(getattr(p, a)[live] != g["pin_" + a][~g["pin_is_dead"]])) for a in ("x", "y", "z"))
+    assert moved > 100                               # the case does exercise the fold
+
