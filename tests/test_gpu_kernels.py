@@ -371,3 +371,50 @@ def test_cell_sort_properties(order):
     assert np.array_equal(before["_id"].view(np.uint64)[ib], out3["_id"].view(np.uint64)[ia])
     for a in ("x", "y", "ux", "w"):
         assert np.array_equal(before[a][ib], out3[a][ia])
+
+
+def test_staggered_constant_fields_known_answer():
+    """reference tests/core/interpolation/test_field_interpolation_2d.py:322-359: constant fields are
+    gathered exactly wherever the particle sits, despite the Yee staggering (TSC weights sum to one on the
+    node-centred and on the half-cell-centred stencil) -- standalone gather and the gather inside the fused
+    kernels (global-memory and LDS-tiled), 2-D and 3-D"""
+    from lambdapic_amd.fields import Fields3D
+    nx, ny, nz, dx, dy, dz = 16, 12, 10, 1.0e-6, 1.5e-6, 0.7e-6
+    vals = dict(ex=1.0, ey=2.0, ez=3.0, bx=4.0, by=5.0, bz=6.0)
+    pos = [(0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (0.25, 0.75, 0.4), (nx - 0.5, ny - 0.5, nz - 0.5), (0.0, 0.0, 0.0),
+           (-0.49, ny - 0.51, 3.3)]
+
+    def bag(dim):
+        p = ParticlesBase(0, 0)
+        p.initialize(len(pos))
+        p.x[:] = [a * dx for a, _, _ in pos]
+        p.y[:] = [b * dy for _, b, _ in pos]
+        if dim == 3:
+            p.z[:] = [min(c, nz - 0.5) * dz for _, _, c in pos]
+        p.w[:] = 1.0
+        p.inv_gamma[:] = 1.0
+        return p
+
+    f2 = Fields2D(nx, ny, dx, dy, 0.0, 0.0, 3)
+    f3 = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, 3)
+    for f in (f2, f3):
+        for a, v in vals.items():
+            getattr(f, a)[...] = v
+    p = bag(2)
+    kernels.interpolation_patches_2d([p], [f2], 1)
+    for a, v in vals.items():
+        assert np.allclose(getattr(p, a + "_part"), v, rtol=1e-14, atol=0), a
+    p = bag(3)
+    kernels.interpolation_patches_3d([p], [f3], 1)
+    for a, v in vals.items():
+        assert np.allclose(getattr(p, a + "_part"), v, rtol=1e-14, atol=0), a
+    # the gather inside the fused kernels writes the same *_part (dt tiny: the mid-step position is the input)
+    for tiled, order in MODES:
+        p = bag(2)
+        kernels.unified_boris_pusher_cpu_2d([p], [f2], 1, 1e-22, QE, ME, tiled=tiled, order=order)
+        for a, v in vals.items():
+            assert np.allclose(getattr(p, a + "_part"), v, rtol=1e-14, atol=0), (a, tiled, order)
+    p = bag(3)
+    kernels.unified_boris_pusher_cpu_3d([p], [f3], 1, 1e-22, QE, ME)
+    for a, v in vals.items():
+        assert np.allclose(getattr(p, a + "_part"), v, rtol=1e-14, atol=0), a
