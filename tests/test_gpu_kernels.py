@@ -418,3 +418,30 @@ def test_staggered_constant_fields_known_answer():
     kernels.unified_boris_pusher_cpu_3d([p], [f3], 1, 1e-22, QE, ME)
     for a, v in vals.items():
         assert np.allclose(getattr(p, a + "_part"), v, rtol=1e-14, atol=0), a
+
+
+def test_known_answer_charge_and_current_3d():
+    """reference tests/core/current/test_current_deposition.py:517-557 (test_precision_3d): for one particle
+    sum rho = q n and sum J = q n v to 1e-10 -- standalone 3-D deposit and the deposit inside the fused kernel"""
+    from lambdapic_amd.fields import Fields3D
+    dx, dy, dz = 1e-8, 1.2e-8, 0.9e-8
+    n = None
+    for fused in (False, True):
+        f = Fields3D(12, 10, 14, dx, dy, dz, 0.0, 0.0, 0.0, 3)
+        p = ParticlesBase(0, 0)
+        p.initialize(1)
+        p.x[:], p.y[:], p.z[:] = 6.3 * dx, 4.8 * dy, 7.45 * dz
+        p.ux[:], p.uy[:], p.uz[:] = 0.3, -0.2, 0.15
+        p.inv_gamma[:] = 1 / np.sqrt(1 + 0.09 + 0.04 + 0.0225)
+        p.w[:] = 1e27 * dx * dy * dz / 10
+        dt = 1e-17
+        if fused:      # E = B = 0: the push keeps u, the deposit sees the same velocity
+            kernels.unified_boris_pusher_cpu_3d([p], [f], 1, dt, QE, ME)
+        else:
+            kernels.current_deposition_cpu_3d([f], [p], 1, dt, QE)
+        n = p.w[0] / (dx * dy * dz)
+        v = np.array([0.3, -0.2, 0.15]) * p.inv_gamma[0] * C
+        assert f.rho.sum() == pytest.approx(QE * n, rel=1e-10)
+        assert f.jx.sum() == pytest.approx(QE * n * v[0], rel=1e-10)
+        assert f.jy.sum() == pytest.approx(QE * n * v[1], rel=1e-10)
+        assert f.jz.sum() == pytest.approx(QE * n * v[2], rel=1e-10)

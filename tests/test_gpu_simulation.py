@@ -199,3 +199,18 @@ def test_set_momentum_and_temperature_on_device():
     assert float((ig * gam - 1).abs().max()) < 1e-14
     assert float(gam.mean()) - 1 == pytest.approx(3 * 0.1 + kn(1, 10.0) / kn(2, 10.0) - 1, rel=0.03)
     assert abs(float(ux.mean())) < 0.01
+
+
+def test_random_seed_reproducible_loading():
+    """reference tests/test_random_seed.py: the same seed loads the same particles, another seed different
+    ones (the generator of a patch is seeded from (seed, species, patch origin), so the loading does not
+    depend on the number of ranks either: tests/test_gpu_multirank.py compares 1 and 2 ranks)"""
+    def load(seed, npx):
+        sim, _ = _sim(nx=64, ny=32, npx=npx, npy=1, ppc=4, seed=seed)
+        sim.initialize()
+        sp = sim.engine.species[0]
+        a = sp.cset.arr
+        return torch.stack([a(k)[: sp.n] for k in ("x", "y", "ux", "uy", "uz")]).cpu().numpy()
+    a, b, c = load(7, 2), load(7, 2), load(8, 2)
+    assert np.array_equal(a, b)
+    assert a.shape == c.shape and not np.array_equal(a, c)
