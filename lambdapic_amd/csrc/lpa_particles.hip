@@ -483,7 +483,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                                        if (on_y) atomicAdd(&s_j[1][o], djy);
                                        if (on) {
                                            atomicAdd(&s_j[2][o], djz);
+#ifndef LPA_ABLATE_NO_RHO   // diagnostic build: what depositing rho costs (open items)
                                            atomicAdd(&s_j[3][o], drho);
+#endif
                                        }
 #endif
                                    });

@@ -491,7 +491,9 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                     int o = b0 + (i * R3Y + j) * R3ZS + kk;
                     if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][o], djy);
                     if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][o], djz);
+#ifndef LPA_ABLATE_NO_RHO   // diagnostic build: what depositing rho costs (open items)
                     atomicAdd(&s_j[3][o], dr);
+#endif
                 }
             });
     }
