@@ -10,6 +10,11 @@ struct PushK3 {
     double dt, q, efactor, bfactor, cdt_half;
     int wrap;
     double lo[3], hi[3], alo[3], ahi[3];
+    // loop invariants of the tiled kernel, computed on the host with the same IEEE operations the kernel used to
+    // do: as kernel arguments they sit in SGPRs -- computed in the kernel they are VALU results that occupied
+    // 14 VGPRs for the whole particle loop, spilled to scratch and reloaded 13 times per particle
+    double inv_d[3];        // 1 / dx, 1 / dy, 1 / dz
+    double c_rho, c_j[3];   // q / (dx dy dz),  q / (dy dz dt), q / (dx dz dt), q / (dx dy dt)
 };
 
 struct GIdx3 { long r[3]; int c[3]; int d[3]; };
@@ -113,11 +118,12 @@ __device__ __forceinline__ void esirkepov_3d(const AxisW &ax, const AxisW &ay, c
 // DS is re-derived as S1 - S0 (its definition in axis_window) instead of being kept in registers.
 template <class SinkX, class SinkYZR>
 __device__ __forceinline__ void esirkepov_3d_lean(const AxisW &ax, const AxisW &ay, const AxisW &az, double w,
-                                                  double q, double dx, double dy, double dz, double dt,
+                                                  double c_rho, double c_jx, double c_jy, double c_jz,
                                                   SinkX &&sink_x, SinkYZR &&sink_yzr) {
+    // c_rho = q / (dx dy dz), c_jx = q / (dy dz dt), c_jy = q / (dx dz dt), c_jz = q / (dx dy dt)
     const double one_third = 0.3333333333333333;
     {
-        double fdx_ = (q / (dy * dz * dt)) * w;
+        double fdx_ = c_jx * w;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             double dsy = ay.S1[j] - ay.S0[j];
@@ -136,9 +142,9 @@ __device__ __forceinline__ void esirkepov_3d_lean(const AxisW &ax, const AxisW &
             }
         }
     }
-    double cd = (q / (dx * dy * dz)) * w;
-    double fdy_ = (q / (dx * dz * dt)) * w;
-    double fdz_ = (q / (dx * dy * dt)) * w;
+    double cd = c_rho * w;
+    double fdy_ = c_jy * w;
+    double fdz_ = c_jz * w;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         double dsx = ax.S1[i] - ax.S0[i];
@@ -358,7 +364,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     }
     __syncthreads();
 
-    const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy, inv_dz = 1.0 / g.dz;
+    const double inv_dx = k.inv_d[0], inv_dy = k.inv_d[1], inv_dz = k.inv_d[2];
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
     auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
     // software pipeline: the eight attribute loads of the next iteration are in flight during this one
@@ -469,7 +475,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         // window plane 3 of an axis carries exact zeros unless the particle changed cell along that axis
         // (see the 2-D kernel)
         esirkepov_3d_lean(
-            ax, ay, az, w, k.q, g.dx, g.dy, g.dz, k.dt,
+            ax, ay, az, w, k.c_rho, k.c_j[0], k.c_j[1], k.c_j[2],
             [&](int i, int j, int kk, double djx) {
                 // a running sum over the 3 window planes of a particle that stayed in its cell along
                 // that axis ends at (sum of DS) * (...) = 0 up to rounding (the reference adds that
@@ -516,8 +522,17 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     }
 }
 
-static PushK3 make_pushk3(const lpa_push_params *pp) {
+static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
     PushK3 k;
+    k.inv_d[0] = k.inv_d[1] = k.inv_d[2] = 0.0;
+    k.c_rho = k.c_j[0] = k.c_j[1] = k.c_j[2] = 0.0;
+    if (g) {
+        k.inv_d[0] = 1.0 / g->dx; k.inv_d[1] = 1.0 / g->dy; k.inv_d[2] = 1.0 / g->dz;
+        k.c_rho = pp->q / (g->dx * g->dy * g->dz);
+        k.c_j[0] = pp->q / (g->dy * g->dz * pp->dt);
+        k.c_j[1] = pp->q / (g->dx * g->dz * pp->dt);
+        k.c_j[2] = pp->q / (g->dx * g->dy * pp->dt);
+    }
     k.dt = pp->dt; k.q = pp->q;
     k.efactor = pp->q * pp->dt / (2 * pp->m * LPA_C);
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
@@ -638,7 +653,7 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
     if (t->n_sorted == 0) return LPA_OK;
     LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_3d: more than 2^29 particles in one store");
     hipLaunchKernelGGL(k_push_deposit_tiled_3d, dim3(t->max_blocks), dim3(K13_THREADS), 0, (hipStream_t)stream,
-                       make_gridv(g, 3), make_partv(p), make_pushk3(pp), t->blk_tile, t->blk_begin, t->blk_end,
+                       make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile, t->blk_begin, t->blk_end,
                        t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols);
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
     return LPA_OK;
