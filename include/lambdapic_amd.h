@@ -73,10 +73,11 @@ typedef struct {
     const int32_t *n_blocks;   /* [1] number of valid work blocks                                */
     int32_t tiles_z;           /* 3-D tilings (lpa_sort_tiles_3d): tiles along z; 0 for 2-D      */
     int32_t reserved_;
-    double *scratch[7];        /* optional (set by the caller, all or none): seven device arrays of at
-                                  least n_sorted doubles, e.g. the idle half of the ping-pong sort stores.
-                                  lpa_push_deposit_tiled_2d parks the particles that changed cell there
-                                  and deposits their extra window cells in a dense second pass           */
+    double *scratch[8];        /* optional (set by the caller, all or none): device arrays of at least n_sorted
+                                  doubles each, e.g. the idle half of the ping-pong sort stores -- seven for a
+                                  2-D tiling, eight for a 3-D one.  The tiled push kernels park the particles that
+                                  changed cell there and deposit them on the general window in a dense second
+                                  pass                                                                     */
 } lpa_tiling;
 
 #define LPA_TILE_X 8       /* cells per tile along x                                            */

@@ -47,7 +47,7 @@ class lpa_tiling(C.Structure):
                 ("max_blocks", C.c_int32), ("order", C.c_int32),
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
-                ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 7)]
+                ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 8)]
 
 
 class lpa_cpml_axis(C.Structure):

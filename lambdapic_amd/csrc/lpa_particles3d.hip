@@ -320,12 +320,22 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
     return acc;
 }
 
+// DEFER (as in the 2-D kernel): particles that change cell during the step park their advanced state (8
+// doubles) in a scratch store -- the idle half of the ping-pong sort buffers -- and are deposited on the general
+// 4 x 4 x 4 window by a dense second pass of the workgroup; the main loop then only sees particles that stay in
+// their cell: old shape = the gather weights, 3 x 3 x 3 window, no window re-basing, no predicated atomics
+// (static instruction count of the loop: 1275 -> 856 VALU, 627 -> 363 SALU, 256 -> 81 ds_add_f64).
+struct Scratch8 { double *a[8]; };
+__device__ __forceinline__ int clamp3(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+template <bool DEFER>
 __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
-    uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols) {
+    uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols, Scratch8 sc) {
     __shared__ double s_j[4][R3N];
     __shared__ double s_eb[6][E3N];
+    __shared__ int s_ncross;
     // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
     // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
     // 4.51 ms per step, tools/exp_k13.sh with LPA_XCD_ORDER_3D) and idles XCDs in an edge / interior part launch
@@ -346,6 +356,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     const int t0[3] = {tx_ * T3X, ty_ * T3Y, tz_ * T3Z};          // first node of the tile
     const int r0[3] = {t0[0] - H3, t0[1] - H3, t0[2] - H3};       // first node of the LDS region
     const int lane = threadIdx.x & 63;
+    if (DEFER && threadIdx.x == 0) s_ncross = 0;
     for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 4; c++) s_j[c][t] = 0.0;
@@ -395,6 +406,8 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         y += k.cdt_half * ig * uy;
         z += k.cdt_half * ig * uz;
         double eb[6];
+        [[maybe_unused]] int mid[3] = {0, 0, 0};          // mid-step nearest node
+        [[maybe_unused]] double gd[3] = {0.0, 0.0, 0.0};  // node - position in cells: the TSC offsets of the gather
         {
             // a particle folded through a locally periodic face since the last sort: work on its periodic
             // image next to the tile (see the 2-D kernel)
@@ -427,6 +440,8 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                          gzd = iz1 - zo, hzd = iz2 - zo + 0.5;
             const int lx1 = ix1 - e0[0], lx2 = ix2 - e0[0], ly1 = iy1 - e0[1], ly2 = iy2 - e0[1],
                       lz1 = iz1 - e0[2], lz2 = iz2 - e0[2];
+            mid[0] = ix1; mid[1] = iy1; mid[2] = iz1;
+            gd[0] = gxd; gd[1] = gyd; gd[2] = gzd;
             // stagger table: unified_pusher_3d.c:190-195
             eb[0] = gather27_l(s_eb[0], lx2, ly1, lz1, hxd, gyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
@@ -447,18 +462,59 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         z += k.cdt_half * ig * uz;
         double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
         AxisW ax, ay, az;
-        axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, inv_dx);
-        axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, inv_dy);
-        axis_window(az, z - vz * 0.5 * k.dt - g.z0, z + vz * 0.5 * k.dt - g.z0, inv_dz);
-        // the LDS path is valid iff the whole 4 x 4 x 4 window lies inside the staged region; anything
-        // else (drifted further than the margin since the sort, non-finite input) goes to the overflow
-        // list untouched -- nothing has been stored or deposited yet
-        const int bx = ax.base - r0[0], by = ay.base - r0[1], bz = az.base - r0[2];
-        if ((unsigned)bx > (unsigned)(R3X - 4) || (unsigned)by > (unsigned)(R3Y - 4) ||
-            (unsigned)bz > (unsigned)(R3Z - 4)) {
-            uint32_t slot = atomicAdd(overflow_count, 1u);
-            overflow[slot] = (uint32_t)ip;
-            continue;
+        bool cross = false;
+        int bx, by, bz;
+        if (DEFER) {
+            // old shape = gather weights around the mid-step node; the particle stays in its cell iff its
+            // advanced position has the same nearest node on every axis
+            const double d1[3] = {mid[0] - (x + vx * 0.5 * k.dt - g.x0) * inv_dx,
+                                  mid[1] - (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
+                                  mid[2] - (z + vz * 0.5 * k.dt - g.z0) * inv_dz};
+            cross = !(d1[0] > -0.5 && d1[0] <= 0.5 && d1[1] > -0.5 && d1[1] <= 0.5 && d1[2] > -0.5 && d1[2] <= 0.5);
+            if (cross) {
+                // the general window covers the cells of the old and the new nearest node +- 1: inside the staged
+                // region?  (otherwise: overflow list, untouched)
+                bool inside = true;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const int i1 = mid[a] - ifloor(d1[a] + 0.5);      // nearest node of the advanced position
+                    const int lo = (i1 < mid[a] ? i1 : mid[a]) - 1 - r0[a], hi = (i1 > mid[a] ? i1 : mid[a]) + 1 - r0[a];
+                    const int rr = a == 0 ? R3X : (a == 1 ? R3Y : R3Z);
+                    inside = inside && lo >= 0 && hi < rr;
+                }
+                if (!inside) {
+                    uint32_t slot = atomicAdd(overflow_count, 1u);
+                    overflow[slot] = (uint32_t)ip;
+                    continue;
+                }
+            }
+            AxisW *aw[3] = {&ax, &ay, &az};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                tsc3(gd[a], aw[a]->S0);
+                tsc3(d1[a], aw[a]->S1);
+                aw[a]->S0[3] = aw[a]->S1[3] = aw[a]->DS[3] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) aw[a]->DS[c] = aw[a]->S1[c] - aw[a]->S0[c];
+                aw[a]->base = mid[a] - 1;
+                aw[a]->tail_zero = true;
+            }
+            // (mid within tile +- 1 => the 3-cell window starts 1 ... T + 3 nodes into the region: inside)
+            bx = ax.base - r0[0]; by = ay.base - r0[1]; bz = az.base - r0[2];
+        } else {
+            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, inv_dx);
+            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, inv_dy);
+            axis_window(az, z - vz * 0.5 * k.dt - g.z0, z + vz * 0.5 * k.dt - g.z0, inv_dz);
+            // the LDS path is valid iff the whole 4 x 4 x 4 window lies inside the staged region; anything
+            // else (drifted further than the margin since the sort, non-finite input) goes to the overflow
+            // list untouched -- nothing has been stored or deposited yet
+            bx = ax.base - r0[0]; by = ay.base - r0[1]; bz = az.base - r0[2];
+            if ((unsigned)bx > (unsigned)(R3X - 4) || (unsigned)by > (unsigned)(R3Y - 4) ||
+                (unsigned)bz > (unsigned)(R3Z - 4)) {
+                uint32_t slot = atomicAdd(overflow_count, 1u);
+                overflow[slot] = (uint32_t)ip;
+                continue;
+            }
         }
         if (p.eb[0]) {
 #pragma unroll
@@ -470,6 +526,13 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             const uint32_t o = (uint32_t)ip * 8u;
             st(p.x, o, xs); st(p.y, o, ys); st(p.z, o, zs);
             st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
+        }
+        if (DEFER && cross) {   // parked: deposited by the second pass (unfolded position: the window is local)
+            const int slot = atomicAdd(&s_ncross, 1);
+            const uint32_t o = (uint32_t)(begin + slot) * 8u;
+            st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, z); st(sc.a[3], o, ux); st(sc.a[4], o, uy);
+            st(sc.a[5], o, uz); st(sc.a[6], o, ig); st(sc.a[7], o, w);
+            continue;
         }
         const int b0 = (bx * R3Y + by) * R3ZS + bz;
         // window plane 3 of an axis carries exact zeros unless the particle changed cell along that axis
@@ -502,6 +565,44 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #endif
                 }
             });
+    }
+    if (DEFER) {
+        // ---- the particles that changed cell: the general 4 x 4 x 4 window, every lane busy
+        __syncthreads();
+        const int ncross = s_ncross;
+        for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
+            const uint32_t o = (uint32_t)(begin + i) * 8u;
+            const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), z = ld(sc.a[2], o), ux = ld(sc.a[3], o),
+                         uy = ld(sc.a[4], o), uz = ld(sc.a[5], o), ig = ld(sc.a[6], o), w = ld(sc.a[7], o);
+            const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+            AxisW ax, ay, az;
+            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, inv_dx);
+            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, inv_dy);
+            axis_window(az, z - vz * 0.5 * k.dt - g.z0, z + vz * 0.5 * k.dt - g.z0, inv_dz);
+            // (clamped: the old cell is re-derived here and may differ by one from the main loop's for a particle
+            // within an ulp of a cell boundary, where the shape value of the extra cell is an ulp as well)
+            const int bx = clamp3(ax.base - r0[0], R3X - 4), by = clamp3(ay.base - r0[1], R3Y - 4),
+                      bz = clamp3(az.base - r0[2], R3Z - 4);
+            const int b0 = (bx * R3Y + by) * R3ZS + bz;
+            esirkepov_3d_lean(
+                ax, ay, az, w, k.c_rho, k.c_j[0], k.c_j[1], k.c_j[2],
+                [&](int ii, int j, int kk, double djx) {
+                    bool on = (ii < (LPA_SKIP_NULL_RUN ? 2 : 3) || !ax.tail_zero) && (j < 3 || !ay.tail_zero) &&
+                              (kk < 3 || !az.tail_zero);
+                    if (on) atomicAdd(&s_j[0][b0 + (ii * R3Y + j) * R3ZS + kk], djx);
+                },
+                [&](int ii, int j, int kk, double djy, double djz, double dr) {
+                    bool on = (ii < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
+                    if (on) {
+                        int oo = b0 + (ii * R3Y + j) * R3ZS + kk;
+                        if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][oo], djy);
+                        if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][oo], djz);
+#ifndef LPA_ABLATE_NO_RHO
+                        atomicAdd(&s_j[3][oo], dr);
+#endif
+                    }
+                });
+        }
     }
     __syncthreads();
     // flush: one FP64 global atomic per touched node and component, on the torus
@@ -652,9 +753,22 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
                 "lpa_push_deposit_tiled_3d: tile-binned stores carry no is_dead array (dead = NaN x)");
     if (t->n_sorted == 0) return LPA_OK;
     LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_3d: more than 2^29 particles in one store");
-    hipLaunchKernelGGL(k_push_deposit_tiled_3d, dim3(t->max_blocks), dim3(K13_THREADS), 0, (hipStream_t)stream,
-                       make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile, t->blk_begin, t->blk_end,
-                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols);
+    Scratch8 sc;
+    bool defer = true;
+    for (int c = 0; c < 8; c++) {
+        sc.a[c] = t->scratch[c];
+        defer = defer && sc.a[c] != nullptr;
+    }
+    if (defer)
+        hipLaunchKernelGGL(k_push_deposit_tiled_3d<true>, dim3(t->max_blocks), dim3(K13_THREADS), 0,
+                           (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
+                           t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
+                           part, t->tiles_x, edge_cols, sc);
+    else
+        hipLaunchKernelGGL(k_push_deposit_tiled_3d<false>, dim3(t->max_blocks), dim3(K13_THREADS), 0,
+                           (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
+                           t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
+                           part, t->tiles_x, edge_cols, sc);
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
     return LPA_OK;
 }

@@ -567,7 +567,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     out->tiles_y = tiles_y;
     out->tiles_z = tiles_z;
     out->reserved_ = 0;
-    for (int c = 0; c < 7; c++) out->scratch[c] = nullptr;   // the caller may attach the idle store
+    for (int c = 0; c < 8; c++) out->scratch[c] = nullptr;   // the caller may attach the idle store
     out->n_sorted = src->n;  // upper bound known on the host; the exact count is hdr->n_live
     out->max_blocks = w.max_blocks;
     out->order = order;

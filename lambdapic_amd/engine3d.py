@@ -158,6 +158,7 @@ class PicEngine3D:
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
+        self.defer_crossers = True   # cell-crossers deposit in a dense second pass of the tiled kernel
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
         self._axes = {}
@@ -250,6 +251,10 @@ class PicEngine3D:
         sp["c"] = self._cstruct(sp["data"], sp["n"])
         ws["counters"].zero_()
         ws["tiling"].n_sorted = n_live
+        # the store that was just sorted FROM is idle until the next sort: scratch for the dense second pass of
+        # the tiled kernel (particles that changed cell park their 8 attributes there)
+        for c in range(8):
+            ws["tiling"].scratch[c] = sp["alt"][c].data_ptr() if self.defer_crossers else None
         sp["tiling"] = ws["tiling"]
         sp["since"] = 0
         self._reset_free_slots(ws)

@@ -16,6 +16,7 @@ ap.add_argument("--nz", type=int, default=256); ap.add_argument("--ppc", type=in
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--global", dest="glob", action="store_true"); ap.add_argument("--sort-interval", type=int, default=10)
 ap.add_argument("--block-particles", type=int, default=4096)
+ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (gamma beta)")
 a = ap.parse_args()
 lam = 0.8e-6
 dx, dy, dz = lam / 20, lam / 10, lam / 10                 # example/laser-target-3d.py:26-31
@@ -32,7 +33,7 @@ data[0] = ((cell // (a.ny * a.nz)).double() + r() - 0.5) * dx
 data[1] = (((cell // a.nz) % a.ny).double() + r() - 0.5) * dy
 data[2] = ((cell % a.nz).double() + r() - 0.5) * dz
 for k in (3, 4, 5):
-    data[k] = torch.randn(n, device=dev, dtype=torch.float64, generator=g) * 0.0442
+    data[k] = torch.randn(n, device=dev, dtype=torch.float64, generator=g) * a.uth
 data[6] = 1.0 / torch.sqrt(1 + data[3] ** 2 + data[4] ** 2 + data[5] ** 2)
 omega = 2 * np.pi * 299792458.0 / lam
 data[7] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE ** 2 * dx * dy * dz / a.ppc
