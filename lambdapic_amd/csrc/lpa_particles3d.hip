@@ -187,14 +187,19 @@ __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, doub
         cols[k] = torus(ay.base + k + g.ng, g.NY) * g.NZ;
         deps[k] = torus(az.base + k + g.ng, g.NZ);
     }
-    esirkepov_3d(ax, ay, az, w, q, g.dx, g.dy, g.dz, dt,
-                 [&](int i, int j, int k, double djx, double djy, double djz, double dr) {
-                     long idx = rows[i] + cols[j] + deps[k];
-                     if (djx != 0.0) atomicAdd(&g.jx[idx], djx);
-                     if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
-                     if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
-                     if (dr != 0.0) atomicAdd(&g.rho[idx], dr);
-                 });
+    // the register-lean two-sweep form (k_deposit_3d: 204 -> 144 VGPRs; the global push kernels stay at 349,
+    // held there by the 162-load gather -- capping them at three waves per SIMD spilled 170-200 dwords)
+    esirkepov_3d_lean(
+        ax, ay, az, w, q / (g.dx * g.dy * g.dz), q / (g.dy * g.dz * dt), q / (g.dx * g.dz * dt), q / (g.dx * g.dy * dt),
+        [&](int i, int j, int k, double djx) {
+            if (djx != 0.0) atomicAdd(&g.jx[rows[i] + cols[j] + deps[k]], djx);
+        },
+        [&](int i, int j, int k, double djy, double djz, double dr) {
+            long idx = rows[i] + cols[j] + deps[k];
+            if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
+            if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
+            if (dr != 0.0) atomicAdd(&g.rho[idx], dr);
+        });
 }
 
 __device__ __forceinline__ double fold3(double v, double lo, double hi) {
