@@ -64,3 +64,14 @@ def test_no_cpu_fallback():
     from lambdapic_amd.fields import Fields2D
     with pytest.raises(_lib.LpaError):
         kernels.update_bfield_2d(Fields2D(8, 8, 1e-8, 1e-8, 0, 0, 3), 1e-17)
+
+
+def test_every_abi_function_is_mapped_in_integration_md():
+    """INTEGRATION.md names the reference call each entry point replaces: no entry point may be missing there"""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    names = sorted(set(re.findall(r"\b(lpa_[a-z0-9_]+)\s*\(", (root / "include" / "lambdapic_amd.h").read_text())))
+    doc = (root / "INTEGRATION.md").read_text()
+    missing = [n for n in names if n not in doc]
+    assert not missing, missing
