@@ -70,7 +70,7 @@ def build_engine(args, comm, device):
     return eng, dt, n
 
 
-def parity_c1(nsteps=30):
+def parity_c1(nsteps=200):
     """SURVEY 8(d)'s accuracy figures on config C1 (256 x 256 cells, 16 ppc, periodic thermal plasma): the
     same seeded particles through the CPU port and through the GPU engine; relative error of the field
     energy, the kinetic energy and the total charge after ``nsteps`` steps (the CPU port is the checker)."""

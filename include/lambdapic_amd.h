@@ -311,7 +311,8 @@ const int32_t *lpa_sort_live_count(void *workspace);
  *      [attr][capacity].
  *      pack  : live particles with x < xlo / x > xhi are copied to buf_lo / buf_hi and killed
  *              (x = y = NaN, sync_particles_2d.c:185-202).  A particle that does not fit stays
- *              where it is and leaves one step later (count > capacity records the event).
+ *              where it is and leaves one step later; `surplus` (device int32, may be NULL) is
+ *              incremented by the number of such particles -- the caller zeroes and reads it.
  *      unpack: append the received particles to the arrival area [first_slot, first_slot +
  *              area_capacity) at the device-side cursor, adding shift_x to x (periodic wrap at
  *              the global edge, sync_particles_2d.c:168-182).  cursor > area_capacity = overflow. */
@@ -328,7 +329,7 @@ typedef struct {
 
 #define LPA_MIG_NATTR 9 /* x y z ux uy uz inv_gamma w id */
 int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
-                       double *buf_hi, int64_t capacity, void *stream);
+                       double *buf_hi, int64_t capacity, int32_t *surplus, void *stream);
 /* the same scan restricted to the particles that can have left a tile-ordered store since its sort: the
  * `edge_cols` tile columns next to each x face (tile index is x-slowest) and the loose particles behind
  * t->n_sorted.  The caller chooses edge_cols from the age of the order (c*dt*age / tile width, rounded
@@ -336,7 +337,7 @@ int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *b
  * the freed slots, see lpa_free_slots. */
 int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo,
                              double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
-                             const lpa_free_slots *fs, void *stream);
+                             const lpa_free_slots *fs, int32_t *surplus, void *stream);
 /* unpack for a tile-ordered store with free-slot stacks: an arrival whose tile (from its position on grid
  * `g`) has a recorded free slot takes it and is pushed by the tiled kernel from the next step on; the others are
  * appended to the arrival area exactly like lpa_migrate_unpack. */

@@ -121,8 +121,8 @@ SIGNATURES = {
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
-    "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp]),
-    "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp]),
+    "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp, _vp]),
+    "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp, _vp]),
     "lpa_migrate_unpack_tiled": (_i, [_P, _G, _T, _FS, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),

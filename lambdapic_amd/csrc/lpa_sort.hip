@@ -623,7 +623,8 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
                                                  double *buf_lo, double *buf_hi, long cap,
                                                  const FreeSlots &fs = FreeSlots{nullptr, nullptr, 0, 0},
                                                  const int32_t *tile_off = nullptr, int ntiles = 0,
-                                                 long n_sorted = 0, bool active = true) {
+                                                 long n_sorted = 0, bool active = true,
+                                                 int32_t *surplus = nullptr) {
     // called by every lane of the wave (`active` = this lane has a particle): the message slots are taken
     // with ONE atomic per wave and face -- tens of thousands of leavers bumping a single counter one by one
     // took 0.14 ms of the 3-D scan
@@ -638,7 +639,13 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
         if (!m) continue;   // wave-uniform
         const int leader = __ffsll((long long)m) - 1;
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd((unsigned long long *)(s == 0 ? buf_lo : buf_hi), (unsigned long long)__popcll(m));
+        if (lane == leader) {
+            const unsigned long long k = (unsigned long long)__popcll(m);
+            base = atomicAdd((unsigned long long *)(s == 0 ? buf_lo : buf_hi), k);
+            // leavers that do not fit into the message: counted for the host (checked at the next sort)
+            if (surplus && base + k > (unsigned long long)cap)
+                atomicAdd(surplus, (int32_t)(base >= (unsigned long long)cap ? k : base + k - (unsigned long long)cap));
+        }
         base = __shfl(base, leader);
         if (side == s) slot = (long)base + __popcll(m & ((1ull << lane) - 1ull));
     }
@@ -674,14 +681,16 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
         }
     }
     // slot >= cap: the particle is NOT lost -- it stays where it is (outside the slab, handled by the
-    // torus path) and leaves at the next step; count > cap is visible to the host at the next sort.
+    // torus path) and leaves at the next step; the event is counted in *surplus, which the engines read
+    // at their next sort and turn into an error (the torus path deposits such a particle on the wrong side
+    // of the slab).
 }
 
 __global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, double xhi, double *buf_lo,
-                                                        double *buf_hi, long cap) {
+                                                        double *buf_hi, long cap, int32_t *surplus) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, FreeSlots{nullptr, nullptr, 0, 0}, nullptr, 0, 0,
-                     ip < p.n);
+                     ip < p.n, surplus);
 }
 
 // the same over the only particles that can have left a tile-ordered store: the first / last `edge_tiles`
@@ -691,7 +700,8 @@ __global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, dou
 __global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int32_t *__restrict__ tile_off,
                                                               int ntiles, int edge_tiles, long n_sorted,
                                                               double xlo, double xhi, double *buf_lo,
-                                                              double *buf_hi, long cap, FreeSlots fs) {
+                                                              double *buf_hi, long cap, FreeSlots fs,
+                                                              int32_t *surplus) {
     const long a1 = tile_off[edge_tiles], b0 = tile_off[ntiles - edge_tiles], b1 = tile_off[ntiles];
     const long nb = b1 - b0, nl = p.n > n_sorted ? p.n - n_sorted : 0;
     const long total = a1 + nb + nl;
@@ -701,7 +711,7 @@ __global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int
         const long t = t0 + lane;
         const bool active = t < total;
         long ip = !active ? 0 : (t < a1 ? t : (t < a1 + nb ? b0 + (t - a1) : n_sorted + (t - a1 - nb)));
-        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active);
+        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active, surplus);
     }
 }
 
@@ -805,7 +815,7 @@ static FreeSlots make_free_slots(const lpa_free_slots *fs, const lpa_tiling *t) 
 }
 
 extern "C" int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,
-                                  double *buf_hi, int64_t capacity, void *stream) {
+                                  double *buf_hi, int64_t capacity, int32_t *surplus, void *stream) {
     LPA_REQUIRE(lpa_part_ok(p, 2) && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
                 "lpa_migrate_pack_x: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -816,14 +826,15 @@ extern "C" int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi
     }
     if (p->n == 0) return LPA_OK;
     hipLaunchKernelGGL(k_migrate_pack_x, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st,
-                       make_partv(p), xlo, xhi, buf_lo, buf_hi, (long)capacity);
+                       make_partv(p), xlo, xhi, buf_lo, buf_hi, (long)capacity, surplus);
     LPA_CHECK_LAUNCH("lpa_migrate_pack_x");
     return LPA_OK;
 }
 
 extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols,
                                         double xlo, double xhi, double *buf_lo, double *buf_hi,
-                                        int64_t capacity, const lpa_free_slots *fs, void *stream) {
+                                        int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
+                                        void *stream) {
     LPA_REQUIRE(!fs || (free_slots_ok(fs, t) && fs->edge_cols >= edge_cols),
                 "lpa_migrate_pack_edges_x: bad free-slot stacks (edge_cols must cover the scanned columns)");
     LPA_REQUIRE(lpa_part_ok(p, 2) && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
@@ -846,7 +857,7 @@ extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling
     if (nblk > 16384) nblk = 16384;
     hipLaunchKernelGGL(k_migrate_pack_edges_x, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), t->tile_off, ntiles,
                        edge_cols * per_col, (long)t->n_sorted, xlo, xhi, buf_lo, buf_hi, (long)capacity,
-                       make_free_slots(fs, t));
+                       make_free_slots(fs, t), surplus);
     LPA_CHECK_LAUNCH("lpa_migrate_pack_edges_x");
     return LPA_OK;
 }

@@ -43,9 +43,14 @@ class SlabComm:
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
         """send_lo -> left neighbour, send_hi -> right neighbour; recv_lo <- left, recv_hi <- right.
 
-        Posting order matters when left == right (two ranks): messages between one pair of ranks
-        match in posting order, so the sends are posted (hi, lo) and the receives (lo, hi): the
-        peer's first receive (its low face) takes my high face.
+        PAIRING RULE (the only one RCCL offers: ncclSend / ncclRecv carry no tag; messages between one
+        pair of ranks match in the order they were posted inside the group): every rank posts its
+        sends as (hi, lo) and its receives as (lo, hi).  With three or more ranks the two neighbours
+        differ and each pair exchanges one message per direction.  With two ranks left == right: the
+        peer's first receive (its low face) takes my first send (my high face), its second receive
+        (its high face) my second send (my low face).  No tags are passed, so the gloo rehearsals
+        (which WOULD match by tag) exercise exactly this rule
+        (the reference tags its messages instead: `core/mpi/sync_fields2d.c:577-578`).
 
         With the ``gloo`` backend (CPU rehearsal of the multi-rank path, or several ranks sharing
         one GPU in a test) device tensors are staged through host memory.
@@ -64,12 +69,12 @@ class SlabComm:
             s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
         ops = []
         if self.has_right:
-            ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp, tag=1))
+            ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp))
         if self.has_left:
-            ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp, tag=0))
-            ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp, tag=1))
+            ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp))
+            ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp))
         if self.has_right:
-            ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp, tag=0))
+            ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if wait or staged:
             for r in reqs:
@@ -84,8 +89,8 @@ class SlabComm:
     def exchange_many(self, sets):
         """several face exchanges in ONE grouped send / recv round; ``sets`` = [(send_lo, send_hi, recv_lo,
         recv_hi), ...].  Every rank lists its sets in the same order; per set the posting order is the one
-        of ``exchange`` (sends hi, lo -- receives lo, hi), so messages between one pair of ranks still match
-        in order when both neighbours are the same rank."""
+        of ``exchange`` (sends hi, lo -- receives lo, hi), set after set, so messages between one pair of ranks
+        still match in posting order when both neighbours are the same rank (no tags: see ``exchange``)."""
         if self.size == 1:
             for s_ in sets:
                 self.exchange(*s_)
@@ -101,12 +106,12 @@ class SlabComm:
             else:
                 s_lo, s_hi, r_lo, r_hi = send_lo, send_hi, recv_lo, recv_hi
             if self.has_right:
-                ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp, tag=2 * k + 1))
+                ops.append(dist.P2POp(dist.isend, s_hi, self.right, grp))
             if self.has_left:
-                ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp, tag=2 * k))
-                ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp, tag=2 * k + 1))
+                ops.append(dist.P2POp(dist.isend, s_lo, self.left, grp))
+                ops.append(dist.P2POp(dist.irecv, r_lo, self.left, grp))
             if self.has_right:
-                ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp, tag=2 * k))
+                ops.append(dist.P2POp(dist.irecv, r_hi, self.right, grp))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         for r in reqs:
             r.wait()

@@ -271,8 +271,16 @@ class PicEngine2D:
         if self._halo is None:
             n = self.ng * self.grid.NY
             mk = lambda c: torch.empty(c * n, dtype=torch.float64, device=self.device)
-            self._halo = {"s_lo": mk(4), "s_hi": mk(4), "r_lo": mk(4), "r_hi": mk(4)}
+            # 6 components: a guard sync of E and B together (the reference's default attrs) is the largest message
+            self._halo = {"s_lo": mk(6), "s_hi": mk(6), "r_lo": mk(6), "r_hi": mk(6)}
         return self._halo
+
+    def _halo_views(self, n):
+        """the first ``n`` doubles of the four face buffers; the C ABI takes no length, so check here"""
+        bufs = self._halo_bufs()
+        if any(n > v.numel() for v in bufs.values()):
+            raise _lib.LpaError(f"halo message of {n} doubles exceeds the face buffers")
+        return {k: v[:n] for k, v in bufs.items()}
 
     def _faces(self, op, which=0):
         """both x faces in one launch (lpa_halo_faces); a missing buffer (open chain end) is skipped"""
@@ -287,8 +295,7 @@ class PicEngine2D:
         st = self.stream
         check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
         if self.comm.size > 1:
-            n = 3 * bin(which).count("1") * self.ng * self.grid.NY
-            h = {k: v[:n] for k, v in self._halo_bufs().items()}
+            h = self._halo_views(3 * bin(which).count("1") * self.ng * self.grid.NY)
             # my low interior edge becomes the LEFT neighbour's high guard and vice versa
             exchange_faces(
                 self.comm,
@@ -306,8 +313,7 @@ class PicEngine2D:
     def sync_currents(self):
         st = self.stream
         if self.comm.size > 1:
-            n = 4 * self.ng * self.grid.NY
-            h = {k: v[:n] for k, v in self._halo_bufs().items()}
+            h = self._halo_views(4 * self.ng * self.grid.NY)
             # my low GUARD planes are added to the LEFT neighbour's high interior edge
             exchange_faces(
                 self.comm,
@@ -327,7 +333,8 @@ class PicEngine2D:
             self._ws[key] = {
                 "sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
                 "overflow": torch.empty(sp.capacity, dtype=torch.int32, device=self.device),
-                "counters": torch.zeros(4, dtype=torch.int32, device=self.device),  # 0: overflow, 1: arrivals
+                # 0: overflow list, 1: arrival cursor, 2: overflow list of the edge part, 3: leavers that did not fit
+                "counters": torch.zeros(4, dtype=torch.int32, device=self.device),
                 "area": area,
                 "tiling": _lib.lpa_tiling(),
                 "mig": None,
@@ -345,9 +352,13 @@ class PicEngine2D:
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
         hdr = ws["sort"][:8].view(torch.int32)
         n_live = int(hdr[0].item())                      # sync point (once per sort_interval steps)
-        arrivals = int(ws["counters"][1].item())
+        cnts = ws["counters"].tolist()
+        arrivals, surplus = cnts[1], cnts[3]
         if arrivals > ws["area"]:
             raise _lib.LpaError(f"arrival area overflow: {arrivals} > {ws['area']} (raise migrate_capacity)")
+        if surplus > 0:
+            raise _lib.LpaError(f"migration message overflow: {surplus} leavers beyond migrate_capacity="
+                                f"{self.migrate_capacity} since the last sort stayed outside the slab (raise migrate_capacity)")
         sp.cur = 1 - sp.cur
         sp.n_sorted = n_live
         area = ws["area"]
@@ -480,7 +491,7 @@ class PicEngine2D:
             self._side = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: the edge goes first
         ready, done = torch.cuda.Event(), torch.cuda.Event()
         ready.record(main)
-        h = self._halo_bufs()
+        h = self._halo_views(4 * self.ng * self.grid.NY)
         # edge tiles + pack + exchange on the high-priority side stream, the interior tiles on the main stream AT
         # THE SAME TIME (they touch disjoint particles and never the x guard planes; both add into J with
         # atomics): a separate edge launch in front of the interior one cost a whole extra round of workgroups
@@ -558,14 +569,15 @@ class PicEngine2D:
         fs = ws.get("fs") if self.reuse_slots else None
         if fs is not None and (cols == 0 or cols > fs.edge_cols):
             fs = None        # the order is older than the stacks were sized for
+        surplus = ws["counters"][3:4].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
         if cols:
             check(self.L.lpa_migrate_pack_edges_x(C.byref(pc), C.byref(sp.tiling), cols, xlo, xhi,
                                                   m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
-                                                  C.byref(fs) if fs is not None else None, st),
+                                                  C.byref(fs) if fs is not None else None, surplus, st),
                   "lpa_migrate_pack_edges_x")
         else:
             check(self.L.lpa_migrate_pack_x(C.byref(pc), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
-                                            cap, st), "lpa_migrate_pack_x")
+                                            cap, surplus, st), "lpa_migrate_pack_x")
         if not self.comm.has_left:
             m["r_lo"][:1].zero_()    # open face: nothing arrives (count = 0)
         if not self.comm.has_right:
@@ -598,8 +610,7 @@ class PicEngine2D:
         if self.comm.size == 1:
             self.sync_currents()
             return
-        n = 4 * self.ng * self.grid.NY
-        h = {k: v[:n] for k, v in self._halo_bufs().items()}
+        h = self._halo_views(4 * self.ng * self.grid.NY)
         self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
         packed = [self._mig_pack(i) for i in range(len(self.species)) if self.species[i].n]
         idx = [i for i in range(len(self.species)) if self.species[i].n]
@@ -700,6 +711,10 @@ class PicEngine2D:
             self.comm.exchange(s_, dummy(), dummy(), r_)
             if k:
                 self._append_device(sp, inc[:-1], inc[-1].view(torch.int64))
+        # the tiling (and the age every edge / leaver-column estimate is derived from) refers to the grid origin of
+        # before the shift: re-sort before the next push, whether or not anything arrived or was injected
+        for sp in self.species:
+            sp.steps_since_sort = 1 << 30
 
     def _append_device(self, sp, data_rows, ids):
         k = int(data_rows.shape[1])

@@ -240,8 +240,12 @@ class PicEngine3D:
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
         n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
         area = self.arrival_area()
-        if int(ws["counters"][1].item()) > area:
+        cnts = ws["counters"].tolist()
+        if cnts[1] > area:
             raise _lib.LpaError("arrival area overflow (raise migrate_capacity)")
+        if cnts[3] > 0:
+            raise _lib.LpaError(f"migration message overflow: {cnts[3]} leavers beyond migrate_capacity="
+                                f"{self.migrate_capacity} since the last sort stayed outside the slab (raise migrate_capacity)")
         if n_live + area > cap:
             raise _lib.LpaError(f"particle capacity {cap} < live {n_live} + arrival area {area}")
         sp["data"], sp["alt"] = sp["alt"], sp["data"]
@@ -284,10 +288,19 @@ class PicEngine3D:
     # ---- guards / currents between slabs (sync_guard_fields_3d, sync_currents_3d) -------------------
     def _halo_bufs(self):
         if self._halo is None:
-            n = 4 * self.ng * self.N[1] * self.N[2]
+            # 6 components: a guard sync of E and B together is the largest message
+            n = 6 * self.ng * self.N[1] * self.N[2]
             mk = lambda: torch.empty(n, dtype=torch.float64, device=self.device)
             self._halo = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
         return self._halo
+
+    def _halo_views(self, ncomp):
+        """the first ``ncomp`` components' worth of the four face buffers (the C ABI takes no length: check here)"""
+        n = ncomp * self.ng * self.N[1] * self.N[2]
+        bufs = self._halo_bufs()
+        if any(n > v.numel() for v in bufs.values()):
+            raise _lib.LpaError(f"halo message of {n} doubles exceeds the face buffers")
+        return {k: v[:n] for k, v in bufs.items()}
 
     def _faces(self, op, which=0):
         """both x faces in one launch (lpa_halo_faces); a missing buffer (open chain end) is skipped"""
@@ -301,8 +314,7 @@ class PicEngine3D:
         st = self.stream
         check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
         if self.comm.size > 1:
-            n = 3 * self.ng * self.N[1] * self.N[2]
-            h = {k: v[:n] for k, v in self._halo_bufs().items()}
+            h = self._halo_views(3 * bin(which).count("1"))
             exchange_faces(
                 self.comm,
                 lambda side, b: check(self.L.lpa_halo_pack_guard_src(self._g(), which, side, b.data_ptr(), st),
@@ -315,7 +327,7 @@ class PicEngine3D:
     def sync_currents(self):
         st = self.stream
         if self.comm.size > 1:
-            h = self._halo_bufs()
+            h = self._halo_views(4)
             exchange_faces(
                 self.comm,
                 lambda side, b: check(self.L.lpa_halo_pack_current(self._g(), side, b.data_ptr(), st),
@@ -343,14 +355,15 @@ class PicEngine3D:
         fs = ws.get("fs") if (self.reuse_slots and cols) else None
         if fs is not None and cols > fs.edge_cols:
             fs = None
+        surplus = ws["counters"][3:4].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
         if cols:   # only the edge tile columns + loose particles
             check(self.L.lpa_migrate_pack_edges_x(C.byref(sp["c"]), C.byref(sp["tiling"]), cols, xlo, xhi,
                                                   m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
-                                                  C.byref(fs) if fs is not None else None, st),
+                                                  C.byref(fs) if fs is not None else None, surplus, st),
                   "lpa_migrate_pack_edges_x")
         else:
             check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
-                                            cap, st), "lpa_migrate_pack_x")
+                                            cap, surplus, st), "lpa_migrate_pack_x")
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         cur = ws["counters"][1:2].data_ptr()
         area = self.arrival_area()
@@ -532,6 +545,10 @@ class PicEngine3D:
                                inc.reshape(-1) if inc.numel() else dummy())
             if k:
                 self.append_device(self.species.index(sp), inc)
+        # the tiling (and the age every edge / leaver-column estimate is derived from) refers to the grid origin of
+        # before the shift: re-sort before the next push, whether or not anything arrived or was injected
+        for sp in self.species:
+            sp["since"] = 1 << 30
 
     def append_device(self, i, rows):
         """append particles (device tensor [8][k], ATTRS3 order) behind the stored ones as loose particles
@@ -612,7 +629,7 @@ class PicEngine3D:
                 self.sort(i)
         ready, done = torch.cuda.Event(), torch.cuda.Event()
         ready.record(main)
-        h = self._halo_bufs()
+        h = self._halo_views(4)
         # edge tiles, pack and exchange on the high-priority side stream, the interior tiles on the main stream
         # at the same time (disjoint particles; both add into J with atomics; see PicEngine2D)
         with torch.cuda.stream(self._side):

@@ -433,8 +433,9 @@ class Simulation:
                 # of ranks (the reference spawns one generator per rank, simulation.py:700-716, so ITS
                 # loading depends on the decomposition; identical physics, different noise)
                 b = load_block_device(s, (p.x0, p.y0), (p.nx, p.ny), (self.dx, self.dy), self._seed(s, p.x0, p.y0),
-                                      self.device, id_prefix=(self.comm.rank << 50) | (p.index << 32))
+                                      self.device, id_prefix=self._next_ids(s.ispec))
                 if b is not None:
+                    self._id_next[s.ispec] += b["x"].numel()
                     blocks.append(b)
                 p.particles[s.ispec].initialize(0)     # the mirrors fill at the first download()
             n_tot = sum(b["x"].numel() for b in blocks)
@@ -455,6 +456,18 @@ class Simulation:
         self.pusher = [BorisPusher(self, i) for i in range(len(self.species))]
         self.sorter = [ParticleSort2D(self, i) for i in range(len(self.species))]
         self.initialized = True
+
+    def _next_ids(self, ispec):
+        """first id of the next block this rank creates for species ``ispec``: rank in the bits above 50 (the
+        reference's layout, `core/particles.py:91-116`: rank << 50 | ipatch << 32 | serial), below it ONE
+        running count per rank and species -- initial loading and every window injection draw from it, so
+        ids cannot collide however large a block or however many shifts"""
+        if not hasattr(self, "_id_next"):
+            self._id_next = {}
+        n = self._id_next.setdefault(ispec, 0)
+        if n >= 1 << 50:
+            raise OverflowError("particle id counter exceeds 50 bits")
+        return (self.comm.rank << 50) | n
 
     def _seed(self, s, x0, y0):
         return None if self.random_seed is None else \
@@ -481,9 +494,9 @@ class Simulation:
                 # so a moving window reproduces what a long static box would have held there
                 y0 = j * self.ny_per_patch * self.dy
                 b = load_block_device(s, (x_new, y0), (n, self.ny_per_patch), (self.dx, self.dy),
-                                      self._seed(s, x_new, y0), self.device,
-                                      id_prefix=(self.comm.rank << 50) | ((1 << 17) + j << 32) | (self.window_shifts << 20))
+                                      self._seed(s, x_new, y0), self.device, id_prefix=self._next_ids(s.ispec))
                 if b is not None:
+                    self._id_next[s.ispec] += b["x"].numel()
                     eng.append_particles_device(s.ispec, b)
 
     # ---- host mirrors <-> device --------------------------------------------------------------------
@@ -518,7 +531,7 @@ class Simulation:
             if callable(iv):
                 hit = bool(iv(self))
             elif isinstance(iv, float):
-                hit = int(self.time / iv) > int((self.time - self.dt) / iv) or self.itime == 0
+                hit = (self.time % iv) < self.dt          # callback/callback.py:41
             else:
                 hit = self.itime % int(iv) == 0
             if hit:

@@ -153,8 +153,7 @@ class Simulation3D:
             blocks = []
             for p in mirrors:
                 org = (p.x0, p.y0, p.z0)
-                b = load_block_device(s, org, npp, d, self._seed(s, org), self.device,
-                                      id_prefix=(self.comm.rank << 50) | (p.index << 32))
+                b = load_block_device(s, org, npp, d, self._seed(s, org), self.device)   # the 3-D store keeps no ids
                 if b is not None:
                     blocks.append(b)
                 p.particles[s.ispec].initialize(0)     # the mirrors fill at the first download()
@@ -267,7 +266,7 @@ class Simulation3D:
             if callable(iv):
                 hit = bool(iv(self))
             elif isinstance(iv, float):
-                hit = int(self.time / iv) > int((self.time - self.dt) / iv) or self.itime == 0
+                hit = (self.time % iv) < self.dt          # callback/callback.py:41
             else:
                 hit = self.itime % int(iv) == 0
             if hit:

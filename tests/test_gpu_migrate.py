@@ -35,11 +35,10 @@ class _Mirror(SlabComm):
         return []
 
 
-def _run(reuse, nsteps=18):
+def _run(reuse, nsteps=18, cap=8192):
     nx, ny, ppc = 128, 64, 8
     dx = dy = 0.8e-6 / 20
     dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
-    cap = 8192
     eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", comm=_Mirror(nx * dx, cap), sort_interval=9,
                       block_particles=2048, migrate_capacity=cap)
     eng.reuse_slots = reuse
@@ -86,3 +85,11 @@ def test_arrivals_take_the_slots_their_tile_freed():
     x = sp.cset.arr("x")[: sp.n]
     ids = sp.cset.id[: sp.n][~torch.isnan(x)]
     assert ids.numel() == n and torch.unique(ids).numel() == n
+
+
+def test_send_side_overflow_is_reported():
+    """more leavers per step than ``migrate_capacity``: the surplus stays outside the slab (it is not lost), and the
+    engine says so at its next sort instead of letting it deposit through the torus wrap on the wrong side"""
+    from lambdapic_amd._lib import LpaError
+    with pytest.raises(LpaError, match="migration message overflow"):
+        _run(True, nsteps=12, cap=64)

@@ -73,6 +73,14 @@ def _run(rank, world, port, q):
     g = eng.grid
     sl = slice(3, 3 + nx)
     fields = {a: g.view(a)[sl, 3:3 + NY].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    # the reference's DEFAULT guard sync moves all six components in one call (patch.py:670, mpi_manager.py:111):
+    # scribble over the x guard planes, sync E and B together, and hand the padded slabs back for inspection
+    eb = ("ex", "ey", "ez", "bx", "by", "bz")
+    for a in eb:
+        g.view(a)[:3] = 777.0
+        g.view(a)[3 + nx:] = -777.0
+    eng.sync_guard_fields(eb)
+    fields.update({"pad_" + a: g.view(a)[:, 3:3 + NY].cpu().numpy()[None] for a in eb})
     q.put((rank, np.array(trace), fields))
     if world > 1:
         dist.barrier()
@@ -101,6 +109,17 @@ def _launch(world):
     return trace, fields
 
 
+def _check_padded(fields, world):
+    """x guard planes after a six-component guard sync == the periodic neighbours' interior edges"""
+    nx = NXG // world
+    for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+        whole = fields[a]                                   # [NXG][NY] interiors, ranks concatenated
+        for r in range(world):
+            pad = fields["pad_" + a][r]                     # [nx + 6][NY]
+            rows = (np.arange(-3, nx + 3) + r * nx) % NXG
+            assert np.array_equal(pad, whole[rows]), (a, r)
+
+
 @pytest.fixture(scope="module")
 def single():
     return _launch(1)
@@ -115,8 +134,12 @@ def test_slabs_match_single_rank(single, world):
     np.testing.assert_allclose(tn[:, 1], t1[:, 1], rtol=1e-12)      # total charge
     np.testing.assert_allclose(tn[:, 2], t1[:, 2], rtol=1e-12)      # kinetic energy
     for a in f1:
+        if a.startswith("pad_"):
+            continue
         scale = np.abs(f1[a]).max()
         assert np.abs(fn[a] - f1[a]).max() <= 1e-9 * scale, a
+    _check_padded(f1, 1)
+    _check_padded(fn, world)
 
 
 # ---- laser-target like case (BASELINE config C3 in small): PML on all sides, laser from x-min, plasma
@@ -222,7 +245,7 @@ def test_laser_target_chain_matches_single_rank():
 
 # ---- moving window on a slab chain: the columns that leave a slab's low face become the left
 # ---- neighbour's tail (rotation of the neighbour ring by one patch width) ----------------
-def _run_window(rank, world, port, q):
+def _run_window(rank, world, port, q, inject=True):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -242,7 +265,9 @@ def _run_window(rank, world, port, q):
     dens = lambda x, y: np.where((x > 150 * dx) & (abs(y - ny * dy / 2) < 20 * dy), 0.05 * nc, 0.0)
     sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=0.01))
     laser = SimpleLaser2D(a0=1.5, w0=1.2e-6, ctau=1.5e-6, l0=lam)
-    mw = MovingWindow(velocity=C, start_time=0.6 * nx * dx / C)
+    # inject=False: the last rank gets neither arrivals nor fresh particles at a shift -- its tiling must still
+    # be rebuilt for the moved origin (edge / leaver columns, tile margins)
+    mw = MovingWindow(velocity=C, start_time=0.6 * nx * dx / C, inject_particles=inject)
     trace = []
     for it in range(520):
         sim.run(1, callbacks=[laser, mw])
@@ -259,11 +284,11 @@ def _run_window(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _launch_window(world):
+def _launch_window(world, inject=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_window, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_window, args=(r, world, port, q, inject)) for r in range(world)]
     for p in procs:
         p.daemon = True
         p.start()
@@ -288,6 +313,20 @@ def test_moving_window_chain_matches_single_rank():
     assert t1[-1, 3] > 1000                                        # plasma was injected and kept
     assert np.array_equal(t2[:, 3], t1[:, 3])
     np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
+
+
+def test_moving_window_chain_without_injection_matches_single_rank():
+    t1, f1 = _launch_window(1, inject=False)
+    t2, f2 = _launch_window(2, inject=False)
+    assert f1["_x0"][0, 0] >= 4 * 32 and np.array_equal(f1["_x0"][0], f2["_x0"][0])
+    assert 0 < t1[-1, 3] < t1[0, 3]                                # plasma leaves through the low face, none enters
+    assert np.array_equal(t2[:, 3], t1[:, 3])
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 1], t1[:, 1], rtol=1e-9, atol=1e-12 * np.abs(t1[:, 1]).max())
     np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
         scale = np.abs(f1[a]).max()
@@ -329,6 +368,13 @@ def _run_3d(rank, world, port, q):
         trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
     sl = (slice(3, 3 + nx), slice(3, 3 + ny), slice(3, 3 + nz))
     fields = {a: eng.view(a)[sl].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    # E and B guards in ONE call (which = 3): six components per face message
+    eb = ("ex", "ey", "ez", "bx", "by", "bz")
+    for a in eb:
+        eng.view(a)[:3] = 777.0
+        eng.view(a)[3 + nx:] = -777.0
+    eng.sync_guard_fields(3)
+    fields.update({"pad_" + a: eng.view(a)[:, 3:3 + ny, 3:3 + nz].cpu().numpy()[None] for a in eb})
     q.put((rank, np.array(trace), fields))
     if world > 1:
         dist.barrier()
@@ -365,8 +411,16 @@ def test_3d_slabs_match_single_rank():
     np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-12)
     assert np.abs(t2[:, 1] - t1[:, 1]).max() <= 1e-12 * 8192 * 1e27 * 4e-8 * 5e-8 * 6e-8 / 4 * 1.6e-19
     for a in f1:
+        if a.startswith("pad_"):
+            continue
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * scale, a
+    for f, world in ((f1, 1), (f2, 2)):                 # x guard planes == the periodic neighbours' interior edges
+        nxl = 16 // world
+        for a in ("ex", "ey", "ez", "bx", "by", "bz"):
+            for r in range(world):
+                rows = (np.arange(-3, nxl + 3) + r * nxl) % 16
+                assert np.array_equal(f["pad_" + a][r], f[a][rows]), (a, world, r)
 
 
 # ---- 3-D chain with CPML on all faces, laser from x-min, plasma slab: 2 slabs against 1 ----------------
