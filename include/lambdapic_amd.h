@@ -348,6 +348,38 @@ int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_
                        int32_t *cursor, const double *buf, int64_t capacity, double shift_x,
                        void *stream);
 
+/* ---- patch-list drop-ins: the reference's own data model (lists of per-patch arrays in the WRAPPED guard
+ *      layout of core/fields.py:24-27, neighbour tables Patch.neighbor_ipatch[8] in Boundary2D order,
+ *      core/patch/patch.py:24-35) kept on the device.  `arrays` is a DEVICE table of device pointers,
+ *      [npatches][ncomp] (ncomp = 4 for the currents: jx jy jz rho); `neighbor_ipatch` a device int64
+ *      [npatches][8], -1 = no neighbour.
+ *      lpa_sync_guard_fields_2d replaces sync_guard_fields_2d(fields_list, patches_list, attrs, npatches, nx,
+ *        ny, ng) (core/patch/sync_fields2d.c:150-255): guard <- the neighbour's interior edge, 8 neighbours.
+ *      lpa_sync_currents_2d replaces sync_currents_2d(fields_list, patches_list, npatches, nx, ny, ng)
+ *        (core/patch/sync_fields2d.c:43-148): interior edge += the neighbour's guard (added in the
+ *        reference's boundary order: bit-identical sums), consumed guards zeroed. */
+int lpa_sync_guard_fields_2d(double *const *arrays, int32_t ncomp, const int64_t *neighbor_ipatch,
+                             int32_t npatches, int32_t nx, int32_t ny, int32_t ng, void *stream);
+int lpa_sync_currents_2d(double *const *arrays, const int64_t *neighbor_ipatch, int32_t npatches, int32_t nx,
+                         int32_t ny, int32_t ng, void *stream);
+
+/* ---- bucket sort with the reference's bookkeeping, one patch per call: replaces the body of
+ *      sort_particles_patches_2d / _3d (core/sort/cpu2d.c:220-303, cpu3d.c) = calculate_bucket_index (:9-54:
+ *      bucket = floor((r - r0) / d) per axis, out of range -> last bucket or clamped when reverse_x, a dead
+ *      slot inherits the bucket of the slot before it) + calculate_bucket_bound (:78-91) + bucket_sort
+ *      (:108-189: in-place permutation of all attributes and is_dead restricted to the misplaced slots; an
+ *      already sorted store moves nothing).  Outputs: bucket_count / bucket_bound_min / bucket_bound_max
+ *      (device int64[nx*ny*nz], what the collision module reads) and *nbuf (device int64) = slots moved.
+ *      Which misplaced particle of a bucket lands in which of its free slots is implementation defined
+ *      (here: atomic order), as in the reference.  `attrs` is a HOST array of `nattrs` device pointers
+ *      (x, y, z are moved whether or not they are listed); nz = 1 selects 2-D (z, dz, z0 unused). */
+int64_t lpa_bucket_sort_workspace_bytes(int64_t npart, int64_t nbuckets);
+int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead, double *const *attrs, int32_t nattrs,
+                    int64_t npart, int64_t nx, int64_t ny, int64_t nz, double dx, double dy, double dz,
+                    double x0, double y0, double z0, int32_t reverse_x, int64_t *bucket_count,
+                    int64_t *bucket_bound_min, int64_t *bucket_bound_max, void *workspace,
+                    int64_t workspace_bytes, int64_t *nbuf, void *stream);
+
 /* ---- diagnostics the parity contract is stated on (field energy, kinetic energy, total
  *      charge; reference tests/test_numerical_heating.py:19-50).  out[] is device memory and is
  *      accumulated into (zero it first).

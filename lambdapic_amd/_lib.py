@@ -125,6 +125,11 @@ SIGNATURES = {
     "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp, _vp]),
     "lpa_migrate_unpack_tiled": (_i, [_P, _G, _T, _FS, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
+    "lpa_sync_guard_fields_2d": (_i, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "lpa_sync_currents_2d": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "lpa_bucket_sort_workspace_bytes": (_i64, [_i64, _i64]),
+    "lpa_bucket_sort": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int32, _i64, _i64, _i64, _i64, _d, _d, _d,
+                             _d, _d, _d, C.c_int32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
     "lpa_selftest_wave_reduce": (_i, [_vp, _vp, _vp]),

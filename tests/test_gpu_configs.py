@@ -281,8 +281,8 @@ def test_c5_slab_full_size_two_species():
         return tot, tot_abs, n
 
     n_init = live()[2]
-    cols = nx - int(np.ceil(1e-6 / dx - 0.5 + 1e-9))             # cell columns with x_i > 1 um
-    assert n_init == 2 * ppc * cols * ny * nz > 60_000_000
+    cols = int((np.arange(nx) * dx > 1e-6).sum())                # cell columns with x_i > 1 um: 38 of 64
+    assert n_init == 2 * ppc * cols * ny * nz > 39_000_000
 
     def near_bounds():       # live particles one step (< 1 cell) away from an absorbing bound, see the 2-D helper
         cnt, dd = 0, (dx, dy, dz)

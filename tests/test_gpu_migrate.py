@@ -92,4 +92,4 @@ def test_send_side_overflow_is_reported():
     engine says so at its next sort instead of letting it deposit through the torus wrap on the wrong side"""
     from lambdapic_amd._lib import LpaError
     with pytest.raises(LpaError, match="migration message overflow"):
-        _run(True, nsteps=12, cap=64)
+        _run(True, nsteps=12, cap=16)
