@@ -276,3 +276,128 @@ def update_bfield_3d(f, dt):
     g = _GridOnDevice(f, dev)
     check(L.lpa_fdtd_b_3d(g.ref(), dt, _stream(dev)), "lpa_fdtd_b_3d")
     g.download(["bx", "by", "bz"])
+
+
+# ---- patch-list drop-ins (lpa_patches.hip): the reference's data model kept on the device ----------------------
+def _patch_arrays_on_device(fields_list, attrs, npatches, dev):
+    """stack the (wrapped-layout) arrays of ``attrs`` of every patch into one device tensor
+    [npatches][len(attrs)][NX][NY] + the device pointer table the kernels index"""
+    host = np.stack([np.stack([np.ascontiguousarray(getattr(f, a), dtype=np.float64) for a in attrs])
+                     for f in fields_list[:npatches]])
+    buf = torch.from_numpy(host).to(dev)
+    ptrs = torch.tensor([buf[p, c].data_ptr() for p in range(npatches) for c in range(len(attrs))],
+                        dtype=torch.int64, device=dev)
+    return buf, ptrs
+
+
+def _neighbor_table(patches_list, npatches, dev):
+    nb = np.stack([np.asarray(p.neighbor_ipatch, dtype=np.int64) for p in patches_list[:npatches]])
+    if nb.shape != (npatches, 8):
+        raise ValueError("neighbor_ipatch must have the 8 entries of Boundary2D")
+    if (nb >= npatches).any():
+        raise ValueError("neighbor_ipatch points outside the patch list")
+    return torch.from_numpy(nb).to(dev)
+
+
+def sync_guard_fields_2d(fields_list, patches_list, attrs, npatches, nx, ny, ng):
+    """GPU drop-in for `core/patch/sync_fields2d.c:150-255`
+    (``sync_guard_fields_2d(fields_list, patches_list, attrs, npatches, nx, ny, ng) -> None``)"""
+    L, dev = lib(), _device()
+    attrs = list(attrs)
+    if npatches <= 0 or not attrs:
+        return None
+    buf, ptrs = _patch_arrays_on_device(fields_list, attrs, npatches, dev)
+    nb = _neighbor_table(patches_list, npatches, dev)
+    check(L.lpa_sync_guard_fields_2d(ptrs.data_ptr(), len(attrs), nb.data_ptr(), npatches, nx, ny, ng, _stream(dev)),
+          "lpa_sync_guard_fields_2d")
+    out = buf.cpu().numpy()
+    for p, f in enumerate(fields_list[:npatches]):
+        for c, a in enumerate(attrs):
+            getattr(f, a)[...] = out[p, c]
+    return None
+
+
+def sync_currents_2d(fields_list, patches_list, npatches, nx, ny, ng):
+    """GPU drop-in for `core/patch/sync_fields2d.c:43-148`
+    (``sync_currents_2d(fields_list, patches_list, npatches, nx, ny, ng) -> None``)"""
+    L, dev = lib(), _device()
+    if npatches <= 0:
+        return None
+    attrs = ["jx", "jy", "jz", "rho"]
+    buf, ptrs = _patch_arrays_on_device(fields_list, attrs, npatches, dev)
+    nb = _neighbor_table(patches_list, npatches, dev)
+    check(L.lpa_sync_currents_2d(ptrs.data_ptr(), nb.data_ptr(), npatches, nx, ny, ng, _stream(dev)),
+          "lpa_sync_currents_2d")
+    out = buf.cpu().numpy()
+    for p, f in enumerate(fields_list[:npatches]):
+        for c, a in enumerate(attrs):
+            getattr(f, a)[...] = out[p, c]
+    return None
+
+
+def _bucket_sort_patch(L, dev, x, y, z, is_dead, attrs, x0, y0, z0, n, d, bucket_count, bmin, bmax, reverse_x):
+    npart = int(x.shape[0])
+    nbin = int(np.prod(n))
+    dim3 = z is not None
+    host = [x, y] + ([z] if dim3 else []) + [a for a in attrs if a is not x and a is not y and a is not z]
+    data = torch.from_numpy(np.stack([np.asarray(a, dtype=np.float64) for a in host]) if npart else
+                            np.zeros((len(host), 0))).to(dev)
+    dead = torch.from_numpy(np.ascontiguousarray(is_dead[:npart]).view(np.uint8).copy()).to(dev)
+    cnt = torch.zeros(3 * nbin, dtype=torch.int64, device=dev)
+    nbytes = L.lpa_bucket_sort_workspace_bytes(npart, nbin)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    nbuf = torch.zeros(1, dtype=torch.int64, device=dev)
+    ptr = lambda k: data[k].data_ptr() if npart else None
+    table = (C.c_void_p * len(host))(*[ptr(k) for k in range(len(host))])
+    check(L.lpa_bucket_sort(ptr(0), ptr(1), ptr(2) if dim3 else None, dead.data_ptr() if npart else None, table,
+                            len(host), npart, n[0], n[1], n[2], d[0], d[1], d[2], x0, y0, z0, int(bool(reverse_x)),
+                            cnt[:nbin].data_ptr(), cnt[nbin:2 * nbin].data_ptr(), cnt[2 * nbin:].data_ptr(),
+                            ws.data_ptr(), ws.numel(), nbuf.data_ptr(), _stream(dev)), "lpa_bucket_sort")
+    out = data.cpu().numpy()
+    for k, a in enumerate(host):
+        a[:npart] = out[k]
+    is_dead[:npart] = dead.cpu().numpy().view(np.bool_)
+    c = cnt.cpu().numpy()
+    bucket_count.reshape(-1)[:] = c[:nbin]
+    bmin.reshape(-1)[:] = c[nbin:2 * nbin]
+    bmax.reshape(-1)[:] = c[2 * nbin:]
+    return int(nbuf.item())
+
+
+def sort_particles_patches_2d(x_list, y_list, is_dead_list, attrs_list, x0s, y0s, nx, ny, dx, dy, npatches,
+                              bucket_count_list, bucket_bound_min_list, bucket_bound_max_list,
+                              bucket_count_not_list, bucket_start_counter_list, particle_index_list,
+                              particle_index_ref_list, particle_index_target_list, buf_list, reverse_x):
+    """GPU drop-in for `core/sort/cpu2d.c:220-303` with the reference's argument list (the last six lists are
+    the CPU algorithm's scratch and are left untouched).  Returns the number of slots moved; arrays are
+    permuted in place, ``bucket_count`` / ``bucket_bound_min`` / ``bucket_bound_max`` are filled."""
+    L, dev = lib(), _device()
+    if npatches <= 0:
+        return 0
+    nattrs = len(attrs_list) // npatches
+    moved = 0
+    for ip in range(npatches):
+        moved += _bucket_sort_patch(L, dev, x_list[ip], y_list[ip], None, is_dead_list[ip],
+                                    attrs_list[ip * nattrs:(ip + 1) * nattrs], float(x0s[ip]), float(y0s[ip]), 0.0,
+                                    (int(nx), int(ny), 1), (float(dx), float(dy), 1.0), bucket_count_list[ip],
+                                    bucket_bound_min_list[ip], bucket_bound_max_list[ip], reverse_x)
+    return moved
+
+
+def sort_particles_patches_3d(x_list, y_list, z_list, is_dead_list, attrs_list, x0s, y0s, z0s, nx, ny, nz, dx, dy,
+                              dz, npatches, bucket_count_list, bucket_bound_min_list, bucket_bound_max_list,
+                              bucket_count_not_list, bucket_start_counter_list, particle_index_list,
+                              particle_index_ref_list, particle_index_target_list, buf_list, reverse_x):
+    """GPU drop-in for ``sort_particles_patches_3d`` (`core/sort/cpu3d.c`), see the 2-D twin"""
+    L, dev = lib(), _device()
+    if npatches <= 0:
+        return 0
+    nattrs = len(attrs_list) // npatches
+    moved = 0
+    for ip in range(npatches):
+        moved += _bucket_sort_patch(L, dev, x_list[ip], y_list[ip], z_list[ip], is_dead_list[ip],
+                                    attrs_list[ip * nattrs:(ip + 1) * nattrs], float(x0s[ip]), float(y0s[ip]),
+                                    float(z0s[ip]), (int(nx), int(ny), int(nz)), (float(dx), float(dy), float(dz)),
+                                    bucket_count_list[ip], bucket_bound_min_list[ip], bucket_bound_max_list[ip],
+                                    reverse_x)
+    return moved
