@@ -171,10 +171,172 @@ def cpu_baseline(args):
     except (OSError, ValueError):
         pass
     return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "port_over_reference_same_cores": ratio, "parity_c1": parity_c1(),
+            "port_over_reference_same_cores": ratio,
+            "port_over_reference_source": "recorded in the build container (oracle/cpu_ratio.py -> "
+                                          "profiles/r01_cpu_port_vs_reference.txt); the reference cannot travel",
+            "parity_c1": parity_c1(),
             "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
                       f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
                       f"-O3 -march=native, {threads} OpenMP threads"}
+
+
+def source_hash():
+    """sha256 of the K1 sources: a recorded profile (traffic, port / reference ratio) is only quoted for the code it
+    was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lambdapic_amd/csrc/lpa_particles.hip", "lambdapic_amd/csrc/lpa_common.hpp"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(args, kernel_prefix):
+    """HBM bytes of one K1 launch from the committed rocprofv3 --pmc passes (tools/prof_pmc.sh ->
+    tools/make_traffic_json.py): counters cannot be read from inside this process.  Refused (None + the reason)
+    when the file was recorded for another kernel, another workload or other kernel sources."""
+    path = os.path.join(ROOT, "profiles", "r02_k1_traffic.json")
+    try:
+        with open(path) as fh:
+            tr = json.load(fh)
+    except Exception as e:   # noqa: BLE001
+        return None, f"no traffic profile ({e.__class__.__name__})"
+    if tr.get("config") != {"nx": args.nx, "ny": args.ny, "ppc": args.ppc}:
+        return None, "traffic profile is for another workload"
+    if not str(tr.get("kernel", "")).startswith(kernel_prefix):
+        return None, "traffic profile is for another kernel"
+    if tr.get("source_sha256_16") != source_hash():
+        return None, "traffic profile predates the current kernel sources: re-run tools/prof_pmc.sh"
+    return tr["traffic_bytes_per_launch"], f"recorded: profiles/r02_k1_traffic.json @ sources {tr['source_sha256_16']}"
+
+
+class StageTimer:
+    """HIP events around the engine's own entry points, grouped into stages (timed on the stream they run on)"""
+
+    def __init__(self, eng, groups):
+        self.ev = {g: [] for g in groups}
+        for g, names in groups.items():
+            for name in names:
+                if hasattr(eng, name):
+                    setattr(eng, name, self._wrap(getattr(eng, name), g, eng.device))
+
+    def _wrap(self, fn, g, device):
+        def timed(*a, **k):
+            st = torch.cuda.current_stream(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r = fn(*a, **k)
+            e1.record(st)
+            self.ev[g].append((e0, e1))
+            return r
+        return timed
+
+    def reset(self):
+        for v in self.ev.values():
+            v.clear()
+
+    def ms_per_step(self, steps):
+        return {g: float(sum(a.elapsed_time(b) for a, b in v)) / steps for g, v in self.ev.items()}
+
+
+STAGES_2D = {"fdtd_cpml": ["update_efield", "update_bfield", "laser_inject"], "guards": ["sync_guard_fields"],
+             "push_deposit": ["push_deposit"], "sort": ["sort"], "fold_migrate": ["sync_currents", "sync_particles"],
+             "reset": ["reset_current"], "window": ["shift_window"]}
+
+
+def extra_c3(steps=400, warm=40):
+    """BASELINE config C3 (2-D laser-target, `example/laser-target.py:28-66`): 2048 x 1024 cells at lambda / 50,
+    1 um slab of e- + p at 32 ppc each, CPML on all sides, GaussianLaser2D a0 = 10, tile sort + a moving window
+    that shifts inside the timed region -- through the Simulation stage loop, one GPU."""
+    from lambdapic_amd import constants
+    from lambdapic_amd.laser import GaussianLaser2D
+    from lambdapic_amd.simulation import MovingWindow, Simulation, Species
+    nx, ny, ppc = 2048, 1024, 32
+    dx = dy = LAMBDA0 / 50
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
+    sim = Simulation(nx, ny, dx, dy, npatch_x=nx // 64, npatch_y=ny // 64, random_seed=1, sort_interval=20)
+    Lx = nx * dx
+    dens = lambda x, y: np.where((x > Lx / 2) & (x < Lx / 2 + 1e-6), 10 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=ppc, momentum_sigma=0.01))
+    sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=ppc))
+    sim.initialize()
+    eng = sim.engine
+    cbs = [GaussianLaser2D(a0=10.0, l0=LAMBDA0, w0=2e-6, ctau=2e-6, x0=4e-6),
+           MovingWindow(velocity=C_LIGHT, start_time=(warm + 0.25 * steps) * sim.dt)]
+    timer = StageTimer(eng, STAGES_2D)
+    sim.run(warm, callbacks=cbs)
+    timer.reset()
+    eng.kernel_events = []
+    torch.cuda.synchronize()
+    n0 = sum(eng.diagnostics()["nalive"])
+    t0 = time.perf_counter()
+    sim.run(steps, callbacks=cbs)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n1 = sum(eng.diagnostics()["nalive"])
+    alive = 0.5 * (n0 + n1)
+    stage = timer.ms_per_step(steps)
+    k1_ms = float(sum(a.elapsed_time(b) for a, b in eng.kernel_events)) / steps
+    ms = 1e3 * el / steps
+    t = eng.cpml_thickness
+    psi_cells = 2 * t * (nx + ny)                       # layer cells (the x layers leave when the window starts)
+    b_fields = 336.0 * nx * ny + 4 * 32.0 * psi_cells   # FDTD 336 B/cell/step + psi_a, psi_b RMW per half step
+    b_k1 = BYTES_PER_PARTICLE * alive + GATHER_SCATTER_BYTES_PER_CELL * nx * ny
+    dom = max(stage, key=stage.get)
+    dom_bytes = {"fdtd_cpml": b_fields, "push_deposit": b_k1}.get(dom)
+    return {"workload": "C3: 2-D laser-target 2048x1024 cells (lambda/50), e- + p 32 ppc each in a 1 um slab, CPML, "
+                        "GaussianLaser2D a0=10, tile sort every 20 steps, moving window at c (Simulation stage loop)",
+            "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": ms, "steps": steps,
+            "alive": int(alive), "window_shifts": int(getattr(sim, "window_shifts", 0)),
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage.items()},
+            "roofline": {"bound": "hbm", "scope": "step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "algorithmic_bytes_per_step": b_fields + b_k1,
+                         "achieved": (b_fields + b_k1) / (ms * 1e-3) / 1e9,
+                         "frac": (b_fields + b_k1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "dominant_stage": dom,
+                         "dominant_stage_frac": (dom_bytes / (stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_bytes else None,
+                         "k1_kernel_ms": k1_ms,
+                         "note": "4 M particles on 2.1 M cells: the step is field / launch bound, not particle bound"}}
+
+
+def extra_c5(steps=40, warm=12):
+    """one GPU's slab of BASELINE config C5 (3-D laser-target, `example/laser-target-3d.py:26-60`): 64 x 256 x 256
+    cells, e- + p at 8 ppc each for x > 1 um, CPML on six faces, GaussianLaser3D -- Simulation3D stage loop"""
+    from lambdapic_amd import constants
+    from lambdapic_amd.laser import GaussianLaser3D
+    from lambdapic_amd.simulation3d import Simulation3D, Species
+    nx, ny, nz, ppc = 64, 256, 256, 8
+    dx, dy, dz = LAMBDA0 / 20, LAMBDA0 / 10, LAMBDA0 / 10
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
+    sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=nx // 32, npatch_y=ny // 64, npatch_z=nz // 64,
+                       random_seed=1, sort_interval=10)
+    dens = lambda x, y, z: np.where(x > 1e-6, nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=ppc, momentum_sigma=0.01))
+    sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=ppc))
+    sim.initialize()
+    eng = sim.engine
+    cbs = [GaussianLaser3D(a0=10.0, l0=LAMBDA0, w0=2e-6, ctau=3e-6, x0=6e-6)]
+    sim.run(warm, callbacks=cbs)
+    eng.kernel_events = []
+    torch.cuda.synchronize()
+    n0 = sum(eng.diagnostics()["nalive"])
+    t0 = time.perf_counter()
+    sim.run(steps, callbacks=cbs)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n1 = sum(eng.diagnostics()["nalive"])
+    alive = 0.5 * (n0 + n1)
+    k_ms = float(sum(a.elapsed_time(b) for a, b in eng.kernel_events)) / steps     # both species' launches
+    ms = 1e3 * el / steps
+    b_k1 = 121.0 * alive                                  # SURVEY 8(d): 3-D particle-update
+    return {"workload": "C5 slab: one GPU's 64x256x256 cells of the 3-D laser-target (dx=lambda/20, dy=dz=lambda/10), "
+                        "e- + p 8 ppc each for x > 1 um, CPML on 6 faces, GaussianLaser3D a0=10, tile sort every 10 "
+                        "steps (Simulation3D stage loop)",
+            "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": ms, "steps": steps,
+            "alive": int(alive),
+            "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_3d", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch_set": b_k1,
+                         "achieved": b_k1 / (k_ms * 1e-3) / 1e9, "frac": b_k1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
 def main():
@@ -191,6 +353,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5-slab legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank path with ranks sharing GPUs (buffers staged "
                          "through the host); the driver's runs use nccl (RCCL)")
@@ -273,16 +436,7 @@ def main():
     alive = d["nalive"][0]
     alg_bytes = BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * args.nx * args.ny
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if ev else float("nan")
-    # HBM traffic of one K1 launch: PMC counters cannot be read from inside this process; the value
-    # comes from the committed rocprofv3 --pmc passes of this same workload (profiles/, tools/prof_pmc.sh)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as fh:
-            tr = json.load(fh)
-        if tr["config"] == {"nx": args.nx, "ny": args.ny, "ppc": args.ppc}:
-            traffic = tr["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    traffic, traffic_source = recorded_traffic(args, "k_push_deposit_tiled_2d")
     n_total = n_local * comm.size
     out = {
         "metric": "particle-updates/sec", "value": n_total * args.steps / elapsed,
@@ -298,8 +452,20 @@ def main():
                    "part_eb_writeback": False},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
+                     "traffic_source": traffic_source},
     }
+    if comm.rank == 0 and comm.size == 1 and not args.no_extra:
+        # north_star: "uniform-plasma and laser-target configs": the other single-GPU configs, bounded legs
+        del eng
+        torch.cuda.empty_cache()
+        out["extra"] = []
+        for leg in (extra_c3, extra_c5):
+            try:
+                out["extra"].append(leg())
+            except Exception as e:   # noqa: BLE001 -- the headline number stands on its own
+                out["extra"].append({"workload": leg.__name__, "value": None, "error": repr(e)})
+            torch.cuda.empty_cache()
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args)

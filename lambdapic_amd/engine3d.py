@@ -162,6 +162,9 @@ class PicEngine3D:
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
         self._axes = {}
+        # bench instrumentation: when a list, (start, end) HIP events are recorded around every launch of the
+        # tiled push+deposit kernel on the stream it runs on
+        self.kernel_events = None
 
     @property
     def stream(self):
@@ -595,9 +598,16 @@ class PicEngine3D:
         else:
             ovf, cnt = ws["overflow"], ws["count"]
         cnt.zero_()
+        timed = self.kernel_events is not None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         check(L.lpa_push_deposit_tiled_part_3d(g, C.byref(sp["c"]), C.byref(pp), C.byref(sp["tiling"]),
                                                ovf.data_ptr(), cnt.data_ptr(), part, edge_cols,
                                                st), "lpa_push_deposit_tiled_3d")
+        if timed:
+            e1.record(torch.cuda.current_stream(self.device))
+            self.kernel_events.append((e0, e1))
         check(L.lpa_push_deposit_list_3d(g, C.byref(sp["c"]), C.byref(pp), ovf.data_ptr(),
                                          cnt.data_ptr(), sp["n_sorted"], st), "lpa_push_deposit_list_3d")
         loose = sp["n"] - sp["n_sorted"]        # arrival area: pushed by the global kernel until the next sort

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""profiles/r02_k1_traffic.json from the 'fetch' and 'write' passes of tools/prof_pmc.sh.
+
+usage: tools/make_traffic_json.py <pmc-outdir> [kernel-substring]   (run where the passes were collected, or on
+their merged gpurun_out copy).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KB; on gfx950
+FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md, HBM section).  The file carries the hash of
+the kernel sources it was measured on; bench.py refuses it for any other."""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+d, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "k_push_deposit_tiled_2d")
+vals, name = {}, None
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if flt in r["Kernel_Name"]:
+            name = r["Kernel_Name"]
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+mean = lambda k: sum(vals[k]) / len(vals[k])
+import hashlib
+h = hashlib.sha256()
+for f in ("lambdapic_amd/csrc/lpa_particles.hip", "lambdapic_amd/csrc/lpa_common.hpp"):
+    h.update(open(os.path.join(ROOT, f), "rb").read())
+out = {"kernel": name.replace("void ", "").split("(")[0].replace(", ", ","),
+       "config": {"nx": 1024, "ny": 1024, "ppc": 64},
+       "FETCH_SIZE_KB_mean": mean("FETCH_SIZE"), "WRITE_SIZE_KB_mean": mean("WRITE_SIZE"),
+       "launches": len(vals["FETCH_SIZE"]),
+       "correction": "gfx950: FETCH_SIZE x 2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+       "traffic_bytes_per_launch": (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024.0,
+       "source_sha256_16": h.hexdigest()[:16],
+       "source": "tools/prof_pmc.sh passes 'fetch' and 'write' (rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / --pmc WRITE_SIZE), "
+                 "bench.py --no-cpu-baseline --no-extra --steps 4 --warmup 2"}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_k1_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

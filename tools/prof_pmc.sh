@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$ROOT/$OUT/$name" -- \
-     python3 "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS > "$ROOT/$OUT/$name.log" 2>&1
+     python3 "$ROOT/bench.py" --no-cpu-baseline --no-extra $BENCH_ARGS > "$ROOT/$OUT/$name.log" 2>&1
   echo "pass $name exit $?"
 }
 BENCH_ARGS="${BENCH_ARGS:---steps 4 --warmup 2}"
