@@ -77,7 +77,21 @@ typedef struct {
                                   doubles each, e.g. the idle half of the ping-pong sort stores -- seven for a
                                   2-D tiling, eight for a 3-D one.  The tiled push kernels park the particles that
                                   changed cell there and deposit them on the general window in a dense second
-                                  pass                                                                     */
+                                  pass.  scratch[7] of a 2-D tiling (optional): one more 8-byte array, holds the ids
+                                  of the particles the in-kernel re-seating moves                          */
+    /* in-kernel cell-index sort of lpa_push_deposit_tiled_2d (optional; all three pointers or none):
+     * slot_class[n_sorted] (caller's memory, two bytes per slot) holds the y-class (cell row mod 32 inside the
+     * tile) every slot was sorted for; with class_init != 0 the push (re)writes it -- set it for the first push
+     * after every sort.  Each step the kernel re-seats the particles whose next gather cell has another class
+     * than their slot (a permutation inside each work block), so the LDS atomics of a 16-lane group keep
+     * hitting 16 different bank pairs between two sorts.  aux_slot / aux_info: uint32 scratch of n_sorted
+     * entries each -- lpa_sort_tiles_* points them at two arrays of its workspace that are idle between sorts. */
+    uint16_t *slot_class;
+    uint32_t *aux_slot, *aux_info;
+    uint32_t *reloc_stats;     /* optional diagnostics, 4 counters the kernel adds to: particles parked for the second
+                                  pass, movers, slots left in the class pools after the class-matched round (twice:
+                                  [2] counted from the pools, [3] from the movers without a seat -- they must agree) */
+    int32_t class_init, reserved2_;
 } lpa_tiling;
 
 #define LPA_TILE_X 8       /* cells per tile along x                                            */

@@ -47,7 +47,9 @@ class lpa_tiling(C.Structure):
                 ("max_blocks", C.c_int32), ("order", C.c_int32),
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
-                ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 8)]
+                ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 8),
+                ("slot_class", C.c_void_p), ("aux_slot", C.c_void_p), ("aux_info", C.c_void_p),
+                ("reloc_stats", C.c_void_p), ("class_init", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class lpa_cpml_axis(C.Structure):

@@ -239,18 +239,46 @@ struct Scratch7 { double *a[7]; };
 #ifndef LPA_SKIP_NULL_RUN
 #define LPA_SKIP_NULL_RUN 1
 #endif
-template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER>
-__global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
+// RELOC -- the in-kernel cell-index sort.  What makes the deposit fast is that the 16 lanes the LDS serves per pass
+// touch 16 different bank pairs, i.e. sit in 16 different y-cells mod 16 (a freshly sorted stripe); every lane that
+// has drifted to another y-cell since the sort costs its group a second pass on all 30 atomics (K1 is 1.65 ms right
+// after a sort, 1.95 ms averaged over 20 steps on C2).  So every slot of the ordered store carries the y-class
+// (ly mod 32) it was sorted for (`cls`, one byte per slot, written by the first push after a sort), and every step
+// the particles whose NEXT gather cell has another class are re-seated: they are parked like the cell-crossers
+// (state + id), their slots form per-class pools, and each takes a slot of its new class from the pool -- a
+// permutation among the movers of one work block, ~2.4 % of the particles per step at 1 keV, no holes created.  A
+// mover that finds no slot of its class takes any left-over one and tries again next step (it is a mover as long
+// as its class differs from its slot's).  Row (x) drift needs no repair: the LDS row stride is a multiple of the
+// bank count.
+struct Reloc {
+    uint16_t *cls;           // [n_sorted] y-class of every slot (16-bit: a byte store would alias every array)
+    uint32_t *aux_slot;      // [n_sorted] scratch: slot of a parked particle
+    uint32_t *aux_info;      // [n_sorted] scratch: flags | slot class << 8 | new class << 16
+    unsigned long long *aux_id;   // [n_sorted] scratch: id of a parked mover
+    uint32_t *stats;         // optional [4]: parked, movers, movers that left their slot, movers without a slot of their class
+    int init;                // first push after a sort: the classes are (re)written, not read (host side: selects the instantiation)
+};
+constexpr int RL_CLASSES = 32, RL_DEPTH = 16;
+constexpr uint32_t RL_DEP = 1u, RL_MOV = 2u;
+
+// RELOC_MODE: 0 = off, 1 = on, 2 = on and this is the first push after a sort (the classes are written, not read:
+// its own instantiation, the 16-bit store in the loop costs the steady-state kernel 44 spilled VGPRs otherwise)
+template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE>
+__global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
                                                               const int32_t *__restrict__ blk_end,
                                                               const int32_t *__restrict__ n_blocks,
                                                               int tiles_y, uint32_t *overflow,
                                                               uint32_t *overflow_count, int part,
-                                                              int tiles_x, int edge_cols, Scratch7 sc) {
+                                                              int tiles_x, int edge_cols, Scratch7 sc, Reloc rl) {
+    constexpr bool RELOC = RELOC_MODE != 0, RL_INIT = RELOC_MODE == 2;
+    static_assert(!RELOC || (DEFER && !WAVE_REDUCE && !WRITE_EB), "RELOC rides on the parked-crosser pass");
     __shared__ __attribute__((aligned(16))) double s_eb[RSZ];
     __shared__ double s_j[4][RSZJ];
     __shared__ int s_ncross;
+    __shared__ int s_stk_cnt[RELOC ? RL_CLASSES : 1], s_stk[RELOC ? RL_CLASSES * RL_DEPTH : 1];
+    __shared__ int s_hl_dst[RELOC ? RL_CLASSES * RL_DEPTH : 1], s_nhl;
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), work blocks
     // are in tile order: give every XCD a contiguous run of them, so that neighbouring tiles -- which
     // share halo rows of E / B and flush into the same J lines -- meet in one L2 (measured effect on C2:
@@ -271,6 +299,10 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
     if (DEFER && threadIdx.x == 0) s_ncross = 0;
+    if (RELOC) {
+        if (threadIdx.x < RL_CLASSES) s_stk_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_nhl = 0;
+    }
 
     // ---- stage E/B (along an open axis nodes outside the padded array are never touched by a fast-path
     //      particle)
@@ -323,6 +355,10 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         const int ip = it + lane;
         bool valid = ip < end;
         double x = nx_, y = ny_, ux = nux, uy = nuy, uz = nuz, ig = nig, w = nw;
+        // the slot's class: issued here, consumed after the Boris rotation (not carried across iterations: the
+        // loop has no VGPR to spare at 4 waves per SIMD)
+        [[maybe_unused]] uint32_t ccls = 0;
+        if (RELOC && !RL_INIT && valid) ccls = rl.cls[ip];
         {
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {
@@ -372,6 +408,8 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         double vz = 0.0;
         int b0 = 0;
         bool cross = false;   // DEFER: changed cell during the step, deposited by the second pass
+        [[maybe_unused]] bool mover = false;   // RELOC: the next gather cell has another y-class than this slot
+        [[maybe_unused]] uint32_t cnow = 0;
         if (valid) {
             double eb[6];
             double gx[3], gy[3];
@@ -415,6 +453,20 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
                 const double d1x = ix1 - (x + vx * 0.5 * k.dt - g.x0) * inv_dx;
                 const double d1y = iy1 - (y + vy * 0.5 * k.dt - g.y0) * inv_dy;
                 cross = !(d1x > -0.5 && d1x <= 0.5 && d1y > -0.5 && d1y <= 0.5);
+                if (RELOC) {
+                    // nearest node of the advanced deposit end point = the gather cell of the NEXT step
+                    const int jy = iy1 + (int)floor(0.5 - d1y);
+                    cnow = (uint32_t)(jy - ty0) & 31u;
+                    if (RL_INIT) {
+                        ccls = (uint32_t)(iy1 - ty0) & 31u;
+                        rl.cls[ip] = (uint16_t)ccls;
+                    }
+                    mover = cnow != ccls;
+#ifdef LPA_RL_NO_PARK     // diagnostic build: classes read and compared, nobody re-seated
+                    if (mover) abl += 1.0;
+                    mover = false;
+#endif
+                }
                 tsc3(d1x, ax.S1);
                 tsc3(d1y, ay.S1);
 #pragma unroll
@@ -434,6 +486,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
             finish_position_2d(xs, ys, k);
+            if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)ip * 8u;
             st(p.x, o, xs); st(p.y, o, ys);
             st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
@@ -451,11 +504,15 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
             // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
             // ds_add_f64 below hits 32 different bank pairs.
             if (valid) {
-                if (DEFER && cross) {
+                if (DEFER && (cross || (RELOC && mover))) {
                     const int slot = atomicAdd(&s_ncross, 1);
                     const uint32_t o = (uint32_t)(begin + slot) * 8u;
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
                     st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
+                    if (RELOC) {
+                        rl.aux_slot[begin + slot] = (uint32_t)ip;
+                        rl.aux_info[begin + slot] = (ccls << 8) | (cnow << 16) | (cross ? RL_DEP : 0u) | (mover ? RL_MOV : 0u);
+                    }
                 }
                 esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                    [&](int kk, int ll, double djx, double djy, double djz, double drho) {
@@ -545,31 +602,109 @@ __global__ void __launch_bounds__(K1_THREADS) k_push_deposit_tiled_2d(GridV g, P
         // ---- the particles that changed cell: the general 4 x 4 window, every lane busy
         __syncthreads();
         const int ncross = s_ncross;
+        // RELOC: a thread re-seats (at most) the first parked particle it handles and keeps its state in registers
+        // across the three barriers below -- no global-memory round trip between the phases (a version that
+        // re-read the parked state in every phase cost more than the conflicts it removed)
+        [[maybe_unused]] double m[7];
+        [[maybe_unused]] unsigned long long mid = 0;
+        [[maybe_unused]] bool mvac = false;
+        [[maybe_unused]] int mcls = 0, mh = -1;
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
+            uint32_t info = RL_DEP;
+            if (RELOC) info = rl.aux_info[begin + i];
+            const bool first = RELOC && i == (int)threadIdx.x;
+            if (!(info & RL_DEP) && !(first && (info & RL_MOV))) continue;
             const uint32_t o = (uint32_t)(begin + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
                          uz = ld(sc.a[4], o), ig = ld(sc.a[5], o), w = ld(sc.a[6], o);
-            const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
-            AxisW ax, ay;
-            axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
-            axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
-            const int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
-            const int b0 = bx * RSJ + by;
-            esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
-                               [&](int kk, int ll, double djx, double djy, double djz, double drho) {
-                                   bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
-                                   if (on) {
-                                       int oo = b0 + kk * RSJ + ll;
-                                       atomicAdd(&s_j[0][oo], djx);
-                                       atomicAdd(&s_j[1][oo], djy);
-                                       atomicAdd(&s_j[2][oo], djz);
-                                       atomicAdd(&s_j[3][oo], drho);
-                                   }
-                               });
+#ifdef LPA_RL_NO_PHASES   // diagnostic build: movers are parked but stay where they are
+            if (false) {
+#else
+            if (first && (info & RL_MOV)) {
+#endif
+                // phase A: the mover's slot joins the pool of its class (it only leaves if the pool has room)
+                const int c = (int)((info >> 8) & 31u);
+                const int pos = atomicAdd(&s_stk_cnt[c], 1);
+                if (rl.stats) atomicAdd(&rl.stats[1], 1u);
+                if (pos < RL_DEPTH) {
+                    const uint32_t slot = rl.aux_slot[begin + i];
+                    s_stk[c * RL_DEPTH + pos] = (int)slot;
+                    if (p.id) mid = p.id[slot];      // read before anybody re-occupies the slot (barrier below)
+                    mvac = true;
+                    mcls = (int)((info >> 16) & 31u);
+                    m[0] = x; m[1] = y; m[2] = ux; m[3] = uy; m[4] = uz; m[5] = ig; m[6] = w;
+                } else {
+                    atomicSub(&s_stk_cnt[c], 1);
+                }
+            }
+            if (info & RL_DEP) {
+                const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
+                AxisW ax, ay;
+                axis_window(ax, x - vx * 0.5 * k.dt - g.x0, x + vx * 0.5 * k.dt - g.x0, 1.0 / g.dx);
+                axis_window(ay, y - vy * 0.5 * k.dt - g.y0, y + vy * 0.5 * k.dt - g.y0, 1.0 / g.dy);
+                const int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
+                const int b0 = bx * RSJ + by;
+                esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
+                                   [&](int kk, int ll, double djx, double djy, double djz, double drho) {
+                                       bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
+                                       if (on) {
+                                           int oo = b0 + kk * RSJ + ll;
+                                           atomicAdd(&s_j[0][oo], djx);
+                                           atomicAdd(&s_j[1][oo], djy);
+                                           atomicAdd(&s_j[2][oo], djz);
+                                           atomicAdd(&s_j[3][oo], drho);
+                                       }
+                                   });
+            }
+        }
+        if (RELOC) {
+            // the mover's state (as parked: before the periodic fold) goes to slot `dst`
+            auto seat = [&](int dst) {
+                const uint32_t od = (uint32_t)dst * 8u;
+                double x = m[0], y = m[1];
+                finish_position_2d(x, y, k);
+                st(p.x, od, x); st(p.y, od, y);
+                st(p.ux, od, m[2]); st(p.uy, od, m[3]); st(p.uz, od, m[4]); st(p.ig, od, m[5]); st(p.w, od, m[6]);
+                if (p.id) p.id[dst] = mid;
+            };
+            __syncthreads();
+            // phase B: every mover that left takes a slot of its new class
+            if (mvac) {
+                const int pos = atomicSub(&s_stk_cnt[mcls], 1) - 1;
+                if (pos >= 0) {
+                    seat(s_stk[mcls * RL_DEPTH + pos]);
+                } else {
+                    atomicAdd(&s_stk_cnt[mcls], 1);
+                    mh = atomicAdd(&s_nhl, 1);       // at most RL_CLASSES * RL_DEPTH movers left their slots
+                }
+            }
+            __syncthreads();
+            // phase C: the others share what is left (exactly as many slots as movers without one): the pools are
+            // flattened into one list and the h-th of them takes the h-th slot; it is a mover again next step
+            if (rl.stats && threadIdx.x == 0) {
+                int left = 0;
+                for (int c = 0; c < RL_CLASSES; c++) left += max(s_stk_cnt[c], 0);
+                atomicAdd(&rl.stats[0], (uint32_t)ncross);
+                atomicAdd(&rl.stats[3], (uint32_t)s_nhl);
+                atomicAdd(&rl.stats[2], (uint32_t)left);      // == s_nhl: slots left in the pools
+            }
+            if (threadIdx.x < 64) {         // one wave: exclusive scan of the 32 pool sizes
+                const int c = (int)threadIdx.x;
+                const int n = c < RL_CLASSES ? max(s_stk_cnt[c], 0) : 0;
+                int inc = n;
+#pragma unroll
+                for (int o = 1; o < RL_CLASSES; o <<= 1) {
+                    const int t = __shfl_up(inc, o, 64);
+                    if (c >= o) inc += t;
+                }
+                for (int e = 0; e < n; e++) s_hl_dst[inc - n + e] = s_stk[c * RL_DEPTH + e];
+            }
+            __syncthreads();
+            if (mh >= 0) seat(s_hl_dst[mh]);
         }
     }
     __syncthreads();
-#if defined(LPA_ABLATE_NO_ATOMICS) || defined(LPA_ABLATE_NO_GATHER)
+#if defined(LPA_ABLATE_NO_ATOMICS) || defined(LPA_ABLATE_NO_GATHER) || defined(LPA_RL_NO_PARK)
     if (abl == 1.2345e-300) s_j[0][0] = abl;  // keeps the ablated arithmetic alive
 #endif
 
@@ -689,16 +824,23 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
         sc.a[c] = t->scratch[c];
         defer = defer && sc.a[c] != nullptr;
     }
-#define LPA_LAUNCH_TILED(E, W, D)                                                                       \
-    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D>), dim3(t->max_blocks), dim3(K1_THREADS), 0,   \
+    // the in-kernel re-seating needs the slot classes, two uint32 scratch arrays and (when ids are carried) an
+    // 8-byte one
+    Reloc rl{t->slot_class, t->aux_slot, t->aux_info, (unsigned long long *)t->scratch[7], t->reloc_stats,
+             t->class_init};
+    const bool reloc = defer && !eb && rl.cls && rl.aux_slot && rl.aux_info && (rl.aux_id || !pv.id);
+#define LPA_LAUNCH_TILED(E, W, D, R)                                                                    \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
-                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc)
-    if (eb && wr) LPA_LAUNCH_TILED(true, true, false);
-    else if (wr) LPA_LAUNCH_TILED(false, true, false);
-    else if (eb && defer) LPA_LAUNCH_TILED(true, false, true);
-    else if (eb) LPA_LAUNCH_TILED(true, false, false);
-    else if (defer) LPA_LAUNCH_TILED(false, false, true);
-    else LPA_LAUNCH_TILED(false, false, false);
+                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl)
+    if (eb && wr) LPA_LAUNCH_TILED(true, true, false, 0);
+    else if (wr) LPA_LAUNCH_TILED(false, true, false, 0);
+    else if (eb && defer) LPA_LAUNCH_TILED(true, false, true, 0);
+    else if (eb) LPA_LAUNCH_TILED(true, false, false, 0);
+    else if (reloc && rl.init) LPA_LAUNCH_TILED(false, false, true, 2);
+    else if (reloc) LPA_LAUNCH_TILED(false, false, true, 1);
+    else if (defer) LPA_LAUNCH_TILED(false, false, true, 0);
+    else LPA_LAUNCH_TILED(false, false, false, 0);
 #undef LPA_LAUNCH_TILED
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_2d");
     return LPA_OK;

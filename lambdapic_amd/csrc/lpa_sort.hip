@@ -576,6 +576,13 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     out->blk_begin = w.blk_begin;
     out->blk_end = w.blk_end;
     out->n_blocks = &w.hdr->n_blocks;
+    // idle until the next sort: scratch of the tiled push kernel's in-kernel re-seating
+    out->aux_slot = w.key;
+    out->aux_info = w.rank;
+    out->slot_class = nullptr;   // the caller may attach a class array (and must then set class_init)
+    out->class_init = 0;
+    out->reloc_stats = nullptr;
+    out->reserved2_ = 0;
     return LPA_OK;
 }
 

@@ -157,6 +157,12 @@ class PicEngine2D:
         self.overlap = False
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.defer_crossers = True
+        # in-kernel cell-index sort (lpa_tiling.slot_class): re-seat the particles whose y-class changed, every step.
+        # Correct and tested, but OFF: on C2 it removes 43 % of the LDS bank conflicts and 70 % of the LDS wait cycles
+        # (profiles/r02_pmc_reseat.txt) and still leaves K1 at 1.95-1.99 ms against 1.91-1.94 ms without it -- the
+        # class test costs 6 % more VALU instructions and the extra parked particles a longer second pass
+        self.reseat = False
+        self.reseat_stats = False  # diagnostics: count parked particles / movers / unmatched movers (ws["reloc_stats"])
         self.fused_cpml = True
         self._axes = {}
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
@@ -374,6 +380,22 @@ class PicEngine2D:
         idle = sp.other()
         for c, a in enumerate(("x", "y", "ux", "uy", "uz", "inv_gamma", "w")):
             ws["tiling"].scratch[c] = idle.arr(a).data_ptr() if self.defer_crossers else None
+        # in-kernel cell-index sort (lpa_tiling.slot_class): every step the tiled kernel re-seats the particles whose
+        # y-class changed, so the order stays as conflict-free as right after this sort; the first push writes the
+        # classes
+        if self.reseat and self.defer_crossers and self.order == _lib.LPA_ORDER_STRIPED:
+            if ws.get("cls") is None or ws["cls"].numel() < sp.capacity:
+                ws["cls"] = torch.empty(sp.capacity, dtype=torch.int16, device=self.device)
+            ws["tiling"].scratch[7] = idle.id.data_ptr()
+            ws["tiling"].slot_class = ws["cls"].data_ptr()
+            ws["tiling"].class_init = 1
+            if self.reseat_stats:
+                ws.setdefault("reloc_stats", torch.zeros(4, dtype=torch.int32, device=self.device))
+                ws["tiling"].reloc_stats = ws["reloc_stats"].data_ptr()
+        else:
+            ws["tiling"].scratch[7] = None
+            ws["tiling"].slot_class = None
+            ws["tiling"].class_init = 0
         sp.tiling = ws["tiling"]
         sp.steps_since_sort = 0
         self._reset_free_slots(ws, ws["tiling"].tiles_x, ws["tiling"].tiles_y, _lib.LPA_TILE_X)
@@ -459,6 +481,8 @@ class PicEngine2D:
             check(self.L.lpa_push_deposit_2d(self._g(), C.byref(pc), C.byref(pp), 0, sp.n, st), "global")
         if part != _lib.LPA_PART_EDGE:
             sp.steps_since_sort += 1
+            if sp.tiling is not None:
+                sp.tiling.class_init = 0      # the slot classes are written by the first push after a sort
 
     def edge_columns(self, dt):
         """tile columns at each x face whose particles (or anything that drifted out of them since the

@@ -138,3 +138,57 @@ def test_tiled_equals_global_and_conserves_charge_full_size():
     rho, jx, jy = g.view("rho")[s, s], g.view("jx")[s, s], g.view("jy")[s, s]
     res = (rho - rho_prev) / dt + (jx - torch.roll(jx, 1, 0)) / dx + (jy - torch.roll(jy, 1, 1)) / dy
     assert res.abs().max().item() <= 1e-10 * rho.abs().max().item() / dt
+
+
+def test_in_kernel_reseat_keeps_particles_and_physics():
+    """the in-kernel cell-index sort (`lpa_tiling.slot_class`, off by default) permutes particles between slots
+    inside a work block every step: nothing may be lost, doubled or detached from its id, and the physics must not
+    notice (same traces and fields as without it, to summation order); the slot classes must keep matching the
+    particles' rows after many steps (that is what the re-seating is for)"""
+    lam = 0.8e-6
+    nx, ny, ppc = 64, 96, 24
+    dx = dy = lam / 20
+    c = 299792458.0
+    dt = 0.95 / (c * np.sqrt(dx ** -2 + dy ** -2))
+    q, m = -oracle.E_CHARGE, oracle.M_E
+    n = nx * ny * ppc
+
+    def run(reseat):
+        eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", sort_interval=12, block_particles=2048)
+        eng.reseat = reseat
+        eng.add_species(q, m, capacity=n + 64)
+        s = eng.species[0].cset
+        g2 = torch.Generator(device="cuda:0").manual_seed(11)
+        cell = torch.arange(n, device="cuda:0") // ppc
+        r = lambda: torch.rand(n, device="cuda:0", dtype=torch.float64, generator=g2)
+        s.arr("x")[:n] = ((cell // ny).double() + r() - 0.5) * dx
+        s.arr("y")[:n] = ((cell % ny).double() + r() - 0.5) * dy
+        for a in ("ux", "uy", "uz"):
+            s.arr(a)[:n] = torch.randn(n, device="cuda:0", dtype=torch.float64, generator=g2) * 0.2   # hot: many movers
+        s.arr("inv_gamma")[:n] = 1.0 / torch.sqrt(1 + s.arr("ux")[:n] ** 2 + s.arr("uy")[:n] ** 2 + s.arr("uz")[:n] ** 2)
+        s.arr("w")[:n] = 1.7e27 * dx * dy / ppc
+        s.id[:n] = torch.arange(n, device="cuda:0") + 1000
+        eng.species[0].n = n
+        tr = []
+        for _ in range(30):
+            eng.step(dt)
+            d = eng.diagnostics()
+            tr.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+        return eng, np.array(tr)
+
+    a, ta = run(True)
+    b, tb = run(False)
+    assert a.species[0].tiling.slot_class and not b.species[0].tiling.slot_class
+    assert np.array_equal(ta[:, 3], tb[:, 3]) and ta[-1, 3] == n
+    np.testing.assert_allclose(ta[:, 0], tb[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(ta[:, 1], tb[:, 1], rtol=1e-12)
+    np.testing.assert_allclose(ta[:, 2], tb[:, 2], rtol=1e-12)
+    for name in ("ex", "ey", "ez", "bz", "rho"):
+        va, vb = a.grid.view(name), b.grid.view(name)
+        assert (va - vb).abs().max().item() <= 1e-9 * vb.abs().max().item(), name
+    # the same particles with the same attributes, whatever slot they sit in now
+    da, db = a.species[0].download(), b.species[0].download()
+    oa, ob = np.argsort(da["_id"].view(np.uint64)), np.argsort(db["_id"].view(np.uint64))
+    assert np.array_equal(da["_id"].view(np.uint64)[oa], np.arange(n, dtype=np.uint64) + 1000)
+    for k in ("x", "y", "ux", "uy", "uz", "inv_gamma", "w"):
+        np.testing.assert_allclose(da[k][oa], db[k][ob], rtol=1e-9, atol=1e-9 * np.abs(db[k]).max(), err_msg=k)

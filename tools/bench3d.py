@@ -40,13 +40,16 @@ data[7] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE 
 eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
 for _ in range(a.warmup):
     eng.step(dt)
+eng.kernel_events = []
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     eng.step(dt)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = eng.diagnostics()
 ov = int(eng.species[0]["ws"]["count"].item()) if eng.species[0]["ws"] else None
+k_ms = sum(x.elapsed_time(y) for x, y in eng.kernel_events) / a.steps if eng.kernel_events else None
 print(json.dumps({"metric": "particle-updates/sec (3-D, %s kernel)" % ("global-memory" if a.glob else "LDS-tiled"),
+                  "k1_3d_ms": k_ms, "k1_3d_frac_of_hbm": (121.0 * n / (k_ms * 1e-3) / 8e12) if k_ms else None,
                   "overflow_last_step": ov, "sort_interval": a.sort_interval, "value": n * a.steps / el,
                   "ms_per_step": 1e3 * el / a.steps, "particles": n, "cells": [a.nx, a.ny, a.nz],
                   "algorithmic_GBps": (121.0 * n) * a.steps / el / 1e9, "alive": d["nalive"][0],
