@@ -278,8 +278,20 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_3d(GridV g, PartV p, 
 constexpr int T3X = LPA_TILE3_X, T3Y = LPA_TILE3_Y, T3Z = LPA_TILE3_Z;
 constexpr int H3 = LPA_TILE3_MARGIN + 2;
 constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10 x 10 x 22
+// E / B image layout experiment (LPA_EB_PAIRED=1, off): components stored in pairs, two 24-double column slots per
+// 48-double row, so that the y stride (48) and the x stride (432) are 16 mod 32 doubles and the two y-adjacent
+// 16-cell columns of a half-wave read the two halves of the bank array; the 11.7 KB this costs come out of the J
+// image's z stride (24 -> 22).  Measured (profiles/r02_pmc3d_layouts.txt, same box): SQ_LDS_BANK_CONFLICT 4.45e8 ->
+// 4.18e8 (-6 %), K1-3D 3.25 -> 3.29 ms: the conflicts of this kernel are NOT the overlap of the two columns.  They
+// are there right after a sort as much as ten steps later (4.06e8 / 4.45e8, profiles/r02_pmc3d_age.txt): at 8
+// particles per cell most stripes of the striped order are partial (a rank-8 stripe holds 41 % of the cells), so
+// the 16 lanes of a group come from several columns and repeat z values -- the order cannot be conflict free at
+// this density, whatever the strides.
+#ifndef LPA_EB_PAIRED
+#define LPA_EB_PAIRED 0
+#endif
 #ifndef LPA_R3ZS
-#define LPA_R3ZS 24
+#define LPA_R3ZS (LPA_EB_PAIRED ? 22 : 24)
 #endif
 constexpr int R3ZS = LPA_R3ZS;   // z stride of the J image (>= R3Z): 24 makes the x stride (240) a multiple of 16
                                  // doubles, so a lane that drifted along x keeps its bank (-3 % against 22)
@@ -287,6 +299,15 @@ constexpr int R3N = R3X * R3Y * R3ZS;
 constexpr int G3L = LPA_TILE3_MARGIN + 2, G3H = LPA_TILE3_MARGIN + 1;      // gather reach below / above the tile
 constexpr int E3X = T3X + G3L + G3H, E3Y = T3Y + G3L + G3H, E3Z = T3Z + G3L + G3H;  // 9 x 9 x 21
 constexpr int E3N = E3X * E3Y * E3Z;                                       // 1701
+#if LPA_EB_PAIRED
+constexpr int EBZ = 24, EBSY = 2 * EBZ, EBSX = E3Y * EBSY;                 // column slot, y stride, x stride
+constexpr int EBN = E3X * EBSX;                                            // doubles per component PAIR
+static_assert(EBSY % 32 == 16 && EBSX % 32 == 16 && EBZ >= E3Z, "E/B image strides");
+__device__ __forceinline__ int eb_base(int c) { return (c >> 1) * EBN + (c & 1) * EBZ; }
+#else
+constexpr int EBSY = E3Z, EBSX = E3Y * E3Z, EBN = 2 * E3N;
+__device__ __forceinline__ int eb_base(int c) { return c * E3N; }
+#endif
 #ifndef LPA_K13_THREADS
 #define LPA_K13_THREADS 768
 #endif
@@ -310,15 +331,15 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
                                              double ddz) {
     double fx[3], fy[3], fz[3];
     tsc3(ddx, fx); tsc3(ddy, fy); tsc3(ddz, fz);
-    lds_ptr3 c = (lds_ptr3)(f + (lx * E3Y + ly) * E3Z + lz);
+    lds_ptr3 c = (lds_ptr3)(f + lx * EBSX + ly * EBSY + lz);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         double pl = 0.0;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            int o = (j - 1) * E3Z + (k - 1);
-            pl += fy[j] * (fx[0] * c[o - E3Y * E3Z] + fx[1] * c[o] + fx[2] * c[o + E3Y * E3Z]);
+            int o = (j - 1) * EBSY + (k - 1);
+            pl += fy[j] * (fx[0] * c[o - EBSX] + fx[1] * c[o] + fx[2] * c[o + EBSX]);
         }
         acc += fz[k] * pl;
     }
@@ -339,7 +360,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
     uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols, Scratch8 sc) {
     __shared__ double s_j[4][R3N];
-    __shared__ double s_eb[6][E3N];
+    __shared__ double s_eb[3 * EBN];     // see eb_base()
     __shared__ int s_ncross;
     // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
     // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
@@ -375,7 +396,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                        node_index(e0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
                       node_index(e0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
 #pragma unroll
-            for (int c = 0; c < 6; c++) s_eb[c][t] = src[c][gi];
+            for (int c = 0; c < 6; c++) s_eb[eb_base(c) + lx * EBSX + ly * EBSY + lz] = src[c][gi];
         }
     }
     __syncthreads();
@@ -448,17 +469,17 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             mid[0] = ix1; mid[1] = iy1; mid[2] = iz1;
             gd[0] = gxd; gd[1] = gyd; gd[2] = gzd;
             // stagger table: unified_pusher_3d.c:190-195
-            eb[0] = gather27_l(s_eb[0], lx2, ly1, lz1, hxd, gyd, gzd);
+            eb[0] = gather27_l(s_eb + eb_base(0), lx2, ly1, lz1, hxd, gyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[1] = gather27_l(s_eb[1], lx1, ly2, lz1, gxd, hyd, gzd);
+            eb[1] = gather27_l(s_eb + eb_base(1), lx1, ly2, lz1, gxd, hyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[2] = gather27_l(s_eb[2], lx1, ly1, lz2, gxd, gyd, hzd);
+            eb[2] = gather27_l(s_eb + eb_base(2), lx1, ly1, lz2, gxd, gyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[3] = gather27_l(s_eb[3], lx1, ly2, lz2, gxd, hyd, hzd);
+            eb[3] = gather27_l(s_eb + eb_base(3), lx1, ly2, lz2, gxd, hyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[4] = gather27_l(s_eb[4], lx2, ly1, lz2, hxd, gyd, hzd);
+            eb[4] = gather27_l(s_eb + eb_base(4), lx2, ly1, lz2, hxd, gyd, hzd);
             __builtin_amdgcn_sched_barrier(0);
-            eb[5] = gather27_l(s_eb[5], lx2, ly2, lz1, hxd, hyd, gzd);
+            eb[5] = gather27_l(s_eb + eb_base(5), lx2, ly2, lz1, hxd, hyd, gzd);
             __builtin_amdgcn_sched_barrier(0);
         }
         boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
