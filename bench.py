@@ -361,7 +361,7 @@ def main():
                          "through the host); the driver's runs use nccl (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-defer", action="store_true", help="A/B: deposit cell-crossers' tail cells inline")
-    ap.add_argument("--no-reseat", action="store_true", help="A/B: without the in-kernel cell-index sort")
+    ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -412,7 +412,7 @@ def main():
 
     eng, dt, n_local = build_engine(args, comm, device)
     eng.defer_crossers = not args.no_defer
-    eng.reseat = not args.no_reseat
+    eng.reseat = args.reseat
     for _ in range(args.warmup):
         eng.step(dt)
     # timed region: EXACTLY --steps steps between barrier + synchronize on both sides

@@ -1,6 +1,6 @@
 #!/bin/bash
 for bp in 8192 6144 4096; do
-  for fl in "" "--no-reseat"; do
+  for fl in "--reseat" ""; do
     echo -n "== block_particles=$bp $fl: "
     timeout -k 10 200 python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 8 --block-particles $bp $fl 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3), 'kernel_ms', round(d['roofline']['kernel_ms'],3))"

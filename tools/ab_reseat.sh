@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B inside one gpurun call: the in-kernel cell-index sort on / off at several sort intervals
 for si in 20 40; do
-  for fl in "" "--no-reseat"; do
+  for fl in "--reseat" ""; do
     echo "== sort_interval=$si $fl"
     timeout -k 10 200 python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 8 --sort-interval $si $fl \
       | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3), 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'alive', d['config']['alive_rank0'])"
