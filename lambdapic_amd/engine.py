@@ -353,8 +353,11 @@ class PicEngine2D:
         ws = self._ws_checked(sp)
         src, dst = sp.cset, sp.other()
         ps, pd = src.cstruct(sp.n), dst.cstruct(dst.capacity)
+        # small stores: smaller work blocks, or a 2 M-particle species is 256 workgroups on 256 CUs (config C3: K1
+        # 0.19 -> 0.15 ms per step with 4096, tools/exp_c3_blocks.py)
+        bp = self.block_particles if sp.n >= (1 << 23) else min(self.block_particles, 4096)
         check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), self.block_particles, self.order,
+                                       ws["sort"].numel(), bp, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
         hdr = ws["sort"][:8].view(torch.int32)
         n_live = int(hdr[0].item())                      # sync point (once per sort_interval steps)
