@@ -581,3 +581,90 @@ def test_moving_window_3d_chain_matches_single_rank():
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-8 * scale, a
+
+
+# ---- particle migration pinned to the reference's fixture (g7: sync_particles on 2 x 2 periodic patches) ----------
+def _run_g7_migration(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C_
+    from pathlib import Path
+    from lambdapic_amd import _lib
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.engine import PicEngine2D
+    from lambdapic_amd.particles import ParticlesBase
+    g = np.load(Path(__file__).resolve().parent / "golden" / "g7_sync_2d.npz")
+    nx, ny, dx, dy = int(g["nx"]), int(g["ny"]), float(g["dx"]), float(g["dy"])     # 16 x 16 cells, 2 x 2 patches
+    eng = PicEngine2D(nx // world, ny, dx, dy, device="cuda:0", comm=SlabComm(None), sort_interval=4,
+                      block_particles=1024, migrate_capacity=512)
+    bags = []
+    for k in (rank, rank + 2):          # this rank's slab = the patch column ipatch_x = rank (patches k and k + 2)
+        p = ParticlesBase(0, 0)
+        p.initialize(g[f"pin{k}_x"].size)
+        for a in ("x", "y", "ux", "w", "_id"):
+            getattr(p, a)[:] = g[f"pin{k}_{a}"]
+        p.inv_gamma[:] = 1.0
+        p.is_dead[:] = g[f"pin{k}_is_dead"]
+        bags.append(p)
+    eng.add_species(-1.6e-19, 9.1e-31, capacity=2048)
+    sp = eng.species[0]
+    sp.upload(bags)
+    eng.sort(0)
+    eng.sync_particles(0)               # leavers through the x faces travel to the ring neighbour (+- Lx at the box edge)
+    pp = eng._push_params(sp, 1.0)      # the y fold the fused kernel applies itself (a patch that is its own y neighbour)
+    pc = sp.cset.cstruct(sp.n)
+    _lib.check(eng.L.lpa_wrap_positions_2d(C_.byref(pc), C_.byref(pp), eng.stream), "lpa_wrap_positions_2d")
+    out = sp.download()
+    # the E / B guard copy of the same fixture through the slab path: local wrap along y + one halo message per x face
+    from lambdapic_amd.patch import make_patches_2d
+    P = make_patches_2d(nx // world, ny, dx, dy, 1, 2)
+    E6 = ["ex", "ey", "ez", "bx", "by", "bz"]
+    for p, k in zip(P, (rank, rank + 2)):
+        for a in E6:
+            getattr(p.fields, a)[...] = g[f"in{k}_{a}"]
+    eng.grid.upload_patches(list(P), 1, 2, attrs=E6)
+    eng.sync_guard_fields(E6)
+    eng.grid.download_patches(list(P), attrs=E6)
+    guards_ok = all(np.array_equal(getattr(p.fields, a), g[f"out{k}_{a}"]) for p, k in zip(P, (rank, rank + 2)) for a in E6)
+    q.put((rank, {a: out[a] for a in ("x", "y", "ux", "w", "_id")}, guards_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_migration_vs_reference_golden(golden):
+    """what `get_npart_to_extend_2d` + `fill_particles_from_boundary_2d` do on 2 x 2 periodic patches
+    (core/patch/sync_particles_2d.c:204-518, recorded in g7) == what two x-slabs do with one migration message per face
+    + the local periodic fold along y: the same particles end up in the same patch column with bit-identical
+    coordinates (the +- L shifts included)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_g7_migration, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        got_all = [q.get(timeout=120) for _ in range(2)]
+        res = {r[0]: r[1] for r in got_all}
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    # sync_guard_fields_2d of the fixture (core/patch/sync_fields2d.c:150-255) == y wrap + x halo of the slabs, bit exact
+    assert all(r[2] for r in got_all), "E / B guards of the slabs differ from the reference's patch guards"
+    g = golden("g7_sync_2d")
+    total = 0
+    for rank in range(2):
+        exp = {a: np.concatenate([g[f"pout{k}_{a}"][~g[f"pout{k}_is_dead"]] for k in (rank, rank + 2)])
+               for a in ("x", "y", "ux", "w", "_id")}
+        got = res[rank]
+        o, r = np.argsort(got["_id"].view(np.uint64)), np.argsort(exp["_id"].view(np.uint64))
+        assert np.array_equal(got["_id"].view(np.uint64)[o], exp["_id"].view(np.uint64)[r]), rank
+        for a in ("x", "y", "ux", "w"):
+            assert np.array_equal(got[a][o], exp[a][r]), (rank, a)
+        total += got["x"].size
+    assert total == sum(int((~g[f"pin{k}_is_dead"]).sum()) for k in range(4))       # nobody lost, nobody doubled
