@@ -182,11 +182,25 @@ __device__ __forceinline__ void axis_window(AxisW &a, double r_old, double r_adv
 // 2-D Esirkepov deposit of one particle on the 4x4 window; `sink(k, l, djx, djy, djz, drho)` adds the
 // contributions of window cell (k, l).  Factor grouping of the fused CPU kernel
 // (current/current_deposit.h:238-241) when FAST, of the standalone one (:104-108) otherwise.
+// The three quotients of the FAST grouping depend on the launch only: the tiled kernel takes them precomputed
+// (DepK, IEEE divisions on the host = the same doubles) -- left in the loop they were three FP64 divisions, ~45 of the
+// 436 VALU instructions per wave iteration, which the compiler did not hoist.
+struct DepK { double c_rho, c_jx, c_jy; };   // q / (dx dy), q / (dy dt), q / (dx dt)
+
 template <bool FAST, class Sink>
 __device__ __forceinline__ void esirkepov_2d(const AxisW &ax, const AxisW &ay, double vz, double w,
-                                             double q, double dx, double dy, double dt, Sink &&sink) {
+                                             double q, double dx, double dy, double dt, Sink &&sink,
+                                             const DepK *pre = nullptr) {
     double cd, fdx_, fdy_, fvz;
-    if (FAST) {
+#ifdef LPA_NO_DEPK     // A/B build: the divisions back in the loop
+    pre = nullptr;
+#endif
+    if (FAST && pre) {
+        cd = pre->c_rho * w;
+        fdx_ = pre->c_jx * w;
+        fdy_ = pre->c_jy * w;
+        fvz = cd * vz;
+    } else if (FAST) {
         cd = (q / (dx * dy)) * w;
         fdx_ = (q / (dy * dt)) * w;
         fdy_ = (q / (dx * dt)) * w;

@@ -21,10 +21,17 @@ struct PushK {
     double efactor, bfactor, cdt_half;
     int wrap;
     double lo[3], hi[3], alo[3], ahi[3];
+    DepK dep;      // deposit factors of the fused (FAST) grouping; valid when the grid was given to make_pushk
 };
 
-static PushK make_pushk(const lpa_push_params *pp) {
+static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
     PushK k;
+    k.dep.c_rho = k.dep.c_jx = k.dep.c_jy = 0.0;
+    if (g) {   // current/current_deposit.h:238-241: (q / (dx dy)) w, (q / (dy dt)) w, (q / (dx dt)) w
+        k.dep.c_rho = pp->q / (g->dx * g->dy);
+        k.dep.c_jx = pp->q / (g->dy * pp->dt);
+        k.dep.c_jy = pp->q / (g->dx * pp->dt);
+    }
     k.dt = pp->dt; k.q = pp->q; k.m = pp->m;
     k.efactor = pp->q * pp->dt / (2 * pp->m * LPA_C);  // unified_pusher_2d.c:246-248
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
@@ -98,7 +105,7 @@ __device__ __forceinline__ void gather_global_2d(const GridV &g, double xo, doub
 template <bool FAST>
 __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, double y, double ux,
                                                   double uy, double uz, double ig, double w, double q,
-                                                  double dt) {
+                                                  double dt, const DepK *pre = nullptr) {
     double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
     AxisW ax, ay;
     axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
@@ -116,7 +123,7 @@ __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, doub
                            if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
                            if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
                            if (drho != 0.0) atomicAdd(&g.rho[idx], drho);
-                       });
+                       }, pre);
 }
 
 // the whole per-particle update on global memory
@@ -135,7 +142,7 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
     x += k.cdt_half * ig * ux;
     y += k.cdt_half * ig * uy;
-    deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt);
+    deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt, &k.dep);
     finish_position_2d(x, y, k);
     p.x[ip] = x; p.y[ip] = y;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
@@ -545,7 +552,7 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
 #endif
                                        }
 #endif
-                                   });
+                                   }, &k.dep);
             }
             continue;
         }
@@ -654,7 +661,7 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
                                            atomicAdd(&s_j[2][oo], djz);
                                            atomicAdd(&s_j[3][oo], drho);
                                        }
-                                   });
+                                   }, &k.dep);
             }
         }
         if (RELOC) {
@@ -767,7 +774,7 @@ extern "C" int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, co
     if (count == 0) return LPA_OK;
     long nb = (count + 255) / 256;
     hipLaunchKernelGGL(k_push_deposit_global_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       make_gridv(g, 2), make_partv(p), make_pushk(pp), (long)first, (long)count);
+                       make_gridv(g, 2), make_partv(p), make_pushk(pp, g), (long)first, (long)count);
     LPA_CHECK_LAUNCH("lpa_push_deposit_2d");
     return LPA_OK;
 }
@@ -781,7 +788,7 @@ extern "C" int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *
     long nb = (max_count + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_push_deposit_list_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       make_gridv(g, 2), make_partv(p), make_pushk(pp), list, list_count);
+                       make_gridv(g, 2), make_partv(p), make_pushk(pp, g), list, list_count);
     LPA_CHECK_LAUNCH("lpa_push_deposit_list_2d");
     return LPA_OK;
 }
@@ -815,7 +822,7 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_2d: more than 2^29 particles in one store");
     GridV gv = make_gridv(g, 2);
     PartV pv = make_partv(p);
-    PushK k = make_pushk(pp);
+    PushK k = make_pushk(pp, g);
     // CELL_MAJOR stores use the wave reduce-scatter deposit, STRIPED stores the conflict-free atomics
     const bool eb = p->part_eb[0] != nullptr, wr = t->order == LPA_ORDER_CELL_MAJOR;
     Scratch7 sc;
