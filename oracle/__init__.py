@@ -247,6 +247,33 @@ def bucket_index_2d(x, y, is_dead, nx, ny, dx, dy, x0, y0, reverse_x=False):
     return index, count
 
 
+def bucket_index_nd(pos, is_dead, nb, d, origin, reverse_x=False):
+    """restates core/sort/cpu2d.c:9-54 / cpu3d.c:8-58 for 2 or 3 axes in numpy (pure-Python loop only for the
+    dead-slot inheritance): bucket = floor((r - r0) / d) per axis, z fastest; out of range -> last bucket (or clamped
+    when the x order is mirrored); a dead slot inherits the bucket of the slot before it (0 at the start).
+    Returns (particle_index, bucket_count)."""
+    dim = len(nb)
+    idx = [np.floor((pos[a] - origin[a]) / d[a]).astype(np.int64) for a in range(dim)]
+    nbin = int(np.prod(nb))
+    if reverse_x:
+        idx = [np.clip(idx[a], 0, nb[a] - 1) for a in range(dim)]
+        idx[0] = nb[0] - 1 - idx[0]
+        inside = np.ones(pos[0].size, dtype=bool)
+    else:
+        inside = np.logical_and.reduce([(idx[a] >= 0) & (idx[a] < nb[a]) for a in range(dim)])
+    lin = idx[0]
+    for a in range(1, dim):
+        lin = lin * nb[a] + idx[a]
+    lin = np.where(inside, lin, nbin - 1)
+    out = np.empty(pos[0].size, dtype=np.int64)
+    run = 0
+    for ip in range(out.size):
+        if not is_dead[ip]:
+            run = lin[ip]
+        out[ip] = run
+    return out, np.bincount(out, minlength=nbin)
+
+
 # -------------------------------------------------------------------------------------------------
 # reference's own compiled kernels (oracle/_ref); only present where `make -C oracle ref` ran
 # -------------------------------------------------------------------------------------------------

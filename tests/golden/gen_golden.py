@@ -703,7 +703,61 @@ def g14_sync_particles_3d():
     np.savez_compressed(OUT / "g14_sync_particles_3d.npz", **out)
 
 
+def g15_sort_variants():
+    """the branches of the reference's sort that g6 does not take, recorded from its compiled extensions:
+    (a) sort_particles_patches_3d (core/sort/cpu3d.c) on a 6 x 5 x 4 bucket grid with dead slots and out-of-range
+    particles (-> last bucket); (b) sort_particles_patches_2d with 2-D buckets and reverse_x = 1 (mirrored x order,
+    clamped; core/sort/cpu2d.c:25-32)"""
+    rng = np.random.default_rng(SEED + 15)
+    out = {}
+    # ---- (a) 3-D
+    n, nb, d, o = 4000, (6, 5, 4), (1.0e-7, 1.5e-7, 2.0e-7), (0.5e-7, -1.0e-7, 0.0)
+    pos = [o[a] + rng.uniform(-0.4, nb[a] + 0.4, n) * d[a] for a in range(3)]     # some out of range
+    dead = rng.random(n) < 0.12
+    dead[0] = True
+    attrs = {"x": pos[0], "y": pos[1], "z": pos[2], "w": rng.uniform(1, 2, n), "tag": np.arange(n, dtype=np.float64)}
+    out.update({"a_in_" + k: v.copy() for k, v in attrs.items()})
+    out["a_in_is_dead"] = dead.copy()
+    out.update(a_nb=np.array(nb), a_d=np.array(d), a_o=np.array(o))
+    mod = oracle.ref_module("sort", "cpu3d")
+    z = lambda: [np.zeros(nb, dtype=np.int64)]
+    cnt, bmin, bmax = z(), z(), z()
+    sc = lambda dt: [np.zeros(n, dtype=dt)]
+    arrs = {k: v.copy() for k, v in attrs.items()}
+    dd = dead.copy()
+    out["a_nbuf"] = mod.sort_particles_patches_3d(
+        [arrs["x"]], [arrs["y"]], [arrs["z"]], [dd], [arrs[k] for k in ("x", "y", "z", "w", "tag")],
+        [o[0]], [o[1]], [o[2]], *nb, *d, 1, cnt, bmin, bmax, z(), z(), sc(np.int64), sc(np.int64), sc(np.int64),
+        sc(np.float64), 0)
+    out.update(a_bucket_count=cnt[0].copy(), a_bucket_bound_min=bmin[0].copy(), a_bucket_bound_max=bmax[0].copy())
+    out.update({"a_out_" + k: v.copy() for k, v in arrs.items()})
+    out["a_out_is_dead"] = dd.copy()
+    # ---- (b) 2-D, 2-D buckets, reverse_x
+    n, nb2, d2, o2 = 3000, (7, 3), (1.0e-7, 2.5e-7), (-2.0e-7, 1.0e-7)
+    pos = [o2[a] + rng.uniform(-0.4, nb2[a] + 0.4, n) * d2[a] for a in range(2)]
+    dead = rng.random(n) < 0.12
+    attrs = {"x": pos[0], "y": pos[1], "w": rng.uniform(1, 2, n), "tag": np.arange(n, dtype=np.float64)}
+    out.update({"b_in_" + k: v.copy() for k, v in attrs.items()})
+    out["b_in_is_dead"] = dead.copy()
+    out.update(b_nb=np.array(nb2), b_d=np.array(d2), b_o=np.array(o2))
+    mod2 = oracle.ref_module("sort", "cpu2d")
+    z2 = lambda: [np.zeros(nb2, dtype=np.int64)]
+    cnt, bmin, bmax = z2(), z2(), z2()
+    arrs = {k: v.copy() for k, v in attrs.items()}
+    dd = dead.copy()
+    out["b_nbuf"] = mod2.sort_particles_patches_2d(
+        [arrs["x"]], [arrs["y"]], [dd], [arrs[k] for k in ("x", "y", "w", "tag")], [o2[0]], [o2[1]], *nb2, *d2, 1,
+        cnt, bmin, bmax, z2(), z2(), sc(np.int64), sc(np.int64), sc(np.int64), sc(np.float64), 1)
+    out.update(b_bucket_count=cnt[0].copy(), b_bucket_bound_min=bmin[0].copy(), b_bucket_bound_max=bmax[0].copy())
+    out.update({"b_out_" + k: v.copy() for k, v in arrs.items()})
+    out["b_out_is_dead"] = dd.copy()
+    np.savez_compressed(OUT / "g15_sort_variants.npz", **out)
+
+
 def main():
+    if "--only-g15" in sys.argv:
+        g15_sort_variants()
+        return
     if "--only-g14" in sys.argv:
         g14_sync_particles_3d()
         return
@@ -733,6 +787,7 @@ def main():
     g12_cpml_laser_3d()
     g13_sync_3d()
     g14_sync_particles_3d()
+    g15_sort_variants()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

@@ -206,3 +206,37 @@ def test_device_tile_sort_pinned_to_g6(golden):
         assert np.array_equal(out["_id"].view(np.uint64)[o], g["out__id"].view(np.uint64)[live_ref][r])
         for a in ("x", "y", "ux", "w"):
             assert np.array_equal(out[a][o], g["out_" + a][live_ref][r]), a
+
+
+def test_sort_dropins_vs_reference_golden_variants(golden):
+    """g15: the reference's 3-D sort (6 x 5 x 4 buckets, out-of-range -> last bucket) and its mirrored 2-D sort with
+    2-D buckets: bookkeeping exact, number of moved slots exact, every slot holds a particle of its bucket, attributes
+    travel with their particle (per-bucket multisets equal the reference's)"""
+    g = golden("g15_sort_variants")
+    for tag, axes, rev in (("a", "xyz", 0), ("b", "xy", 1)):
+        nb, d, o = tuple(int(v) for v in g[f"{tag}_nb"]), tuple(g[f"{tag}_d"]), tuple(g[f"{tag}_o"])
+        arrs = {k: g[f"{tag}_in_{k}"].copy() for k in list(axes) + ["w", "tag"]}
+        dead = g[f"{tag}_in_is_dead"].copy()
+        n = dead.size
+        z = lambda: [np.zeros(nb, dtype=np.int64)]
+        cnt, bmin, bmax = z(), z(), z()
+        s = lambda: [np.full(n, -1, dtype=np.int64)]
+        attrs = [arrs[k] for k in list(axes) + ["w", "tag"]]
+        if len(nb) == 3:
+            moved = kernels.sort_particles_patches_3d([arrs["x"]], [arrs["y"]], [arrs["z"]], [dead], attrs, [o[0]], [o[1]],
+                                                      [o[2]], *nb, *d, 1, cnt, bmin, bmax, z(), z(), s(), s(), s(),
+                                                      [np.zeros(n)], rev)
+        else:
+            moved = kernels.sort_particles_patches_2d([arrs["x"]], [arrs["y"]], [dead], attrs, [o[0]], [o[1]], *nb, *d, 1,
+                                                      cnt, bmin, bmax, z(), z(), s(), s(), s(), [np.zeros(n)], rev)
+        assert np.array_equal(cnt[0], g[f"{tag}_bucket_count"])
+        assert np.array_equal(bmin[0], g[f"{tag}_bucket_bound_min"])
+        assert np.array_equal(bmax[0], g[f"{tag}_bucket_bound_max"])
+        assert moved == int(g[f"{tag}_nbuf"])
+        src, src_ref = arrs["tag"].astype(np.int64), g[f"{tag}_out_tag"].astype(np.int64)
+        assert np.array_equal(np.sort(src), np.arange(n))
+        for k in list(axes) + ["w"]:
+            assert np.array_equal(arrs[k], g[f"{tag}_in_{k}"][src]), k
+        assert np.array_equal(dead, g[f"{tag}_in_is_dead"][src])
+        for lo, hi in zip(g[f"{tag}_bucket_bound_min"].ravel(), g[f"{tag}_bucket_bound_max"].ravel()):
+            assert np.array_equal(np.sort(src[lo:hi]), np.sort(src_ref[lo:hi]))      # same slots' contents per bucket

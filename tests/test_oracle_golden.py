@@ -351,3 +351,22 @@ def test_g14_sync_particles_3d_single_periodic_patch(golden):
     moved = sum(int(np.sum(getattr(p, a)[live] != g["pin_" + a][~g["pin_is_dead"]])) for a in ("x", "y", "z"))
     assert moved > 100                               # the case does exercise the fold
 
+
+
+def test_g15_sort_variants(golden):
+    """the numpy restatement of the bucket rule against the reference's compiled 3-D sort and its mirrored 2-D sort
+    (out-of-range particles, dead-slot inheritance, clamping): counts, bounds and the number of misplaced slots"""
+    g = golden("g15_sort_variants")
+    for tag, axes, rev in (("a", "xyz", False), ("b", "xy", True)):
+        pos = [g[f"{tag}_in_{a}"] for a in axes]
+        idx, cnt = oracle.bucket_index_nd(pos, g[f"{tag}_in_is_dead"], tuple(g[f"{tag}_nb"]), tuple(g[f"{tag}_d"]),
+                                          tuple(g[f"{tag}_o"]), rev)
+        assert np.array_equal(cnt.reshape(g[f"{tag}_bucket_count"].shape), g[f"{tag}_bucket_count"])
+        lo = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        assert np.array_equal(lo, g[f"{tag}_bucket_bound_min"].ravel())
+        assert np.array_equal(lo + cnt, g[f"{tag}_bucket_bound_max"].ravel())
+        ref = np.repeat(np.arange(cnt.size), cnt)
+        assert int((idx != ref).sum()) == int(g[f"{tag}_nbuf"])
+        # the reference's output: slot s holds input slot tag[s]; every slot holds a particle of its bucket
+        src = g[f"{tag}_out_tag"].astype(np.int64)
+        assert np.array_equal(np.sort(src), np.arange(src.size)) and np.array_equal(idx[src], ref)
