@@ -7,6 +7,7 @@ import bench, argparse
 a = argparse.Namespace(nx=1024, ny=1024, ppc=64, sort_interval=20, block_particles=8192)
 from lambdapic_amd.dist import SlabComm
 eng, dt, n = bench.build_engine(a, SlabComm(None), torch.device("cuda:0"))
+eng.reseat = True
 eng.reseat_stats = True
 prev = [0, 0, 0, 0]
 for it in range(24):
