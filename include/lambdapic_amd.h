@@ -88,9 +88,11 @@ typedef struct {
      * entries each -- lpa_sort_tiles_* points them at two arrays of its workspace that are idle between sorts. */
     uint16_t *slot_class;
     uint32_t *aux_slot, *aux_info;
-    uint32_t *reloc_stats;     /* optional diagnostics, 4 counters the kernel adds to: particles parked for the second
-                                  pass, movers, slots left in the class pools after the class-matched round (twice:
-                                  [2] counted from the pools, [3] from the movers without a seat -- they must agree) */
+    uint32_t *reloc_stats;     /* optional, 4 counters the tiled 2-D kernel adds to.  [0]: particles parked for the second
+                                  pass = particles that changed cell during the step (every build with the second
+                                  pass; a drift gauge for the caller's sort policy).  With the re-seating: [1] movers,
+                                  [2] / [3] slots left in the class pools after the class-matched round, counted from
+                                  the pools and from the movers without a seat -- they must agree */
     int32_t class_init, reserved2_;
 } lpa_tiling;
 

@@ -609,6 +609,8 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
         // ---- the particles that changed cell: the general 4 x 4 window, every lane busy
         __syncthreads();
         const int ncross = s_ncross;
+        // drift gauge for the caller's sort policy: particles that changed cell this step (one atomic per block)
+        if (rl.stats && threadIdx.x == 0 && ncross) atomicAdd(&rl.stats[0], (uint32_t)ncross);
         // RELOC: a thread re-seats (at most) the first parked particle it handles and keeps its state in registers
         // across the three barriers below -- no global-memory round trip between the phases (a version that
         // re-read the parked state in every phase cost more than the conflicts it removed)
@@ -691,7 +693,6 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
             if (rl.stats && threadIdx.x == 0) {
                 int left = 0;
                 for (int c = 0; c < RL_CLASSES; c++) left += max(s_stk_cnt[c], 0);
-                atomicAdd(&rl.stats[0], (uint32_t)ncross);
                 atomicAdd(&rl.stats[3], (uint32_t)s_nhl);
                 atomicAdd(&rl.stats[2], (uint32_t)left);      // == s_nhl: slots left in the pools
             }
