@@ -86,6 +86,7 @@ typedef struct {
      * than their slot (a permutation inside each work block), so the LDS atomics of a 16-lane group keep
      * hitting 16 different bank pairs between two sorts.  aux_slot / aux_info: uint32 scratch of n_sorted
      * entries each -- lpa_sort_tiles_* points them at two arrays of its workspace that are idle between sorts. */
+    const int32_t *pad_ranks;  /* [ntiles] LPA_ORDER_PADDED: full stripes per tile (0 for the other orders) */
     uint16_t *slot_class;
     uint32_t *aux_slot, *aux_info;
     uint32_t *reloc_stats;     /* optional, 4 counters the tiled 2-D kernel adds to.  [0]: particles parked for the second
@@ -116,6 +117,14 @@ typedef struct {
  *                atomics fall on 32 different bank pairs (conflict free). */
 #define LPA_ORDER_CELL_MAJOR 0
 #define LPA_ORDER_STRIPED 1
+/* LPA_ORDER_PADDED (2-D): the striped order with its leading ranks -- those that at least LPA_PAD_MIN_CELLS of the
+ * tile's 256 cells have -- stored as FULL stripes: slot = tile start + rank * 256 + cell, the missing cells are holes
+ * (x = y = NaN); the other ranks follow compacted as in LPA_ORDER_STRIPED, and every tile's slot count is rounded up to
+ * 64.  A slot's position then tells the cell it belongs to (lpa_tiling.pad_ranks[tile] = number of full stripes):
+ * what the cooperative deposit of lpa_push_deposit_tiled_2d needs.  The store grows by the holes (a few per cent);
+ * the live count is NOT the slot count (lpa_sort_live_count returns the slots). */
+#define LPA_ORDER_PADDED 2
+#define LPA_PAD_MIN_CELLS 192
 
 const char *lpa_last_error(void);
 int lpa_version(void);

@@ -17,6 +17,7 @@ LPA_TILE_X = 8
 LPA_TILE_Y = 32
 LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1
+LPA_ORDER_PADDED = 2
 LPA_TILE_MARGIN = 2
 LPA_TILE3_X, LPA_TILE3_Y, LPA_TILE3_Z, LPA_TILE3_MARGIN = 4, 4, 16, 1
 LPA_MIG_NATTR = 9
@@ -48,7 +49,7 @@ class lpa_tiling(C.Structure):
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
                 ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 8),
-                ("slot_class", C.c_void_p), ("aux_slot", C.c_void_p), ("aux_info", C.c_void_p),
+                ("pad_ranks", C.c_void_p), ("slot_class", C.c_void_p), ("aux_slot", C.c_void_p), ("aux_info", C.c_void_p),
                 ("reloc_stats", C.c_void_p), ("class_init", C.c_int32), ("reserved2_", C.c_int32)]
 
 

@@ -43,6 +43,7 @@ constexpr int32_t SORT_MAGIC = 0x4c504131;
 struct SortWs {
     SortHdr *hdr;
     int32_t *cell_cnt, *cell_off, *cell_base, *tile_cnt, *tile_off, *tile_off_prev, *blk_tile, *blk_begin, *blk_end, *apre;
+    int32_t *pad_ranks;
     unsigned long long *masks;
     uint32_t *key, *rank;
     int ntiles, max_blocks;
@@ -72,6 +73,7 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_off = (int32_t *)p;
     p = take(sizeof(int32_t) * (size_t)nt * TCELLS); if (w) w->cell_base = (int32_t *)p;
     p = take(sizeof(int32_t) * nt); if (w) w->tile_cnt = (int32_t *)p;
+    p = take(sizeof(int32_t) * nt); if (w) w->pad_ranks = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off_prev = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_tile = (int32_t *)p;
@@ -282,12 +284,13 @@ __global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ c
 // relative to the tile start).
 __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict__ cell_cnt,
                                                       unsigned long long *masks, int32_t *apre,
-                                                      int32_t *cell_off) {
+                                                      int32_t *cell_off, int pad_min, int32_t *tile_cnt_out,
+                                                      int32_t *pad_ranks) {
     __shared__ unsigned long long s_mask[4];
     const int c = threadIdx.x, lane = c & 63, wv = c >> 6;
     const long t = blockIdx.x;
     const int n = cell_cnt[t * TCELLS + c];
-    int run = 0;
+    int run = 0, ra = 0;
     for (int r = 0; r < RMAX; r++) {
         unsigned long long m = __ballot(n > r);
         if (lane == 0) s_mask[wv] = m;
@@ -295,14 +298,37 @@ __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict_
         unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
         if (c < 4) masks[(t * RMAX + r) * 4 + c] = s_mask[c];
         if (c == 0) apre[t * (RMAX + 1) + r] = run;
-        run += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        const int pop = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        // LPA_ORDER_PADDED: a rank that most cells have is stored as a FULL stripe of 256 slots (slot = cell; the
+        // missing cells are holes), so that a slot's position tells its cell; pop is non-increasing in r, so the
+        // padded ranks are the leading ones
+        const bool pad = pad_min > 0 && pop >= pad_min;     // block-uniform
+        run += pad ? TCELLS : pop;
+        if (pad) ra = r + 1;
         __syncthreads();
-        if (!(m0 | m1 | m2 | m3)) break;  // block-uniform: no cell is this deep; later rows are never read
+        if (!pop) break;  // block-uniform: no cell is this deep; later rows are never read
     }
     if (c == 0) apre[t * (RMAX + 1) + RMAX] = run;
-    int extra = n > RMAX ? n - RMAX : 0;
-    int ex = block_excl_scan256(extra, nullptr);
+    int extra = n > RMAX ? n - RMAX : 0, total_extra = 0;
+    int ex = block_excl_scan256(extra, &total_extra);
     cell_off[t * TCELLS + c] = run + ex;
+    if (c == 0) {
+        // (the padded tile total is rounded up to a whole wave: tile starts stay multiples of 64 slots)
+        if (tile_cnt_out) tile_cnt_out[t] = (run + total_extra + 63) & ~63;
+        if (pad_ranks) pad_ranks[t] = ra;
+    }
+}
+
+// slot of (cell c, rank r < RMAX) inside its tile for the striped orders: a stripe that holds all 256 slots (full, or
+// padded: next offset - this offset == 256) is indexed by the cell itself
+__device__ __forceinline__ int stripe_slot(const unsigned long long *__restrict__ m, const int32_t *__restrict__ ap,
+                                           uint32_t r, int c) {
+    const int a0 = ap[r], a1 = ap[r + 1];
+    if (a1 - a0 == TCELLS) return a0 + c;
+    int w = c >> 6, b = c & 63, below = 0;
+    for (int q = 0; q < w; q++) below += __popcll(m[q]);
+    below += __popcll(m[w] & ((1ull << b) - 1ull));
+    return a0 + below;
 }
 
 __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
@@ -324,15 +350,8 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
     } else {
         long t = ck >> 8;
         int c = ck & 255;
-        if (r < RMAX) {
-            const unsigned long long *m = masks + (t * RMAX + r) * 4;
-            int w = c >> 6, b = c & 63, below = 0;
-            for (int q = 0; q < w; q++) below += __popcll(m[q]);
-            below += __popcll(m[w] & ((1ull << b) - 1ull));
-            o = (long)tile_off[t] + apre[t * (RMAX + 1) + r] + below;
-        } else {
-            o = (long)tile_off[t] + cell_off[ck] + (r - RMAX);
-        }
+        if (r < RMAX) o = (long)tile_off[t] + stripe_slot(masks + (t * RMAX + r) * 4, apre + t * (RMAX + 1), r, c);
+        else o = (long)tile_off[t] + cell_off[ck] + (r - RMAX);
     }
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
@@ -380,13 +399,7 @@ __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
     if (!striped) return (long)cell_off[ck] + r;
     long t = ck >> 8;
     int c = ck & 255;
-    if (r < RMAX) {
-        const unsigned long long *m = masks + (t * RMAX + r) * 4;
-        int w = c >> 6, b = c & 63, below = 0;
-        for (int q = 0; q < w; q++) below += __popcll(m[q]);
-        below += __popcll(m[w] & ((1ull << b) - 1ull));
-        return (long)tile_off[t] + apre[t * (RMAX + 1) + r] + below;
-    }
+    if (r < RMAX) return (long)tile_off[t] + stripe_slot(masks + (t * RMAX + r) * 4, apre + t * (RMAX + 1), r, c);
     return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
 }
 
@@ -491,7 +504,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                 "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(src, dim) && lpa_part_ok(dst, dim) && workspace && out,
                 "%s: bad particle stores / workspace", name);
-    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED, "%s: bad order", name);
+    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || (order == LPA_ORDER_PADDED && dim == 2),
+                "%s: bad order", name);
     LPA_REQUIRE(src->n < (1ll << 31) - 1, "%s: more than 2^31 particles in one store", name);
     LPA_REQUIRE(dst->n >= src->n, "%s: dst capacity (dst->n) smaller than src->n", name);
     LPA_REQUIRE(block_particles >= 1024, "%s: block_particles must be >= 1024", name);
@@ -533,15 +547,29 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, kg, w.hdr, w.cell_cnt, w.key, w.rank);
         LPA_CHECK_LAUNCH("k_cell_count");
     }
-    hipLaunchKernelGGL(k_tile_sum, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_cnt);
-    LPA_CHECK_LAUNCH("k_tile_sum");
+    const bool padded = order == LPA_ORDER_PADDED;
+    if (padded) {
+        // the padded tile totals come out of the stripe tables: tables first, then the scan; the destination's
+        // positions start as NaN, so every slot the scatter does not fill is a hole
+        hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre, w.cell_off,
+                           LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks);
+        LPA_CHECK_LAUNCH("k_stripe_table (padded)");
+        if (hipMemsetAsync(dv.x, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
+            hipMemsetAsync(dv.y, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess) {
+            lpa_set_error("%s: memset failed", name);
+            return LPA_ERR_HIP;
+        }
+    } else {
+        hipLaunchKernelGGL(k_tile_sum, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_cnt);
+        LPA_CHECK_LAUNCH("k_tile_sum");
+    }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off, w.blk_tile,
                        w.blk_begin, w.blk_end, w.hdr, (int)block_particles, w.max_blocks);
     LPA_CHECK_LAUNCH("k_tile_scan");
     if (order == LPA_ORDER_STRIPED)
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre,
-                           w.cell_off);
-    else
+                           w.cell_off, 0, (int32_t *)nullptr, w.pad_ranks);
+    else if (!padded)
         hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
     LPA_CHECK_LAUNCH("k_cell_scan / k_stripe_table");
     if (src->n > 0) {
@@ -553,7 +581,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         add((const double *)sv.id, (double *)dv.id);       // 8-byte payload, moved as is
         if (sv.eb[0] && dv.eb[0])
             for (int c = 0; c < 6; c++) add(sv.eb[c], dv.eb[c]);
-        const int striped = (int)(order == LPA_ORDER_STRIPED);
+        const int striped = (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
         hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
                            w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped);
@@ -577,6 +605,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     out->blk_end = w.blk_end;
     out->n_blocks = &w.hdr->n_blocks;
     // idle until the next sort: scratch of the tiled push kernel's in-kernel re-seating
+    out->pad_ranks = w.pad_ranks;
     out->aux_slot = w.key;
     out->aux_info = w.rank;
     out->slot_class = nullptr;   // the caller may attach a class array (and must then set class_init)

@@ -281,7 +281,7 @@ def test_wave_reduce_scatter_selftest():
     np.testing.assert_allclose(d_out.cpu().numpy(), a.sum(axis=1), rtol=1e-13, atol=1e-13)
 
 
-@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR])
+@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR, 2])
 def test_cell_sort_properties(order):
     """reference tests/test_sort.py:38-117,201-251 restated for the device sort: per-cell counts
     equal a numpy histogram, tiles are contiguous and in order, inside a tile the particles are cell
@@ -305,7 +305,7 @@ def test_cell_sort_properties(order):
     p.x[7] = np.nan
     live = ~p.is_dead & ~np.isnan(p.x)
     eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024, order=order)
-    eng.add_species(QE, ME, capacity=n + 64)
+    eng.add_species(QE, ME, capacity=2 * n if order == 2 else n + 64)     # LPA_ORDER_PADDED stores holes
     eng.species[0].upload([p])
     assert eng.species[0].n == live.sum()
     eng.sort(0)
@@ -445,3 +445,63 @@ def test_known_answer_charge_and_current_3d():
         assert f.jx.sum() == pytest.approx(QE * n * v[0], rel=1e-10)
         assert f.jy.sum() == pytest.approx(QE * n * v[1], rel=1e-10)
         assert f.jz.sum() == pytest.approx(QE * n * v[2], rel=1e-10)
+
+
+def test_padded_order_layout():
+    """LPA_ORDER_PADDED: in every tile the leading ranks that at least 192 of the 256 cells have are FULL stripes --
+    slot = tile start + rank * 256 + cell, holes (NaN) where a cell has no such particle --, tile starts are
+    multiples of 64, the compact rest follows, and a re-sort of the padded store (holes in the source) keeps all of
+    that"""
+    import torch
+    from lambdapic_amd.engine import PicEngine2D
+    rng = np.random.default_rng(19)
+    nx, ny, dx, dy = 24, 64, 4e-8, 5e-8          # 3 x 2 tiles
+    ppc = 40
+    n = nx * ny * ppc
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    cell = np.arange(n) // ppc
+    p.x[:] = ((cell // ny) + rng.uniform(-0.5, 0.5, n)) * dx
+    p.y[:] = ((cell % ny) + rng.uniform(-0.5, 0.5, n)) * dy
+    p.is_dead[rng.random(n) < 0.3] = True          # Poisson-like counts: mean 28, partial ranks
+    p.w[:] = 1.0
+    p.inv_gamma[:] = 1.0
+    live = ~p.is_dead
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024, order=2)
+    eng.add_species(QE, ME, capacity=2 * n)
+    sp = eng.species[0]
+    sp.upload([p])
+
+    def check():
+        x = sp.cset.arr("x")[: sp.n_sorted].cpu().numpy()
+        y = sp.cset.arr("y")[: sp.n_sorted].cpu().numpy()
+        ok = ~np.isnan(x)
+        assert ok.sum() == live.sum() and np.array_equal(np.isnan(x), np.isnan(y))
+        i = np.clip(np.floor(x[ok] / dx + 0.5).astype(int), 0, nx - 1)
+        j = np.clip(np.floor(y[ok] / dy + 0.5).astype(int), 0, ny - 1)
+        tile = (i // 8) * 2 + j // 32
+        cellk = (i % 8) * 32 + (j % 32)
+        slot = np.nonzero(ok)[0]
+        assert np.all(np.diff(tile) >= 0)
+        start = 0
+        for t in range(6):
+            st = slot[tile == t]
+            ct = cellk[tile == t]
+            cnt = np.bincount(ct, minlength=256)
+            ra = int(sum(1 for r in range(cnt.max()) if (cnt > r).sum() >= 192))
+            assert ra >= 10                                            # most of the tile is in full stripes
+            assert start % 64 == 0 and st.min() >= start
+            rel = st - start
+            full = rel < ra * 256
+            assert np.array_equal(rel[full] % 256, ct[full])           # the slot tells the cell
+            assert np.array_equal(np.bincount(rel[full] // 256, minlength=ra),
+                                  np.array([(cnt > r).sum() for r in range(ra)]))   # holes exactly where a cell is short
+            total = ra * 256 + int(np.maximum(cnt - ra, 0).sum())
+            assert rel.max() < total
+            start += (total + 63) // 64 * 64
+        assert sp.n_sorted == start
+
+    eng.sort(0)
+    check()
+    eng.sort(0)       # re-sort: tile-staged path, source with holes
+    check()
