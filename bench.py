@@ -47,9 +47,13 @@ def build_engine(args, comm, device):
     n_c = constants.EPSILON_0 * m * omega ** 2 / q ** 2     # tests/test_numerical_heating.py:16,86
     u_th = 0.0442                                           # 1 keV electrons
     n = nx * ny * ppc
+    from lambdapic_amd import _lib
+    padded = getattr(args, "order", "striped") == "padded"
     eng = PicEngine2D(nx, ny, dx, dy, n_guard=3, device=device, comm=comm,
-                      sort_interval=args.sort_interval, block_particles=args.block_particles)
-    eng.add_species(q, m, capacity=n + 4096)
+                      sort_interval=args.sort_interval, block_particles=args.block_particles,
+                      order=_lib.LPA_ORDER_PADDED if padded else _lib.LPA_ORDER_STRIPED)
+    # (the padded order stores a few per cent of holes and rounds every tile to 64 slots)
+    eng.add_species(q, m, capacity=int(1.12 * n) + 65536 if padded else n + 4096)
     s = eng.species[0].cset
     gen = torch.Generator(device=device).manual_seed(20260722 + comm.rank)
     chunk = 1 << 24
@@ -361,6 +365,8 @@ def main():
                          "through the host); the driver's runs use nccl (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--no-defer", action="store_true", help="A/B: deposit cell-crossers' tail cells inline")
+    ap.add_argument("--order", default="striped", choices=["striped", "padded"],
+                    help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
     args = ap.parse_args()
 

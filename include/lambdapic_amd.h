@@ -417,6 +417,9 @@ int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stre
 /* ---- self test of the wave-level reduce-scatter used by the tiled deposit: in[64][64] doubles
  *      (value index, lane) -> out[lane] = sum over lanes of in[lane][.]; one wave. */
 int lpa_selftest_wave_reduce(const double *in, double *out, void *stream);
+/* self test of the neighbour exchange of the cooperative deposit (DPP wave_shr:1 / wave_shl:1): in[64] ->
+ * out[0..63] = value of lane - 1 (0 for lane 0), out[64..127] = value of lane + 1 (0 for lane 63); one wave. */
+int lpa_selftest_wave_shift(const double *in, double *out, void *stream);
 
 #ifdef __cplusplus
 }

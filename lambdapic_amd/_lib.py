@@ -136,6 +136,7 @@ SIGNATURES = {
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
     "lpa_selftest_wave_reduce": (_i, [_vp, _vp, _vp]),
+    "lpa_selftest_wave_shift": (_i, [_vp, _vp, _vp]),
 }
 
 _LIB = None

@@ -270,17 +270,32 @@ constexpr uint32_t RL_DEP = 1u, RL_MOV = 2u;
 
 // RELOC_MODE: 0 = off, 1 = on, 2 = on and this is the first push after a sort (the classes are written, not read:
 // its own instantiation, the 16-bit store in the loop costs the steady-state kernel 44 spilled VGPRs otherwise)
-template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE>
-__global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
+// COOP -- cooperative deposit on LPA_ORDER_PADDED stores.  In the full stripes a slot's position tells its cell, so
+// lane l of a half-wave OWNS cell (lx, l) of one tile row whether or not its slot holds a particle of that cell.  The
+// three columns of a particle's 3 x 3 window are the own columns of lanes l - 1, l, l + 1: every lane hands its outer
+// columns to the neighbours (DPP wave_shr:1 / wave_shl:1), adds what it receives to its own middle column and issues
+// ONE ds_add_f64 per row and quantity -- 11 per particle instead of 30, all to consecutive addresses (conflict free
+// whatever the particles did since the sort).  Particles that are not in their slot's cell any more, and the
+// cell-crossers, contribute zeros here and are parked for the second pass; the two lanes at the ends of a 32-cell row
+// deposit their outward column themselves (11 partially filled atomics per iteration).
+struct Coop {
+    const int32_t *tile_off;    // [ntiles + 1]
+    const int32_t *pad_ranks;   // [ntiles] full stripes per tile
+};
+
+template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE, bool COOP = false>
+__global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
                                                               const int32_t *__restrict__ blk_end,
                                                               const int32_t *__restrict__ n_blocks,
                                                               int tiles_y, uint32_t *overflow,
                                                               uint32_t *overflow_count, int part,
-                                                              int tiles_x, int edge_cols, Scratch7 sc, Reloc rl) {
+                                                              int tiles_x, int edge_cols, Scratch7 sc, Reloc rl,
+                                                              Coop co) {
     constexpr bool RELOC = RELOC_MODE != 0, RL_INIT = RELOC_MODE == 2;
     static_assert(!RELOC || (DEFER && !WAVE_REDUCE && !WRITE_EB), "RELOC rides on the parked-crosser pass");
+    static_assert(!COOP || (DEFER && !WAVE_REDUCE), "COOP parks what it cannot deposit");
     __shared__ __attribute__((aligned(16))) double s_eb[RSZ];
     __shared__ double s_j[4][RSZJ];
     __shared__ int s_ncross;
@@ -305,6 +320,12 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
     const int tx0 = (tile / tiles_y) * TX, ty0 = (tile % tiles_y) * TY;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
+    // COOP: first slot of the tile and one past its last full-stripe slot (both multiples of 64, like `begin`)
+    [[maybe_unused]] int tile_first = 0, pad_end = 0;
+    if (COOP) {
+        tile_first = co.tile_off[tile];
+        pad_end = tile_first + co.pad_ranks[tile] * 256;
+    }
     if (DEFER && threadIdx.x == 0) s_ncross = 0;
     if (RELOC) {
         if (threadIdx.x < RL_CLASSES) s_stk_cnt[threadIdx.x] = 0;
@@ -505,6 +526,56 @@ __global__ void __launch_bounds__(K1_THREADS, RELOC_MODE ? 4 : 1) k_push_deposit
             }
             ax.base = ay.base = 0;
             ax.tail_zero = ay.tail_zero = false;
+        }
+        if (COOP && it + 64 <= pad_end) {      // wave-uniform: this wave walks 64 slots of a full stripe
+            const int cn = (ip - tile_first) & 255;                 // the cell this lane owns
+            const int lxn = cn >> 5, lyn = cn & 31;
+            const bool fast = valid && !cross && ix1 - tx0 == lxn && iy1 - ty0 == lyn;
+            if (valid && !fast) {              // changed cell, or not (any more) in its slot's cell: second pass
+                const int slot = atomicAdd(&s_ncross, 1);
+                const uint32_t o = (uint32_t)(begin + slot) * 8u;
+                st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
+                st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
+            }
+            // every lane from here on (the exchange reads all 64 lanes): lanes without a fast particle carry zeros
+            const double wq = fast ? w : 0.0;
+            const double cd = k.dep.c_rho * wq, fdx_ = k.dep.c_jx * wq, fdy_ = k.dep.c_jy * wq, fvz = cd * vz;
+            const double mp = lyn != 0 ? 1.0 : 0.0, mn = lyn != 31 ? 1.0 : 0.0;   // row ends: nothing comes across
+            const bool edge = fast && (lyn == 0 || lyn == 31);
+            const int bn = (lxn + HALO - 1) * RSJ + lyn + HALO;    // own cell, window row 0
+            const int be = bn + (lyn == 0 ? -1 : 1);               // the outward column of a row-end lane
+            double bb[3], jxr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int l = 0; l < 3; l++) bb[l] = ay.S0[l] + 0.5 * ay.DS[l];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                const double a = ax.S0[kk] + 0.5 * ax.DS[kk];
+                const double fdx = fdx_ * ax.DS[kk], t12 = (1.0 / 12.0) * ax.DS[kk];
+                double vjx[3], vjy[3], vjz[3], vrh[3], jyr = 0.0;
+#pragma unroll
+                for (int l = 0; l < 3; l++) {
+                    jxr[l] -= fdx * bb[l];
+                    jyr -= fdy_ * (ay.DS[l] * a);
+                    vjx[l] = jxr[l]; vjy[l] = jyr;
+                    vjz[l] = fvz * (a * bb[l] + t12 * ay.DS[l]);
+                    vrh[l] = cd * ax.S1[kk] * ay.S1[l];
+                }
+                const int o = bn + kk * RSJ;
+                // own middle column + the left neighbour's upper column + the right neighbour's lower column
+                atomicAdd(&s_j[3][o], fma(mn, wr_dpp<0x130>(vrh[0]), fma(mp, wr_dpp<0x138>(vrh[2]), vrh[1])));
+                atomicAdd(&s_j[2][o], fma(mn, wr_dpp<0x130>(vjz[0]), fma(mp, wr_dpp<0x138>(vjz[2]), vjz[1])));
+                atomicAdd(&s_j[1][o], fma(mn, wr_dpp<0x130>(vjy[0]), vjy[1]));           // (column 2 of jy is the null run)
+                if (kk < 2) atomicAdd(&s_j[0][o], fma(mn, wr_dpp<0x130>(vjx[0]), fma(mp, wr_dpp<0x138>(vjx[2]), vjx[1])));
+                if (edge) {                    // nobody owns the column beyond the row end
+                    const int oe = be + kk * RSJ;
+                    const bool lo = lyn == 0;
+                    atomicAdd(&s_j[3][oe], lo ? vrh[0] : vrh[2]);
+                    atomicAdd(&s_j[2][oe], lo ? vjz[0] : vjz[2]);
+                    if (lo) atomicAdd(&s_j[1][oe], vjy[0]);
+                    if (kk < 2) atomicAdd(&s_j[0][oe], lo ? vjx[0] : vjx[2]);
+                }
+            }
+            continue;
         }
 
         if (!WAVE_REDUCE) {
@@ -750,6 +821,22 @@ __global__ void __launch_bounds__(64) k_selftest_wave_reduce(const double *in, d
     out[lane] = wr_finish16(s16, lane);
 }
 
+// self-test of the neighbour exchange of the cooperative deposit: out[lane] = value of lane - 1 (wave_shr:1, 0 for
+// lane 0), out[64 + lane] = value of lane + 1 (wave_shl:1, 0 for lane 63)
+__global__ void __launch_bounds__(64) k_selftest_wave_shift(const double *in, double *out) {
+    const int lane = threadIdx.x;
+    const double v = in[lane];
+    out[lane] = wr_dpp<0x138>(v);
+    out[64 + lane] = wr_dpp<0x130>(v);
+}
+
+extern "C" int lpa_selftest_wave_shift(const double *in, double *out, void *stream) {
+    LPA_REQUIRE(in && out, "lpa_selftest_wave_shift: bad args");
+    hipLaunchKernelGGL(k_selftest_wave_shift, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    LPA_CHECK_LAUNCH("lpa_selftest_wave_shift");
+    return LPA_OK;
+}
+
 extern "C" int lpa_selftest_wave_reduce(const double *in, double *out, void *stream) {
     LPA_REQUIRE(in && out, "lpa_selftest_wave_reduce: bad args");
     hipLaunchKernelGGL(k_selftest_wave_reduce, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
@@ -837,11 +924,18 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     Reloc rl{t->slot_class, t->aux_slot, t->aux_info, (unsigned long long *)t->scratch[7], t->reloc_stats,
              t->class_init};
     const bool reloc = defer && !eb && rl.cls && rl.aux_slot && rl.aux_info && (rl.aux_id || !pv.id);
+    Coop co{t->tile_off, t->pad_ranks};
+    const bool coop = t->order == LPA_ORDER_PADDED && defer && !eb && t->pad_ranks && t->tile_off;
+    LPA_REQUIRE(t->order != LPA_ORDER_PADDED || !reloc, "lpa_push_deposit_tiled_2d: slot classes and the padded order exclude each other");
 #define LPA_LAUNCH_TILED(E, W, D, R)                                                                    \
     hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
-                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl)
-    if (eb && wr) LPA_LAUNCH_TILED(true, true, false, 0);
+                       t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl, co)
+    if (coop)
+        hipLaunchKernelGGL((k_push_deposit_tiled_2d<false, false, true, 0, true>), dim3(t->max_blocks),
+                           dim3(K1_THREADS), 0, (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
+                           t->n_blocks, t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl, co);
+    else if (eb && wr) LPA_LAUNCH_TILED(true, true, false, 0);
     else if (wr) LPA_LAUNCH_TILED(false, true, false, 0);
     else if (eb && defer) LPA_LAUNCH_TILED(true, false, true, 0);
     else if (eb) LPA_LAUNCH_TILED(true, false, false, 0);

@@ -133,13 +133,17 @@ def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024, order=_lib.LPA_
     names = list(PART_CORE) + list(PART_EB)
     host = np.stack([np.asarray(getattr(p, a)[:n], dtype=np.float64)[live] for a in names])
     src = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
-    dst = torch.empty_like(src)
+    padded = order == _lib.LPA_ORDER_PADDED
+    # LPA_ORDER_PADDED stores holes: every tile may grow by its padded stripes and a 64-slot rounding
+    ntiles = -(-g.c.nx // _lib.LPA_TILE_X) * -(-g.c.ny // _lib.LPA_TILE_Y)
+    cap = 2 * nl + 320 * ntiles if padded else nl
+    dst = torch.empty((src.shape[0], cap), dtype=src.dtype, device=dev)
     sid = torch.from_numpy(live.astype(np.int64)).to(dev)
-    did = torch.empty_like(sid)
+    did = torch.empty(cap, dtype=torch.int64, device=dev)
 
-    def cs(t, tid):
+    def cs(t, tid, n):
         c = _lib.lpa_particles()
-        c.n = nl
+        c.n = n
         for a in PART_CORE:
             setattr(c, a, t[names.index(a)].data_ptr())
         c.z = None
@@ -148,26 +152,37 @@ def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024, order=_lib.LPA_
         c.id, c.is_dead = tid.data_ptr(), None
         return c
 
-    ps, pd = cs(src, sid), cs(dst, did)
-    nbytes = L.lpa_sort_workspace_bytes(g.ref(), nl)
+    ps, pd = cs(src, sid, nl), cs(dst, did, cap)
+    nbytes = L.lpa_sort_workspace_bytes(g.ref(), cap)
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     tiling = _lib.lpa_tiling()
     st = _stream(dev)
     check(L.lpa_sort_tiles_2d(g.ref(), C.byref(ps), C.byref(pd), ws.data_ptr(), nbytes, block_particles,
                               order, C.byref(tiling), st), "lpa_sort_tiles_2d")
-    n_live = int(ws[:4].view(torch.int32)[0].item())
-    assert n_live == nl
-    tiling.n_sorted = nl
-    overflow = torch.empty(nl, dtype=torch.int32, device=dev)
+    n_slots = int(ws[:4].view(torch.int32)[0].item())          # live particles (+ holes of the padded order)
+    assert n_slots == nl or (padded and nl <= n_slots <= cap)
+    tiling.n_sorted = n_slots
+    pd.n = n_slots
+    if padded:
+        # the cooperative deposit parks what it cannot deposit in the main loop: give it the scratch arrays
+        # (and no per-particle E / B write-back: that variant has no cooperative form)
+        scratch = torch.empty((7, n_slots), dtype=torch.float64, device=dev)
+        for c in range(7):
+            tiling.scratch[c] = scratch[c].data_ptr()
+        for k in range(6):
+            pd.part_eb[k] = None
+    overflow = torch.empty(max(n_slots, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     check(L.lpa_push_deposit_tiled_2d(g.ref(), C.byref(pd), C.byref(pp), C.byref(tiling),
                                       overflow.data_ptr(), cnt.data_ptr(), st), "lpa_push_deposit_tiled_2d")
     check(L.lpa_push_deposit_list_2d(g.ref(), C.byref(pd), C.byref(pp), overflow.data_ptr(), cnt.data_ptr(),
-                                     nl, st), "lpa_push_deposit_list_2d")
-    out = dst.cpu().numpy()
-    slot = did.cpu().numpy()
-    for a in list(PART_CORE[:6]) + list(PART_EB):
-        getattr(p, a)[slot] = out[names.index(a)]
+                                     n_slots, st), "lpa_push_deposit_list_2d")
+    out = dst[:, :n_slots].cpu().numpy()
+    slot = did[:n_slots].cpu().numpy()
+    keep = ~np.isnan(out[names.index("x")])                     # (holes of the padded order)
+    assert int(keep.sum()) == nl
+    for a in list(PART_CORE[:6]) + ([] if padded else list(PART_EB)):
+        getattr(p, a)[slot[keep]] = out[names.index(a)][keep]
     return int(cnt.item())
 
 

@@ -505,3 +505,51 @@ def test_padded_order_layout():
     check()
     eng.sort(0)       # re-sort: tile-staged path, source with holes
     check()
+
+
+def test_wave_shift_selftest():
+    """DPP wave_shr:1 / wave_shl:1 as the cooperative deposit uses them: lane l reads lane l - 1 / l + 1 across the
+    four 16-lane rows of the wave, the ends read zero"""
+    import torch
+    from lambdapic_amd import _lib
+    L = _lib.lib()
+    a = np.arange(64, dtype=np.float64) * 1.5 + 0.25
+    d_in = torch.from_numpy(a).cuda()
+    d_out = torch.zeros(128, dtype=torch.float64, device="cuda")
+    _lib.check(L.lpa_selftest_wave_shift(d_in.data_ptr(), d_out.data_ptr(), None), "selftest")
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[:64], np.concatenate([[0.0], a[:-1]]))
+    assert np.array_equal(out[64:], np.concatenate([a[1:], [0.0]]))
+
+
+def test_cooperative_deposit_vs_oracle():
+    """the cooperative deposit (LPA_ORDER_PADDED store, neighbour exchange, row-end lanes, parked misfits) against the
+    oracle's fused kernel on a multi-tile patch: hot enough for cell changes, ragged cell counts, dead slots"""
+    import copy
+    rng = np.random.default_rng(23)
+    nx, ny, dx, dy = 24, 70, 4e-8, 5e-8
+    dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2))
+    f = Fields2D(nx, ny, dx, dy, 0.0, 0.0, 3)
+    for a in ("ex", "ey", "ez"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e12
+    for a in ("bx", "by", "bz"):
+        getattr(f, a)[...] = rng.normal(size=f.shape) * 1e4
+    n = nx * ny * 30
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx
+    p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    for a in ("ux", "uy", "uz"):
+        getattr(p, a)[:] = rng.normal(size=n) * 0.3
+    p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+    p.w[:] = rng.uniform(0.5, 1.5, n) * 1e27 * dx * dy / 30
+    p.is_dead[rng.random(n) < 0.05] = True
+    fo, po = copy.deepcopy(f), copy.deepcopy(p)
+    kernels.unified_boris_pusher_cpu_2d([p], [f], 1, dt, QE, ME, tiled=True, order=2)
+    oracle.unified_boris_pusher_cpu_2d([po], [fo], 1, dt, QE, ME)
+    live = ~p.is_dead
+    for a in ("x", "y", "ux", "uy", "uz", "inv_gamma"):
+        assert_close(getattr(p, a)[live], getattr(po, a)[live], 1e-12, what=a)
+    for a in ("rho", "jx", "jy", "jz"):
+        assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
