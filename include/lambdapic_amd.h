@@ -388,6 +388,29 @@ int lpa_sync_guard_fields_2d(double *const *arrays, int32_t ncomp, const int64_t
 int lpa_sync_currents_2d(double *const *arrays, const int64_t *neighbor_ipatch, int32_t npatches, int32_t nx,
                          int32_t ny, int32_t ng, void *stream);
 
+/* ---- particle ownership between the patches of a list: the two halves of Patches.sync_particles
+ *      (core/patch/patch.py:705-742).  Tables are DEVICE arrays of per-patch device pointers; `bounds` =
+ *      [npatches][4] xmin xmax ymin ymax WITH the half cell the reference adds (sync_particles_2d.c:236-241).
+ *      lpa_sync_particles_count_2d: the counting loop of get_npart_to_extend_2d (core/patch/sync_particles_2d.c:37-84,
+ *        204-283).  `xy` = [npatches][2] x and y pointers; npart_outgoing[npatches][8] (Boundary2D order) and
+ *        ndead[npatches] (device int64) are zeroed and filled; the caller derives npart_incoming / npart_to_extend /
+ *        npart_alive from them exactly like :285-318 and grows its arrays.
+ *      lpa_sync_particles_fill_2d: fill_particles_from_boundary_2d (:322-518).  `attrs` = [npatches][nattrs] pointers
+ *        (x at iattr_x, y at iattr_y).  The leavers of the 8 neighbours, in (boundary, index) order, go into the
+ *        receiver's dead slots in ascending order -- the reference's own placement, slot for slot --, with +- L on
+ *        x / y like handle_periodic (:168-182); then every live particle outside its patch's bounds dies (x = y = NaN,
+ *        :185-202).  Workspace: lpa_sync_particles_workspace_bytes. */
+int lpa_sync_particles_count_2d(const double *const *xy, const uint8_t *const *is_dead, const int64_t *npart,
+                                const double *bounds, int32_t npatches, int64_t max_npart,
+                                int64_t *npart_outgoing, int64_t *ndead, void *stream);
+int64_t lpa_sync_particles_workspace_bytes(int32_t npatches, int64_t max_npart);
+int lpa_sync_particles_fill_2d(double *const *attrs, int32_t nattrs, int32_t iattr_x, int32_t iattr_y,
+                               uint8_t *const *is_dead, const int64_t *npart, const double *bounds,
+                               const int64_t *neighbor_ipatch, const int64_t *npart_incoming,
+                               const int64_t *npart_outgoing, int32_t npatches, int64_t max_npart,
+                               double xmin_global, double xmax_global, double ymin_global, double ymax_global,
+                               double dx, double dy, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- bucket sort with the reference's bookkeeping, one patch per call: replaces the body of
  *      sort_particles_patches_2d / _3d (core/sort/cpu2d.c:220-303, cpu3d.c) = calculate_bucket_index (:9-54:
  *      bucket = floor((r - r0) / d) per axis, out of range -> last bucket or clamped when reverse_x, a dead

@@ -375,3 +375,224 @@ extern "C" int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead
     }
     return LPA_OK;
 }
+
+// =====================================================================================================
+// particle ownership between the patches of a list (core/patch/sync_particles_2d.c:37-518):
+//   lpa_sync_particles_count_2d   count_outgoing_particles of get_npart_to_extend_2d (:37-84,258-283): the leavers of
+//                                 every patch per boundary (Boundary2D order) + its dead slots
+//   lpa_sync_particles_fill_2d    fill_particles_from_boundary_2d (:322-518): the leavers of the 8 neighbours, in
+//                                 (boundary, index) order, go into the receiver's dead slots in ascending order
+//                                 (periodic +- L on x / y like handle_periodic), then everything outside a patch's
+//                                 bounds dies (x = y = NaN).  The placement is the reference's own, slot for slot.
+// Patch arrays: device tables of per-patch device pointers; `bounds` = [npatches][4] xmin xmax ymin ymax WITH the half
+// cell the reference adds (:236-241).
+// =====================================================================================================
+constexpr int SP_DEAD = 8, SP_STAY = 9;
+
+// x / y of patch p inside a table of per-patch array pointers: tab[p * stride + ix], tab[p * stride + iy]
+struct XYTab {
+    const double *const *tab;
+    int stride, ix, iy;
+    __device__ __forceinline__ const double *x(int p) const { return tab[(long)p * stride + ix]; }
+    __device__ __forceinline__ const double *y(int p) const { return tab[(long)p * stride + iy]; }
+};
+
+// the reference's classification (count_outgoing_particles, sync_particles_2d.c:37-84)
+__device__ __forceinline__ int sp_class(double x, double y, bool dead, const double *b) {
+    if (dead) return SP_DEAD;
+    const double xmin = b[0], xmax = b[1], ymin = b[2], ymax = b[3];
+    if (y < ymin) return x < xmin ? 4 : (x > xmax ? 5 : 2);
+    if (y > ymax) return x < xmin ? 6 : (x > xmax ? 7 : 3);
+    return x < xmin ? 0 : (x > xmax ? 1 : SP_STAY);
+}
+
+__global__ void __launch_bounds__(256) k_sync_particles_count(XYTab xy, const uint8_t *const *is_dead,
+                                                              const int64_t *npart, const double *bounds,
+                                                              unsigned long long *nout, unsigned long long *ndead) {
+    const int p = blockIdx.y;
+    const long n = npart[p];
+    const double *x = xy.x(p), *y = xy.y(p);
+    const uint8_t *dead = is_dead[p];
+    __shared__ unsigned int s_cnt[9];
+    if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (long ip = (long)blockIdx.x * blockDim.x + threadIdx.x; ip < n; ip += (long)gridDim.x * blockDim.x) {
+        const int c = sp_class(x[ip], y[ip], dead[ip] != 0, bounds + 4 * p);
+        if (c != SP_STAY) atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && s_cnt[threadIdx.x])
+        atomicAdd(&nout[(long)p * 8 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    if (threadIdx.x == 8 && s_cnt[8]) atomicAdd(&ndead[p], (unsigned long long)s_cnt[8]);
+}
+
+// one workgroup per patch: stable rank of every leaver inside its class and of every dead slot among the dead
+// (ascending index, like the reference's sequential loops); leavers are listed class by class
+__global__ void __launch_bounds__(256) k_sync_particles_rank(XYTab xy, const uint8_t *const *is_dead,
+                                                             const int64_t *npart, const double *bounds,
+                                                             const int64_t *nout, int32_t *list, int32_t *drank,
+                                                             long stride) {
+    const int p = blockIdx.x;
+    const long n = npart[p];
+    const double *x = xy.x(p), *y = xy.y(p);
+    const uint8_t *dead = is_dead[p];
+    __shared__ int s_base[9], s_w[4][9], s_cbase[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 9) s_base[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < 8; c++) { s_cbase[c] = run; run += (int)nout[(long)p * 8 + c]; }
+    }
+    __syncthreads();
+    for (long c0 = 0; c0 < n; c0 += 256) {
+        const long ip = c0 + threadIdx.x;
+        const int cls = ip < n ? sp_class(x[ip], y[ip], dead[ip] != 0, bounds + 4 * p) : SP_STAY;
+        int pre = 0;
+        for (int c = 0; c < 9; c++) {          // wave-uniform loop: rank inside the wave, per class
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) pre = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_w[wv][c] = __popcll(m);
+        }
+        __syncthreads();
+        if (cls != SP_STAY) {
+            int r = s_base[cls] + pre;
+            for (int w = 0; w < wv; w++) r += s_w[w][cls];
+            if (cls == SP_DEAD) drank[(long)p * stride + ip] = r;
+            else list[(long)p * stride + s_cbase[cls] + r] = (int32_t)ip;
+        }
+        __syncthreads();
+        if (threadIdx.x < 9)
+            s_base[threadIdx.x] += s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double sp_periodic(double v, double gmin, double gmax, double L, double pmin, double pmax,
+                                              double cell) {   // handle_periodic, sync_particles_2d.c:168-182
+    double out = v;
+    if (v > gmax && fabs(pmin - gmin) < cell) out -= L;
+    if (v < gmin && fabs(pmax - gmax) < cell) out += L;
+    return out;
+}
+
+__global__ void __launch_bounds__(256) k_sync_particles_fill(double *const *attrs, int nattrs, int iax, int iay,
+                                                             uint8_t *const *is_dead, const int64_t *npart,
+                                                             const double *bounds, const int64_t *neighbor,
+                                                             const int64_t *nin, const int64_t *nout,
+                                                             const int32_t *list, const int32_t *drank, long stride,
+                                                             double gx0, double gx1, double gy0, double gy1,
+                                                             double dx, double dy) {
+    const int p = blockIdx.y;
+    const long n = npart[p], new_n = nin[p];
+    const int opp[8] = {1, 0, 3, 2, 7, 6, 5, 4};      // OPPOSITE_BOUNDARY, sync_particles_2d.c:26-35
+    uint8_t *dead = is_dead[p];
+    for (long ip = (long)blockIdx.x * blockDim.x + threadIdx.x; ip < n; ip += (long)gridDim.x * blockDim.x) {
+        if (!dead[ip]) continue;
+        long r = drank[(long)p * stride + ip];         // this is the r-th dead slot: it takes incoming particle r
+        if (r >= new_n) continue;
+        long q = -1, src = -1;
+        for (int b = 0; b < 8 && q < 0; b++) {         // incoming order: boundary by boundary (:131-146)
+            const long nb = neighbor[(long)p * 8 + b];
+            if (nb < 0) continue;
+            const long cnt = nout[nb * 8 + opp[b]];
+            if (r < cnt) {
+                long base = 0;
+                for (int c = 0; c < opp[b]; c++) base += nout[nb * 8 + c];
+                q = nb;
+                src = list[nb * stride + base + r];
+            } else {
+                r -= cnt;
+            }
+        }
+        if (q < 0) continue;                            // (counts inconsistent with the arrays: nothing to take)
+        const double *bp = bounds + 4 * p;
+        for (int a = 0; a < nattrs; a++) {
+            double v = attrs[q * nattrs + a][src];
+            if (a == iax) v = sp_periodic(v, gx0, gx1, gx1 - gx0, bp[0], bp[1], dx);
+            if (a == iay) v = sp_periodic(v, gy0, gy1, gy1 - gy0, bp[2], bp[3], dy);
+            attrs[(long)p * nattrs + a][ip] = v;
+        }
+        dead[ip] = 0;
+    }
+}
+
+// mark_out_of_bound_as_dead (:185-202)
+__global__ void __launch_bounds__(256) k_sync_particles_mark(double *const *attrs, int nattrs, int iax, int iay,
+                                                             uint8_t *const *is_dead, const int64_t *npart,
+                                                             const double *bounds) {
+    const int p = blockIdx.y;
+    const long n = npart[p];
+    const double *b = bounds + 4 * p;
+    double *x = attrs[(long)p * nattrs + iax], *y = attrs[(long)p * nattrs + iay];
+    uint8_t *dead = is_dead[p];
+    for (long ip = (long)blockIdx.x * blockDim.x + threadIdx.x; ip < n; ip += (long)gridDim.x * blockDim.x) {
+        if (dead[ip]) continue;
+        if (x[ip] < b[0] || x[ip] > b[1] || y[ip] < b[2] || y[ip] > b[3]) {
+            dead[ip] = 1;
+            x[ip] = __longlong_as_double(0x7ff8000000000000ll);
+            y[ip] = x[ip];
+        }
+    }
+}
+
+static unsigned sp_blocks(int64_t max_npart) {
+    long nb = (max_npart + 255) / 256;
+    return (unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+
+extern "C" int lpa_sync_particles_count_2d(const double *const *xy, const uint8_t *const *is_dead,
+                                           const int64_t *npart, const double *bounds, int32_t npatches,
+                                           int64_t max_npart, int64_t *npart_outgoing, int64_t *ndead, void *stream) {
+    LPA_REQUIRE(xy && is_dead && npart && bounds && npatches >= 0 && max_npart >= 0 && npart_outgoing && ndead,
+                "lpa_sync_particles_count_2d: bad args");
+    if (npatches == 0) return LPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(npart_outgoing, 0, 8 * (size_t)npatches * 8, st) != hipSuccess ||
+        hipMemsetAsync(ndead, 0, 8 * (size_t)npatches, st) != hipSuccess) {
+        lpa_set_error("lpa_sync_particles_count_2d: memset failed");
+        return LPA_ERR_HIP;
+    }
+    if (max_npart == 0) return LPA_OK;
+    hipLaunchKernelGGL(k_sync_particles_count, dim3(sp_blocks(max_npart), npatches), dim3(256), 0, st,
+                       XYTab{xy, 2, 0, 1}, is_dead, npart, bounds, (unsigned long long *)npart_outgoing,
+                       (unsigned long long *)ndead);
+    LPA_CHECK_LAUNCH("lpa_sync_particles_count_2d");
+    return LPA_OK;
+}
+
+extern "C" int64_t lpa_sync_particles_workspace_bytes(int32_t npatches, int64_t max_npart) {
+    if (npatches < 0 || max_npart < 0) return -1;
+    return 2 * (int64_t)sizeof(int32_t) * (npatches > 0 ? npatches : 1) * (max_npart > 0 ? max_npart : 1);
+}
+
+extern "C" int lpa_sync_particles_fill_2d(double *const *attrs, int32_t nattrs, int32_t iattr_x, int32_t iattr_y,
+                                          uint8_t *const *is_dead, const int64_t *npart, const double *bounds,
+                                          const int64_t *neighbor_ipatch, const int64_t *npart_incoming,
+                                          const int64_t *npart_outgoing, int32_t npatches, int64_t max_npart,
+                                          double xmin_global, double xmax_global, double ymin_global,
+                                          double ymax_global, double dx, double dy, void *workspace,
+                                          int64_t workspace_bytes, void *stream) {
+    LPA_REQUIRE(attrs && nattrs >= 2 && iattr_x >= 0 && iattr_x < nattrs && iattr_y >= 0 && iattr_y < nattrs &&
+                    iattr_x != iattr_y && is_dead && npart && bounds && neighbor_ipatch && npart_incoming &&
+                    npart_outgoing && npatches >= 0 && max_npart >= 0 && dx > 0 && dy > 0 && workspace,
+                "lpa_sync_particles_fill_2d: bad args (attrs must contain x and y)");
+    if (npatches == 0 || max_npart == 0) return LPA_OK;
+    if (workspace_bytes < lpa_sync_particles_workspace_bytes(npatches, max_npart)) {
+        lpa_set_error("lpa_sync_particles_fill_2d: workspace too small");
+        return LPA_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *list = (int32_t *)workspace, *drank = list + (size_t)npatches * max_npart;
+    const XYTab xy{(const double *const *)attrs, nattrs, iattr_x, iattr_y};
+    hipLaunchKernelGGL(k_sync_particles_rank, dim3(npatches), dim3(256), 0, st, xy, (const uint8_t *const *)is_dead,
+                       npart, bounds, npart_outgoing, list, drank, (long)max_npart);
+    LPA_CHECK_LAUNCH("lpa_sync_particles_fill_2d (rank)");
+    hipLaunchKernelGGL(k_sync_particles_fill, dim3(sp_blocks(max_npart), npatches), dim3(256), 0, st, attrs, nattrs,
+                       iattr_x, iattr_y, is_dead, npart, bounds, neighbor_ipatch, npart_incoming, npart_outgoing, list,
+                       drank, (long)max_npart, xmin_global, xmax_global, ymin_global, ymax_global, dx, dy);
+    LPA_CHECK_LAUNCH("lpa_sync_particles_fill_2d (fill)");
+    hipLaunchKernelGGL(k_sync_particles_mark, dim3(sp_blocks(max_npart), npatches), dim3(256), 0, st, attrs, nattrs,
+                       iattr_x, iattr_y, is_dead, npart, bounds);
+    LPA_CHECK_LAUNCH("lpa_sync_particles_fill_2d (mark)");
+    return LPA_OK;
+}

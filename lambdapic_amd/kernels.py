@@ -416,3 +416,89 @@ def sort_particles_patches_3d(x_list, y_list, z_list, is_dead_list, attrs_list, 
                                     bucket_count_list[ip], bucket_bound_min_list[ip], bucket_bound_max_list[ip],
                                     reverse_x)
     return moved
+
+
+# ---- particle ownership between the patches of a list (core/patch/sync_particles_2d.c) -------------------------
+def _patch_bounds(patches_list, npatches, dx, dy):
+    return np.array([[p.xmin - 0.5 * dx, p.xmax + 0.5 * dx, p.ymin - 0.5 * dy, p.ymax + 0.5 * dy]
+                     for p in patches_list[:npatches]], dtype=np.float64)
+
+
+class _PatchParticlesOnDevice:
+    """the attribute arrays of every patch's particle bag, padded to the longest bag, + the pointer tables"""
+
+    def __init__(self, particles_list, npatches, attrs, dev):
+        self.parts, self.attrs, self.dev = particles_list[:npatches], list(attrs), dev
+        self.npart = np.array([q.npart for q in self.parts], dtype=np.int64)
+        self.nmax = int(self.npart.max()) if npatches else 0
+        host = np.full((npatches, len(self.attrs), max(self.nmax, 1)), np.nan)
+        dead = np.ones((npatches, max(self.nmax, 1)), dtype=np.uint8)
+        for k, q in enumerate(self.parts):
+            for a, name in enumerate(self.attrs):
+                host[k, a, :q.npart] = getattr(q, name)[:q.npart]
+            dead[k, :q.npart] = q.is_dead[:q.npart]
+        self.data = torch.from_numpy(host).to(dev)
+        self.dead = torch.from_numpy(dead).to(dev)
+        self.ptrs = torch.tensor([self.data[k, a].data_ptr() for k in range(npatches) for a in range(len(self.attrs))],
+                                 dtype=torch.int64, device=dev)
+        self.dead_ptrs = torch.tensor([self.dead[k].data_ptr() for k in range(npatches)], dtype=torch.int64, device=dev)
+        self.npart_dev = torch.from_numpy(self.npart).to(dev)
+
+    def download(self):
+        data, dead = self.data.cpu().numpy(), self.dead.cpu().numpy()
+        for k, q in enumerate(self.parts):
+            for a, name in enumerate(self.attrs):
+                getattr(q, name)[:q.npart] = data[k, a, :q.npart]
+            q.is_dead[:q.npart] = dead[k, :q.npart].view(np.bool_)
+
+
+def get_npart_to_extend_2d(particles_list, patches_list, npatches, dx, dy):
+    """GPU drop-in for `core/patch/sync_particles_2d.c:204-320`: returns ``(npart_to_extend, npart_incoming,
+    npart_outgoing, npart_alive)`` (int64 arrays; npart_outgoing is [npatches * 8] in Boundary2D order)"""
+    L, dev = lib(), _device()
+    z = lambda n: np.zeros(n, dtype=np.int64)
+    if npatches <= 0:
+        return z(0), z(0), z(0), z(0)
+    d = _PatchParticlesOnDevice(particles_list, npatches, ["x", "y"], dev)
+    bounds = torch.from_numpy(_patch_bounds(patches_list, npatches, dx, dy)).to(dev)
+    nout = torch.zeros(npatches * 8, dtype=torch.int64, device=dev)
+    ndead = torch.zeros(npatches, dtype=torch.int64, device=dev)
+    check(L.lpa_sync_particles_count_2d(d.ptrs.data_ptr(), d.dead_ptrs.data_ptr(), d.npart_dev.data_ptr(),
+                                        bounds.data_ptr(), npatches, d.nmax, nout.data_ptr(), ndead.data_ptr(),
+                                        _stream(dev)), "lpa_sync_particles_count_2d")
+    nout_h, ndead_h = nout.cpu().numpy(), ndead.cpu().numpy()
+    opp = [1, 0, 3, 2, 7, 6, 5, 4]                        # OPPOSITE_BOUNDARY, sync_particles_2d.c:26-35
+    ext, inc, alive = z(npatches), z(npatches), z(npatches)
+    for ip, p in enumerate(patches_list[:npatches]):      # sync_particles_2d.c:285-318
+        new = sum(int(nout_h[int(nb) * 8 + opp[b]]) for b, nb in enumerate(p.neighbor_ipatch) if nb >= 0)
+        npart = int(d.npart[ip])
+        alive[ip] = npart - int(ndead_h[ip]) + new
+        if new - int(ndead_h[ip]) > 0:
+            ext[ip] = new - int(ndead_h[ip]) + int(npart * 0.25)
+        inc[ip] = new
+    return ext, inc, nout_h, alive
+
+
+def fill_particles_from_boundary_2d(particles_list, patches_list, npart_incoming, npart_outgoing, npatches, dx, dy,
+                                    xmin_global, xmax_global, ymin_global, ymax_global, attrs):
+    """GPU drop-in for `core/patch/sync_particles_2d.c:322-518` (arrays are filled / killed in place)"""
+    L, dev = lib(), _device()
+    attrs = list(attrs)
+    if "x" not in attrs or "y" not in attrs:
+        raise ValueError("attrs must contain 'x' and 'y'")
+    if npatches <= 0:
+        return None
+    d = _PatchParticlesOnDevice(particles_list, npatches, attrs, dev)
+    bounds = torch.from_numpy(_patch_bounds(patches_list, npatches, dx, dy)).to(dev)
+    nb = _neighbor_table(patches_list, npatches, dev)
+    nin = torch.from_numpy(np.ascontiguousarray(npart_incoming, dtype=np.int64)).to(dev)
+    nout = torch.from_numpy(np.ascontiguousarray(npart_outgoing, dtype=np.int64)).to(dev)
+    nbytes = L.lpa_sync_particles_workspace_bytes(npatches, d.nmax)
+    ws = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    check(L.lpa_sync_particles_fill_2d(d.ptrs.data_ptr(), len(attrs), attrs.index("x"), attrs.index("y"),
+                                       d.dead_ptrs.data_ptr(), d.npart_dev.data_ptr(), bounds.data_ptr(),
+                                       nb.data_ptr(), nin.data_ptr(), nout.data_ptr(), npatches, d.nmax,
+                                       xmin_global, xmax_global, ymin_global, ymax_global, dx, dy, ws.data_ptr(),
+                                       ws.numel(), _stream(dev)), "lpa_sync_particles_fill_2d")
+    d.download()
+    return None

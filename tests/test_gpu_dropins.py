@@ -240,3 +240,34 @@ def test_sort_dropins_vs_reference_golden_variants(golden):
         assert np.array_equal(dead, g[f"{tag}_in_is_dead"][src])
         for lo, hi in zip(g[f"{tag}_bucket_bound_min"].ravel(), g[f"{tag}_bucket_bound_max"].ravel()):
             assert np.array_equal(np.sort(src[lo:hi]), np.sort(src_ref[lo:hi]))      # same slots' contents per bucket
+
+
+def test_sync_particles_dropins_vs_reference_golden(golden):
+    """`get_npart_to_extend_2d` + `fill_particles_from_boundary_2d` (core/patch/sync_particles_2d.c:204,322) on the
+    reference's fixture (g7: 2 x 2 periodic patches, everything shifted across two boundaries): counts, the slot every
+    incoming particle lands in, the +- L shifts and the dead pattern are the reference's, bit for bit"""
+    g = golden("g7_sync_2d")
+    dx, dy = float(g["dx"]), float(g["dy"])
+    P = make_patches_2d(int(g["nx"]), int(g["ny"]), dx, dy, int(g["npx"]), int(g["npy"]))
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        q.initialize(g[f"pin{k}_x"].size)
+        for a in ["x", "y", "ux", "w", "_id"]:
+            getattr(q, a)[:] = g[f"pin{k}_{a}"]
+        q.is_dead[:] = g[f"pin{k}_is_dead"]
+    parts = [p.particles[0] for p in P]
+    ext, inc, outg, alive = kernels.get_npart_to_extend_2d(parts, list(P), P.npatches, dx, dy)
+    assert np.array_equal(alive, g["npart_alive"])
+    for q, n in zip(parts, ext):                       # Patches.sync_particles, core/patch/patch.py:705-742
+        if n > 0:
+            q.extend(int(n))
+    kernels.fill_particles_from_boundary_2d(parts, list(P), inc, outg, P.npatches, dx, dy, P.xmin_global, P.xmax_global,
+                                            P.ymin_global, P.ymax_global, parts[0].attrs)
+    for k, q in enumerate(parts):
+        assert q.npart == g[f"pout{k}_x"].size
+        assert np.array_equal(q.is_dead, g[f"pout{k}_is_dead"]), k
+        live = ~q.is_dead
+        for a in ["x", "y", "ux", "w"]:
+            assert np.array_equal(getattr(q, a)[live], g[f"pout{k}_{a}"][live]), (k, a)
+        assert np.array_equal(q.id[live], g[f"pout{k}__id"].view(np.uint64)[live])
+        assert np.all(np.isnan(q.x[q.is_dead & np.isnan(g[f"pout{k}_x"])]))
