@@ -502,3 +502,67 @@ def fill_particles_from_boundary_2d(particles_list, patches_list, npart_incoming
                                        ws.numel(), _stream(dev)), "lpa_sync_particles_fill_2d")
     d.download()
     return None
+
+
+# ---- numba-level Maxwell drivers on array lists (core/maxwell/cpu.py:38-79,115-158) ---------------------------------
+class _ArrayBag:
+    """the minimum of a Fields2D / Fields3D the grid upload reads, around caller-owned arrays (wrapped layout)"""
+
+    def __init__(self, arrays, n, d, ng):
+        self.nx, self.ny = n[0], n[1]
+        self.dx, self.dy = d[0], d[1]
+        self.x0 = self.y0 = self.z0 = 0.0
+        if len(n) == 3:
+            self.nz, self.dz = n[2], d[2]
+        self.n_guard = ng
+        zero = None
+        for name in FIELD_ORDER:
+            a = arrays.get(name)
+            if a is None:
+                zero = np.zeros_like(arrays["ex"]) if zero is None else zero
+                a = zero
+            setattr(self, name, a)
+
+
+def _maxwell_patches(which, lists, npatches, n, d, dt, ng):
+    L, dev = lib(), _device()
+    dim = len(n)
+    names = ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz")[:len(lists)]
+    for ip in range(npatches):
+        bag = _ArrayBag({a: lst[ip] for a, lst in zip(names, lists)}, n, d, ng)
+        g = _GridOnDevice(bag, dev)
+        st = _stream(dev)
+        if which == "e":
+            fn = L.lpa_fdtd_e_2d if dim == 2 else L.lpa_fdtd_e_3d
+            check(fn(g.ref(), dt, constants.EPSILON_0, st), "lpa_fdtd_e")
+            g.download(["ex", "ey", "ez"])
+        else:
+            fn = L.lpa_fdtd_b_2d if dim == 2 else L.lpa_fdtd_b_3d
+            check(fn(g.ref(), dt, st), "lpa_fdtd_b")
+            g.download(["bx", "by", "bz"])
+
+
+def update_efield_patches_2d(ex_list, ey_list, ez_list, bx_list, by_list, bz_list, jx_list, jy_list, jz_list, npatches,
+                             dx, dy, dt, nx, ny, n_guard):
+    """GPU drop-in for `core/maxwell/cpu.py:38-59` (arrays in λPIC's wrapped layout, updated in place)"""
+    _maxwell_patches("e", [ex_list, ey_list, ez_list, bx_list, by_list, bz_list, jx_list, jy_list, jz_list], npatches,
+                     (nx, ny), (dx, dy), dt, n_guard)
+
+
+def update_bfield_patches_2d(ex_list, ey_list, ez_list, bx_list, by_list, bz_list, npatches, dx, dy, dt, nx, ny, n_guard):
+    """GPU drop-in for `core/maxwell/cpu.py:61-79`"""
+    _maxwell_patches("b", [ex_list, ey_list, ez_list, bx_list, by_list, bz_list], npatches, (nx, ny), (dx, dy), dt, n_guard)
+
+
+def update_efield_patches_3d(ex_list, ey_list, ez_list, bx_list, by_list, bz_list, jx_list, jy_list, jz_list, npatches,
+                             dx, dy, dz, dt, nx, ny, nz, n_guard):
+    """GPU drop-in for `core/maxwell/cpu.py:115-137`"""
+    _maxwell_patches("e", [ex_list, ey_list, ez_list, bx_list, by_list, bz_list, jx_list, jy_list, jz_list], npatches,
+                     (nx, ny, nz), (dx, dy, dz), dt, n_guard)
+
+
+def update_bfield_patches_3d(ex_list, ey_list, ez_list, bx_list, by_list, bz_list, npatches, dx, dy, dz, dt, nx, ny, nz,
+                             n_guard):
+    """GPU drop-in for `core/maxwell/cpu.py:139-158`"""
+    _maxwell_patches("b", [ex_list, ey_list, ez_list, bx_list, by_list, bz_list], npatches, (nx, ny, nz), (dx, dy, dz),
+                     dt, n_guard)

@@ -271,3 +271,25 @@ def test_sync_particles_dropins_vs_reference_golden(golden):
             assert np.array_equal(getattr(q, a)[live], g[f"pout{k}_{a}"][live]), (k, a)
         assert np.array_equal(q.id[live], g[f"pout{k}__id"].view(np.uint64)[live])
         assert np.all(np.isnan(q.x[q.is_dead & np.isnan(g[f"pout{k}_x"])]))
+
+
+def test_maxwell_patch_drivers_vs_reference_golden(golden):
+    """`update_efield_patches_2d/3d`, `update_bfield_patches_2d/3d` with the reference's argument lists
+    (core/maxwell/cpu.py:38-79,115-158) on g5 (recorded from the reference's own FDTD), two patches per call"""
+    for dim, name in ((2, "g5_fdtd_2d"), (3, "g5_fdtd_3d")):
+        g = golden(name)
+        n = tuple(int(g[k]) for k in ("nx", "ny", "nz")[:dim])
+        d = tuple(float(g[k]) for k in ("dx", "dy", "dz")[:dim])
+        ng, dt = int(g["ng"]), float(g["dt"])
+        names = ["ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"]
+        lists = {a: [g["in_" + a].copy(), g["in_" + a].copy()] for a in names}      # the same patch twice
+        args_e = [lists[a] for a in names] + [2, *d, dt, *n, ng]
+        (kernels.update_efield_patches_2d if dim == 2 else kernels.update_efield_patches_3d)(*args_e)
+        for k in range(2):
+            for a in ["ex", "ey", "ez"]:
+                assert_close(lists[a][k], g[f"outE_{a}"], 1e-14, what=f"{name} {a}")
+        args_b = [lists[a] for a in names[:6]] + [2, *d, dt, *n, ng]
+        (kernels.update_bfield_patches_2d if dim == 2 else kernels.update_bfield_patches_3d)(*args_b)
+        for k in range(2):
+            for a in ["bx", "by", "bz"]:
+                assert_close(lists[a][k], g[f"outB_{a}"], 1e-14, what=f"{name} {a}")
