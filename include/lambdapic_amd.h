@@ -117,7 +117,7 @@ typedef struct {
  *                atomics fall on 32 different bank pairs (conflict free). */
 #define LPA_ORDER_CELL_MAJOR 0
 #define LPA_ORDER_STRIPED 1
-/* LPA_ORDER_PADDED (2-D): the striped order with its leading ranks -- those that at least LPA_PAD_MIN_CELLS of the
+/* LPA_ORDER_PADDED (2-D and 3-D tilings): the striped order with its leading ranks -- those that at least LPA_PAD_MIN_CELLS of the
  * tile's 256 cells have -- stored as FULL stripes: slot = tile start + rank * 256 + cell, the missing cells are holes
  * (x = y = NaN); the other ranks follow compacted as in LPA_ORDER_STRIPED, and every tile's slot count is rounded up to
  * 64.  A slot's position then tells the cell it belongs to (lpa_tiling.pad_ranks[tile] = number of full stripes):

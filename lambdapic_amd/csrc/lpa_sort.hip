@@ -504,7 +504,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                 "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(src, dim) && lpa_part_ok(dst, dim) && workspace && out,
                 "%s: bad particle stores / workspace", name);
-    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || (order == LPA_ORDER_PADDED && dim == 2),
+    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED,
                 "%s: bad order", name);
     LPA_REQUIRE(src->n < (1ll << 31) - 1, "%s: more than 2^31 particles in one store", name);
     LPA_REQUIRE(dst->n >= src->n, "%s: dst capacity (dst->n) smaller than src->n", name);
@@ -555,7 +555,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                            LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks);
         LPA_CHECK_LAUNCH("k_stripe_table (padded)");
         if (hipMemsetAsync(dv.x, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
-            hipMemsetAsync(dv.y, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess) {
+            hipMemsetAsync(dv.y, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
+            (dim == 3 && hipMemsetAsync(dv.z, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess)) {
             lpa_set_error("%s: memset failed", name);
             return LPA_ERR_HIP;
         }

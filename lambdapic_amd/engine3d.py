@@ -162,6 +162,9 @@ class PicEngine3D:
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
         self._axes = {}
+        # LPA_ORDER_STRIPED, or LPA_ORDER_PADDED: the leading ranks of every tile as full stripes with holes (the store
+        # needs a few per cent more slots) -- every 16-lane group is then one z column of 16 different cells
+        self.order = _lib.LPA_ORDER_STRIPED
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every launch of the
         # tiled push+deposit kernel on the stream it runs on
         self.kernel_events = None
@@ -239,7 +242,7 @@ class PicEngine3D:
         cap = sp["data"].shape[1]
         src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
         check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), self.block_particles, _lib.LPA_ORDER_STRIPED,
+                                       ws["sort"].numel(), self.block_particles, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
         n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
         area = self.arrival_area()

@@ -67,8 +67,8 @@ def test_3d_step_vs_oracle():
         assert_close(got[a], getattr(parts[0], a), 1e-11, what=a)
 
 
-@pytest.mark.parametrize("uth,sort_interval", [(0.3, 4), (0.02, 3)])
-def test_3d_tiled_step_vs_oracle(uth, sort_interval):
+@pytest.mark.parametrize("uth,sort_interval,order", [(0.3, 4, 1), (0.02, 3, 1), (0.3, 3, 2)])
+def test_3d_tiled_step_vs_oracle(uth, sort_interval, order):
     """the tile-sorted path: lpa_sort_tiles_3d (4 x 4 x 16-cell tiles) + LDS-tiled kernel + overflow list
     against the oracle's 3-D step.  Hot case: particles drift beyond the tile margin between sorts
     (overflow list) and wrap around the box; cold case: everything stays on the LDS path."""
@@ -85,8 +85,10 @@ def test_3d_tiled_step_vs_oracle(uth, sort_interval):
     f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, 3)
     eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=True, sort_interval=sort_interval, block_particles=1024)
     assert eng.tiled
-    eng.add_species(*species[0], e)
-    eng.add_species(*species[1], ion)
+    eng.order = order                      # 2 = LPA_ORDER_PADDED: full stripes with holes (the store grows)
+    cap = 3 * n if order == 2 else None
+    eng.add_species(*species[0], e, capacity=cap)
+    eng.add_species(*species[1], ion, capacity=cap)
     parts = [copy.deepcopy(e), copy.deepcopy(ion)]
     lo = (-dx / 2, -dy / 2, -dz / 2)
     hi = (nx * dx - dx / 2, ny * dy - dy / 2, nz * dz - dz / 2)

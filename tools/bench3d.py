@@ -16,6 +16,7 @@ ap.add_argument("--nz", type=int, default=256); ap.add_argument("--ppc", type=in
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--global", dest="glob", action="store_true"); ap.add_argument("--sort-interval", type=int, default=10)
 ap.add_argument("--block-particles", type=int, default=4096)
+ap.add_argument("--order", default="striped", choices=["striped", "padded"])
 ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (gamma beta)")
 a = ap.parse_args()
 lam = 0.8e-6
@@ -24,19 +25,22 @@ dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
 eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3, tiled=not a.glob, sort_interval=a.sort_interval,
                   block_particles=a.block_particles)
 n = a.nx * a.ny * a.nz * a.ppc
+if a.order == "padded":
+    eng.order = _lib.LPA_ORDER_PADDED
+cap = int(1.6 * n) + 65536 if a.order == "padded" else n
 dev = eng.device
 g = torch.Generator(device=dev).manual_seed(1)
 cell = torch.arange(n, device=dev) // a.ppc
 r = lambda: torch.rand(n, device=dev, dtype=torch.float64, generator=g)
-data = torch.empty((8, n), dtype=torch.float64, device=dev)
-data[0] = ((cell // (a.ny * a.nz)).double() + r() - 0.5) * dx
-data[1] = (((cell // a.nz) % a.ny).double() + r() - 0.5) * dy
-data[2] = ((cell % a.nz).double() + r() - 0.5) * dz
+data = torch.full((8, cap), float('nan'), dtype=torch.float64, device=dev)
+data[0, :n] = ((cell // (a.ny * a.nz)).double() + r() - 0.5) * dx
+data[1, :n] = (((cell // a.nz) % a.ny).double() + r() - 0.5) * dy
+data[2, :n] = ((cell % a.nz).double() + r() - 0.5) * dz
 for k in (3, 4, 5):
-    data[k] = torch.randn(n, device=dev, dtype=torch.float64, generator=g) * a.uth
-data[6] = 1.0 / torch.sqrt(1 + data[3] ** 2 + data[4] ** 2 + data[5] ** 2)
+    data[k, :n] = torch.randn(n, device=dev, dtype=torch.float64, generator=g) * a.uth
+data[6, :n] = 1.0 / torch.sqrt(1 + data[3, :n] ** 2 + data[4, :n] ** 2 + data[5, :n] ** 2)
 omega = 2 * np.pi * 299792458.0 / lam
-data[7] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE ** 2 * dx * dy * dz / a.ppc
+data[7, :n] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE ** 2 * dx * dy * dz / a.ppc
 eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
 for _ in range(a.warmup):
     eng.step(dt)
