@@ -689,7 +689,11 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         [[maybe_unused]] unsigned long long mid = 0;
         [[maybe_unused]] bool mvac = false;
         [[maybe_unused]] int mcls = 0, mh = -1;
+#ifdef LPA_ABLATE_NO_PASS2   // diagnostic build (wrong physics): what the second pass costs
+        for (int i = threadIdx.x; i < 0; i += blockDim.x) {
+#else
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
+#endif
             uint32_t info = RL_DEP;
             if (RELOC) info = rl.aux_info[begin + i];
             const bool first = RELOC && i == (int)threadIdx.x;

@@ -596,7 +596,11 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         // ---- the particles that changed cell: the general 4 x 4 x 4 window, every lane busy
         __syncthreads();
         const int ncross = s_ncross;
+#ifdef LPA_ABLATE_NO_PASS2   // diagnostic build (wrong physics): what the second pass costs
+        for (int i = threadIdx.x; i < 0; i += blockDim.x) {
+#else
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
+#endif
             const uint32_t o = (uint32_t)(begin + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), z = ld(sc.a[2], o), ux = ld(sc.a[3], o),
                          uy = ld(sc.a[4], o), uz = ld(sc.a[5], o), ig = ld(sc.a[6], o), w = ld(sc.a[7], o);
