@@ -327,23 +327,66 @@ __device__ __forceinline__ int node_index(int node, int n, int ng, int N, bool p
 // centre; evaluation order of interp_field_fast_3d (unified_pusher_3d.c:111-143): z outermost
 // The TSC weights are rebuilt from the three offsets here (5 flops per axis) instead of keeping six
 // weight triples alive across the whole gather: registers, not flops, bound this kernel.
+#ifndef LPA_GATHER3_BATCH
+#define LPA_GATHER3_BATCH 9
+#endif
 __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, int lz, double ddx, double ddy,
                                              double ddz) {
     double fx[3], fy[3], fz[3];
     tsc3(ddx, fx); tsc3(ddy, fy); tsc3(ddz, fz);
-    lds_ptr3 c = (lds_ptr3)(f + lx * EBSX + ly * EBSY + lz);
+#ifdef LPA_ABLATE3_NO_GATHER   // diagnostic build (wrong physics): the 27 FMAs stay, the 27 LDS reads go
+    const double c0 = 1e-3 * (lx + ly + lz);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         double pl = 0.0;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            int o = (j - 1) * EBSY + (k - 1);
-            pl += fy[j] * (fx[0] * c[o - EBSX] + fx[1] * c[o] + fx[2] * c[o + EBSX]);
-        }
+        for (int j = 0; j < 3; j++) pl += fy[j] * (fx[0] * c0 + fx[1] * (c0 + j) + fx[2] * (c0 + k));
         acc += fz[k] * pl;
     }
     return acc;
+#else
+    lds_ptr3 c = (lds_ptr3)(f + lx * EBSX + ly * EBSY + lz);
+    // the 3-D loop runs at 3 waves per SIMD: the reads of a batch are issued back to back and the arithmetic waits on
+    // them with counted lgkmcnt (LDS returns in order).  Left to itself the scheduler, short of registers, issued 1-2
+    // reads, waited for lgkmcnt(0), used them ... 108 exposed LDS latencies per particle.
+    double acc = 0.0;
+#if LPA_GATHER3_BATCH == 27
+    double v[3][3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int o = (j - 1) * EBSY + (k - 1);
+            v[k][j][0] = c[o - EBSX]; v[k][j][1] = c[o]; v[k][j][2] = c[o + EBSX];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double pl = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) pl += fy[j] * (fx[0] * v[k][j][0] + fx[1] * v[k][j][1] + fx[2] * v[k][j][2]);
+        acc += fz[k] * pl;
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double v[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int o = (j - 1) * EBSY + (k - 1);
+            v[j][0] = c[o - EBSX]; v[j][1] = c[o]; v[j][2] = c[o + EBSX];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double pl = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) pl += fy[j] * (fx[0] * v[j][0] + fx[1] * v[j][1] + fx[2] * v[j][2]);
+        acc += fz[k] * pl;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    return acc;
+#endif
 }
 
 // DEFER (as in the 2-D kernel): particles that change cell during the step park their advanced state (8
@@ -354,6 +397,11 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
 struct Scratch8 { double *a[8]; };
 __device__ __forceinline__ int clamp3(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
+// LPA_K13_PERSIST = N > 0: the kernel is launched with at most N workgroups per CU-count (256 x N) and every workgroup
+// walks the work blocks wb, wb + gridDim.x, ... instead of one workgroup per work block
+#ifndef LPA_K13_PERSIST
+#define LPA_K13_PERSIST 0
+#endif
 template <bool DEFER>
 __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
@@ -362,9 +410,15 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     __shared__ double s_j[4][R3N];
     __shared__ double s_eb[3 * EBN];     // see eb_base()
     __shared__ int s_ncross;
+#if LPA_K13_PERSIST
+    const int nb = *n_blocks;
+    for (int wb = (int)blockIdx.x; wb < nb; wb += (int)gridDim.x) {
+    if (wb != (int)blockIdx.x) __syncthreads();   // the flush of the previous block has read the images
+#endif
     // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
     // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
     // 4.51 ms per step, tools/exp_k13.sh with LPA_XCD_ORDER_3D) and idles XCDs in an edge / interior part launch
+#if !LPA_K13_PERSIST
     const int nb = *n_blocks, chunk = (nb + 7) >> 3;
 #ifdef LPA_XCD_ORDER_3D
     const int wb = part ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
@@ -372,12 +426,17 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     const int wb = (int)blockIdx.x;
 #endif
     if ((int)blockIdx.x >= 8 * chunk || wb >= nb) return;  // block-uniform
+#endif
     const int tile = blk_tile[wb];
     const int begin = blk_begin[wb], end = blk_end[wb];
     const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y, tx_ = tile / (tiles_z * tiles_y);
     if (part) {  // LPA_PART_EDGE / LPA_PART_INTERIOR: see lpa_push_deposit_tiled_part_2d
         const bool edge = tx_ < edge_cols || tx_ >= tiles_x - edge_cols;
+#if LPA_K13_PERSIST
+        if ((part == LPA_PART_EDGE) != edge) continue;  // block-uniform, before any barrier of this block
+#else
         if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform, before any barrier
+#endif
     }
     const int t0[3] = {tx_ * T3X, ty_ * T3Y, tz_ * T3Z};          // first node of the tile
     const int r0[3] = {t0[0] - H3, t0[1] - H3, t0[2] - H3};       // first node of the LDS region
@@ -402,6 +461,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     __syncthreads();
 
     const double inv_dx = k.inv_d[0], inv_dy = k.inv_d[1], inv_dz = k.inv_d[2];
+    [[maybe_unused]] double abl3v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // LPA_ABLATE3_* diagnostic builds (independent chains)
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
     auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
     // software pipeline: the eight attribute loads of the next iteration are in flight during this one
@@ -414,7 +474,11 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             nuz = ld(p.uz, o); nig = ld(p.ig, o); nw = ld(p.w, o);
         }
     }
+#ifdef LPA_ABLATE3_NO_LOOP   // diagnostic build (wrong physics): only the per-tile phases (zero, stage E/B, flush) run
+    for (int it = end; it < end; it += blockDim.x) {
+#else
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
+#endif
         const int ip = it + lane;
         bool valid = ip < end;
         double x = nx_, y = ny_, z = nz_, ux = nux, uy = nuy, uz = nuz, ig = nig, w = nw;
@@ -575,7 +639,11 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #ifdef LPA_ABLATE_NO_TAIL
                 on = i < 3 && j < 3 && kk < 3;
 #endif
+#ifdef LPA_ABLATE3_NO_ATOMICS   // diagnostic build (wrong physics): the arithmetic stays, the LDS atomics go
+                if (on) abl3v[(i * 9 + j * 3 + kk) & 7] += djx + (b0 + (i * R3Y + j) * R3ZS + kk);
+#else
                 if (on) atomicAdd(&s_j[0][b0 + (i * R3Y + j) * R3ZS + kk], djx);
+#endif
             },
             [&](int i, int j, int kk, double djy, double djz, double dr) {
                 bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
@@ -584,10 +652,14 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #endif
                 if (on) {
                     int o = b0 + (i * R3Y + j) * R3ZS + kk;
+#ifdef LPA_ABLATE3_NO_ATOMICS
+                    abl3v[(i * 9 + j * 3 + kk) & 7] += djy + djz + dr + o;
+#else
                     if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][o], djy);
                     if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][o], djz);
 #ifndef LPA_ABLATE_NO_RHO   // diagnostic build: what depositing rho costs (open items)
                     atomicAdd(&s_j[3][o], dr);
+#endif
 #endif
                 }
             });
@@ -635,6 +707,13 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         }
     }
     __syncthreads();
+#ifdef LPA_ABLATE3_NO_ATOMICS
+    {
+        double abl3 = 0.0;
+        for (int q = 0; q < 8; q++) abl3 += abl3v[q];
+        if (abl3 == 1.2345e-300) s_j[0][0] = abl3;  // keeps the ablated arithmetic alive
+    }
+#endif
     // flush: one FP64 global atomic per touched node and component, on the torus
     {
         double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
@@ -651,6 +730,9 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
             }
         }
     }
+#if LPA_K13_PERSIST
+    }
+#endif
 }
 
 static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
@@ -789,13 +871,17 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
         sc.a[c] = t->scratch[c];
         defer = defer && sc.a[c] != nullptr;
     }
+    unsigned grid = (unsigned)t->max_blocks;
+#if LPA_K13_PERSIST
+    if (grid > 256u * LPA_K13_PERSIST) grid = 256u * LPA_K13_PERSIST;
+#endif
     if (defer)
-        hipLaunchKernelGGL(k_push_deposit_tiled_3d<true>, dim3(t->max_blocks), dim3(K13_THREADS), 0,
+        hipLaunchKernelGGL(k_push_deposit_tiled_3d<true>, dim3(grid), dim3(K13_THREADS), 0,
                            (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
                            t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
                            part, t->tiles_x, edge_cols, sc);
     else
-        hipLaunchKernelGGL(k_push_deposit_tiled_3d<false>, dim3(t->max_blocks), dim3(K13_THREADS), 0,
+        hipLaunchKernelGGL(k_push_deposit_tiled_3d<false>, dim3(grid), dim3(K13_THREADS), 0,
                            (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
                            t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
                            part, t->tiles_x, edge_cols, sc);
