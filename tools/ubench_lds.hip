@@ -9,12 +9,13 @@
 constexpr int NDBL = 16384;   // 128 KB of doubles
 
 template <int MODE>
-__global__ void __launch_bounds__(1024) k(const int *__restrict__ idx, double *out, int iters, long long *cyc) {
+__global__ void __launch_bounds__(1024) k(const int *__restrict__ idx, double *out, int iters, long long *cyc, int every) {
     __shared__ double s[NDBL];
     for (int t = threadIdx.x; t < NDBL; t += blockDim.x) s[t] = MODE == 0 ? 0.0 : out[2048 + (t & 7)];   // run-time data: nothing to fold
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int a = idx[lane] + wave * 600;      // per-wave base: waves work on different regions (like different cells)
+    const bool active = (lane % every) == 0;   // exec-masked atomics: what a sparse wave instruction costs
     double acc = 0.0, acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
@@ -23,7 +24,7 @@ __global__ void __launch_bounds__(1024) k(const int *__restrict__ idx, double *o
 #pragma unroll
         for (int u = 0; u < 27; u++) {
             int o = MODE == 0 ? ai + (u / 9) * 240 + ((u / 3) % 3) * 24 + (u % 3) : ai + u * 300;   // reads: too far apart for ds_read2_b64
-            if (MODE == 0) atomicAdd(&s[o], 1.0);
+            if (MODE == 0) { if (active) atomicAdd(&s[o], 1.0); }
             else acc9[u % 9] += s[o];        // nine independent chains: the reads stay in flight
         }
     }
@@ -58,15 +59,18 @@ int main() {
     hipMalloc(&d_idx, 64 * 4); hipMalloc(&d_out, 8 * 4096); hipMalloc(&d_cyc, 8);
     const int iters = 200, nblk = pr.multiProcessorCount;
     for (int mode = 0; mode < 2; mode++)
+      for (int every : {1, 2, 4, 16, 64}) {
+        if (mode == 1 && every > 1) continue;
         for (int threads : {256, 768}) {
-            printf("== %s, %d threads per CU (27 ops per iteration, %d iterations)\n", mode == 0 ? "ds_add_f64" : "ds_read_b64", threads, iters);
+            if (every > 1 && threads == 256) continue;
+            printf("== %s, %d threads per CU, 1 lane in %d active (27 ops per iteration, %d iterations)\n", mode == 0 ? "ds_add_f64" : "ds_read_b64", threads, every, iters);
             for (auto &p : pats) {
                 hipMemcpy(d_idx, p.v.data(), 64 * 4, hipMemcpyHostToDevice);
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 for (int rep = 0; rep < 2; rep++) {
                     hipEventRecord(e0);
-                    if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(threads), 0, 0, d_idx, d_out, iters, d_cyc);
-                    else hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(threads), 0, 0, d_idx, d_out, iters, d_cyc);
+                    if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(threads), 0, 0, d_idx, d_out, iters, d_cyc, every);
+                    else hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(threads), 0, 0, d_idx, d_out, iters, d_cyc, every);
                     hipEventRecord(e1); hipEventSynchronize(e1);
                 }
                 float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -77,5 +81,6 @@ int main() {
                        p.name, ms, ns_per_op, ns_per_op * 2.4, (double)wc / ops);
             }
         }
+      }
     return 0;
 }
