@@ -6,12 +6,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[1] bench.py"; timeout -k 10 500 python3 $ROOT/bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "   exit $?"
-echo "[2] kernel stats (2-D)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2d -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/stats2d.log 2>&1; echo "   exit $?"
-echo "[3] kernel stats (3-D slab)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3d -- python3 $ROOT/tools/bench3d.py > $OUT/stats3d.log 2>&1; echo "   exit $?"
 cd $ROOT
-echo "[4] PMC passes"; BENCH_ARGS="--steps 4 --warmup 2" tools/prof_pmc.sh gpurun_out/prof_round/pmc
+echo "[0] PMC passes (first: bench.py quotes the traffic recorded for THESE sources)"; BENCH_ARGS="--steps 4 --warmup 2" tools/prof_pmc.sh gpurun_out/prof_round/pmc
 python3 tools/pmc_summary.py gpurun_out/prof_round/pmc k_push_deposit_tiled_2d > $OUT/pmc_k1.txt
 python3 tools/make_traffic_json.py gpurun_out/prof_round/pmc > $OUT/traffic.log 2>&1
 cp profiles/r02_k1_traffic.json $OUT/ 2>/dev/null
+cd /tmp
+echo "[1] bench.py"; timeout -k 10 500 python3 $ROOT/bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "   exit $?"
+echo "[2] kernel stats (2-D)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2d -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/stats2d.log 2>&1; echo "   exit $?"
+echo "[3] kernel stats (3-D slab)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3d -- python3 $ROOT/tools/bench3d.py > $OUT/stats3d.log 2>&1; echo "   exit $?"
 find $OUT -name "*kernel_stats.csv" | head
