@@ -22,10 +22,16 @@ import torch
 
 from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
+from .device import restore_device, to_host
 from .dist import SlabComm, exchange_faces
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 
 ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
+# the resident store is float64[NROWS3][capacity]: the eight attributes + the bit pattern of ParticlesBase._id
+# (`core/particles.py:50-51,91-116`: a uint64 viewed as float64), carried through the tile sort
+# (`core/sort/cpu3d.c:214-299` permutes every attribute), the migration message and the window shift
+ID_ROW = len(ATTRS3)
+NROWS3 = ID_ROW + 1
 SIDES3 = ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")
 
 
@@ -73,6 +79,22 @@ class DevicePML3D:
                     z = lambda: torch.zeros(cells, dtype=torch.float64, device=device)
                     self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
                                             psi_a=z(), psi_b=z()))
+        self._coef = {}
+
+    def __getstate__(self):
+        st = {k: v for k, v in self.__dict__.items() if k not in ("kappa", "_coef", "layers")}
+        st["device"] = str(self.device)
+        st["layers_host"] = [{**{k: v for k, v in l.items() if k not in ("psi_a", "psi_b")},
+                              "psi_a": to_host(l["psi_a"]), "psi_b": to_host(l["psi_b"])} for l in self.layers]
+        return st
+
+    def __setstate__(self, st):
+        layers = st.pop("layers_host")
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.kappa = {k: dev(v["kappa"]) for k, v in self.host.items()}
+        self.layers = [{**l, "psi_a": dev(l["psi_a"]), "psi_b": dev(l["psi_b"])} for l in layers]
         self._coef = {}
 
     def coef(self, key, dt, d):
@@ -153,6 +175,7 @@ class PicEngine3D:
                 self.alo[a] = t * self.d[a] - self.d[a] / 2
                 self.ahi[a] = (ntot[a] - 1 - t) * self.d[a] + self.d[a] / 2
         self.species = []
+        self._id_next = {}       # per species: ids issued by this rank so far (new_ids)
         self.eps0, self.mu0 = constants.EPSILON_0, constants.MU_0
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
         self._halo = None
@@ -168,6 +191,42 @@ class PicEngine3D:
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every launch of the
         # tiled push+deposit kernel on the stream it runs on
         self.kernel_events = None
+
+    # ---- restart (RestartDump, `callback/restart.py:88-107`) ------------------------------------------------
+    _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events")
+
+    def __getstate__(self):
+        """see PicEngine2D.__getstate__: fields and the slots in use of every store as host arrays, handles,
+        workspaces and tilings dropped (the first push after a load re-sorts)"""
+        torch.cuda.synchronize(self.device)
+        st = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+        st["device"], st["buf_host"] = str(self.device), to_host(self.buf)
+        st["species_host"] = [{"q": sp["q"], "m": sp["m"], "n": sp["n"], "capacity": int(sp["data"].shape[1]),
+                               "data": to_host(sp["data"][:, : sp["n"]])} for sp in self.species]
+        return st
+
+    def __setstate__(self, st):
+        buf, species = st.pop("buf_host"), st.pop("species_host")
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        self.L = lib()
+        self.buf = torch.from_numpy(buf).to(self.device)
+        g = _lib.lpa_grid()
+        g.nx, g.ny, g.nz, g.ng = *self.n, self.ng
+        g.dx, g.dy, g.dz = self.d
+        g.x0, g.y0, g.z0 = self.x0, 0.0, 0.0
+        for k, name in enumerate(FIELD_ATTRS):
+            setattr(g, name, self.buf[k].data_ptr())
+        self.c = g
+        self._halo, self._side, self._axes, self.kernel_events = None, None, {}, None
+        self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.species = []
+        for h in species:
+            data = torch.full((NROWS3, h["capacity"]), float("nan"), dtype=torch.float64, device=self.device)
+            data[:, : h["n"]] = torch.from_numpy(h["data"])
+            self.species.append({"q": h["q"], "m": h["m"], "data": data, "c": self._cstruct(data, h["n"]),
+                                 "n": h["n"], "n_sorted": 0, "alt": None, "tiling": None, "since": 1 << 30,
+                                 "ws": None})
 
     @property
     def stream(self):
@@ -187,21 +246,50 @@ class PicEngine3D:
         return self.migrate_capacity * 2 * max(self.sort_interval, 1) if self.comm.size > 1 else 0
 
     def add_species(self, q, m, host_particles, capacity=None):
-        """upload the live particles of one host bag (ParticlesBase-like with z); ``capacity`` = live
-        particles this rank must be able to hold (the arrival area is added)"""
-        live = ~host_particles.is_dead
+        """upload the live particles of one host bag (ParticlesBase-like with z, ``is_dead`` honoured: dead or
+        NaN-position slots are not stored -- dead = x NaN in the resident store); ``capacity`` = live particles
+        this rank must be able to hold (the arrival area is added).  ``_id`` travels when the bag has one."""
+        live = ~np.asarray(host_particles.is_dead, dtype=bool) & ~np.isnan(host_particles.x)
         n = int(live.sum())
         cap = max(int(capacity or n), n) + self.arrival_area()
-        data = torch.full((len(ATTRS3), max(cap, 1)), float("nan"), dtype=torch.float64, device=self.device)
+        data = torch.full((NROWS3, max(cap, 1)), float("nan"), dtype=torch.float64, device=self.device)
         if n:
-            data[:, :n] = torch.from_numpy(np.stack([getattr(host_particles, a)[live] for a in ATTRS3])).to(self.device)
-        return self.add_species_device(q, m, data, n)
+            data[:ID_ROW, :n] = torch.from_numpy(np.stack([getattr(host_particles, a)[live] for a in ATTRS3])).to(self.device)
+        ids = None
+        if n and getattr(host_particles, "_id", None) is not None:
+            ids = torch.from_numpy(np.ascontiguousarray(host_particles._id[live]).view(np.int64)).to(self.device)
+        return self.add_species_device(q, m, data, n, ids=ids)
 
-    def add_species_device(self, q, m, data, n):
-        """``data``: device tensor [8][capacity] in ATTRS3 order, the first ``n`` columns in use"""
+    def new_ids(self, ispec, k):
+        """``k`` fresh ids of species ``ispec`` (device int64): rank in the bits above 50 like the reference
+        (`core/particles.py:91-116`), below it ONE running count per rank and species (``PicEngine2D`` /
+        ``Simulation._next_ids`` use the same layout), so loading, injection and appends never collide"""
+        start = self._id_next.get(ispec, 0)
+        if start + k >= 1 << 50:
+            raise OverflowError("particle id counter exceeds 50 bits")
+        self._id_next[ispec] = start + int(k)
+        return torch.arange(start, start + int(k), dtype=torch.int64, device=self.device) + (self.comm.rank << 50)
+
+    def add_species_device(self, q, m, data, n, ids=None):
+        """``data``: device tensor [NROWS3][capacity] (ATTRS3 order + the id row), the first ``n`` columns in
+        use; an [8][capacity] tensor is accepted and gets its id row here.  ``ids`` (device int64[n]) overrides
+        the id row; without either the engine issues fresh ids (``new_ids``)."""
+        ispec = len(self.species)
+        if data.shape[0] == ID_ROW:
+            full = torch.empty((NROWS3, data.shape[1]), dtype=torch.float64, device=self.device)
+            full[:ID_ROW] = data
+            data, have_ids = full, False
+        elif data.shape[0] == NROWS3:
+            have_ids = True
+        else:
+            raise ValueError(f"particle data must have {ID_ROW} or {NROWS3} rows")
+        if ids is not None:
+            data[ID_ROW, :n] = ids.to(self.device).view(torch.float64)
+        elif not have_ids:
+            data[ID_ROW, :n] = self.new_ids(ispec, n).view(torch.float64)
         self.species.append({"q": float(q), "m": float(m), "data": data, "c": self._cstruct(data, n), "n": int(n),
                              "n_sorted": 0, "alt": None, "tiling": None, "since": 0, "ws": None})
-        return len(self.species) - 1
+        return ispec
 
     @staticmethod
     def _cstruct(data, n):
@@ -211,14 +299,23 @@ class PicEngine3D:
             setattr(p, a, data[k].data_ptr())
         for k in range(6):
             p.part_eb[k] = None
-        p.id, p.is_dead = None, None
+        p.id, p.is_dead = data[ID_ROW].data_ptr(), None
         return p
 
+    def ids(self, i):
+        """device int64 view of the id row of species ``i`` (slots [0, n))"""
+        sp = self.species[i]
+        return sp["data"][ID_ROW, : sp["n"]].view(torch.int64)
+
     def download_species(self, i):
+        """host arrays of the LIVE particles (device order): ATTRS3 + ``_id`` (float64 bit pattern, as in
+        ParticlesBase)"""
         sp = self.species[i]
         d = sp["data"][:, : sp["n"]]
         d = d[:, ~torch.isnan(d[0])].cpu().numpy()
-        return {a: d[k] for k, a in enumerate(ATTRS3)}
+        out = {a: d[k] for k, a in enumerate(ATTRS3)}
+        out["_id"] = np.ascontiguousarray(d[ID_ROW])
+        return out
 
     def _g(self):
         return C.byref(self.c)
@@ -545,7 +642,7 @@ class PicEngine3D:
             out = sp["data"][:, idx].contiguous()
             x[idx] = float("nan")
             k = int(got.item()) if self.comm.has_right else 0
-            inc = torch.empty((len(ATTRS3), k), dtype=torch.float64, device=self.device)
+            inc = torch.empty((NROWS3, k), dtype=torch.float64, device=self.device)
             dummy = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
             self.comm.exchange(out.reshape(-1) if out.numel() else dummy(), dummy(), dummy(),
                                inc.reshape(-1) if inc.numel() else dummy())
@@ -556,16 +653,25 @@ class PicEngine3D:
         for sp in self.species:
             sp["since"] = 1 << 30
 
-    def append_device(self, i, rows):
-        """append particles (device tensor [8][k], ATTRS3 order) behind the stored ones as loose particles
-        and force a re-sort; grows the store when needed"""
+    def append_device(self, i, rows, ids=None):
+        """append particles (device tensor [NROWS3][k]: ATTRS3 order + id row; or [8][k] with ``ids`` int64[k],
+        fresh ids when omitted) behind the stored ones as loose particles and force a re-sort; grows the store
+        when needed"""
         sp = self.species[i]
         k = int(rows.shape[1])
         if k == 0:
             return
+        if rows.shape[0] == ID_ROW:
+            full = torch.empty((NROWS3, k), dtype=torch.float64, device=self.device)
+            full[:ID_ROW] = rows
+            full[ID_ROW] = (ids if ids is not None else self.new_ids(i, k)).to(self.device).view(torch.float64)
+            rows = full
+        elif ids is not None:
+            rows = rows.clone()
+            rows[ID_ROW] = ids.to(self.device).view(torch.float64)
         cap = sp["data"].shape[1]
         if sp["n"] + k + self.arrival_area() > cap:
-            new = torch.full((len(ATTRS3), int(1.5 * (sp["n"] + k)) + self.arrival_area()), float("nan"),
+            new = torch.full((NROWS3, int(1.5 * (sp["n"] + k)) + self.arrival_area()), float("nan"),
                              dtype=torch.float64, device=self.device)
             new[:, : sp["n"]] = sp["data"][:, : sp["n"]]
             sp["data"], sp["alt"], sp["ws"], sp["tiling"], sp["n_sorted"] = new, None, None, None, 0

@@ -14,7 +14,7 @@ import torch
 
 from . import constants
 from .dist import SlabComm
-from .engine3d import ATTRS3, SIDES3, PicEngine3D
+from .engine3d import ATTRS3, NROWS3, SIDES3, PicEngine3D
 from .fields import FIELD_ATTRS, Fields3D, from_device_layout, to_device_layout
 from .particles import ParticlesBase
 from .simulation import MPIFacade, Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
@@ -153,20 +153,23 @@ class Simulation3D:
             blocks = []
             for p in mirrors:
                 org = (p.x0, p.y0, p.z0)
-                b = load_block_device(s, org, npp, d, self._seed(s, org), self.device)   # the 3-D store keeps no ids
+                b = load_block_device(s, org, npp, d, self._seed(s, org), self.device)
                 if b is not None:
                     blocks.append(b)
                 p.particles[s.ispec].initialize(0)     # the mirrors fill at the first download()
             n_tot = sum(b["x"].numel() for b in blocks)
             cap = int(n_tot * self.capacity_factor) + 65536 + self.engine.arrival_area()
-            data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device=self.device)
+            data = torch.full((NROWS3, cap), float("nan"), dtype=torch.float64, device=self.device)
             o = 0
             for b in blocks:
                 k = b["x"].numel()
                 for i, a in enumerate(ATTRS3):
                     data[i, o:o + k] = b[a]
                 o += k
-            self.engine.add_species_device(s.q, s.m, data, n_tot)
+            # ids: rank << 50 | one running count per rank and species (the 2-D rule, simulation.py:_next_ids;
+            # reference layout `core/particles.py:91-116`); loading, window injection and appends draw from it
+            ids = self.engine.new_ids(len(self.engine.species), n_tot)
+            self.engine.add_species_device(s.q, s.m, data, n_tot, ids=ids)
         self.maxwell = MaxwellSolver3D(self)
         self.pusher = [BorisPusher3D(self, i) for i in range(len(self.species))]
         self.sorter = [ParticleSort3D(self, i) for i in range(len(self.species))]
@@ -207,14 +210,19 @@ class Simulation3D:
                 for j in range(py):
                     org = (x_new, j * npp[1] * self.dy, k * npp[2] * self.dz)
                     b = load_block_device(s, org, npp, d, self._seed(s, org), self.device)
-                    if b is not None:
+                    if b is not None:     # fresh ids from the engine's per-rank counter
                         eng.append_device(s.ispec, torch.stack([b[a] for a in ATTRS3]))
 
     # ---- host mirrors <-> device ----------------------------------------------------------------------------
     def _upload_particles(self, ispec):
+        """mirrors -> device: live slots only (``is_dead`` or a NaN position = dead, the reference's rule
+        `unified_pusher_3d.c` strip test); ``_id`` travels, so a particle keeps its identity through any number
+        of mirror round trips"""
         sp = self.engine.species[ispec]
-        cols = [np.concatenate([getattr(p.particles[ispec], a)[~p.particles[ispec].is_dead] for p in self.patches])
-                for a in ATTRS3]
+        live = [~q.is_dead & ~np.isnan(q.x) & ~np.isnan(q.y) & ~np.isnan(q.z)
+                for q in (p.particles[ispec] for p in self.patches)]
+        cols = [np.concatenate([getattr(p.particles[ispec], a)[m] for p, m in zip(self.patches, live)])
+                for a in ATTRS3 + ("_id",)]
         n = cols[0].size
         if n > sp["data"].shape[1] - self.engine.arrival_area():
             raise RuntimeError("particle capacity exceeded by the host mirrors")
@@ -242,7 +250,7 @@ class Simulation3D:
                 sel = owner == k
                 q = p.particles[s.ispec]
                 q.initialize(int(sel.sum()))
-                for a in ATTRS3:
+                for a in ATTRS3 + ("_id",):
                     getattr(q, a)[:] = d[a][sel]
 
     def upload(self):
@@ -285,6 +293,11 @@ class Simulation3D:
         if host:
             self.upload()
 
+    def update_lists(self):
+        """the reference re-points its facades at the (possibly re-allocated) per-patch arrays
+        (`simulation/simulation.py:781-824`; called by RestartDump.load).  The facades here hold no array
+        pointers -- every call reads the engine's current stores -- so there is nothing to re-point."""
+
     def sync_currents(self):
         if not self.current_synced:
             self.patches.sync_currents()
@@ -311,6 +324,8 @@ class Simulation3D:
             nsteps = int(sim_time / self.dt) if sim_time is not None else \
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
         self._run_stage(table, "init")
+        # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
+        restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         eng = self.engine
         for self.istep in range(self.itime, self.itime + nsteps):
@@ -344,6 +359,9 @@ class Simulation3D:
             self.patches.sync_guard_fields(E)
             self._run_stage(table, "maxwell_2")
             self._run_stage(table, "end")
+            if restart_cb is not None and restart_cb._dump_requested:      # simulation.py:1124-1127
+                restart_cb._call(self)
+                return
             self.time += self.dt
             self.itime += 1
             if stop_callback():

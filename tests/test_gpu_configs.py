@@ -188,9 +188,12 @@ def _run_checked(sim, cbs, nsteps, every, ledger):
 
 
 def _unique_ids(eng):
-    for sp in eng.species:
-        s = sp.cset
-        ids = s.id[: sp.n][~torch.isnan(s.arr("x")[: sp.n])]
+    for i, sp in enumerate(eng.species):
+        if isinstance(sp, dict):          # PicEngine3D: id row of the [9][capacity] store
+            ids = eng.ids(i)[~torch.isnan(sp["data"][0, : sp["n"]])]
+        else:
+            s = sp.cset
+            ids = s.id[: sp.n][~torch.isnan(s.arr("x")[: sp.n])]
         if torch.unique(ids).numel() != ids.numel():
             return False
     return True
@@ -320,3 +323,4 @@ def test_c5_slab_full_size_two_species():
             checks += 1
     assert checks == 6
     assert 0 < live()[2] <= n_init
+    assert _unique_ids(eng)          # through 24 steps, 3 re-sorts and the absorption at six faces

@@ -216,6 +216,15 @@ def test_3d_tiled_equals_global_and_continuity_at_c5_slab_size():
     a, b = make(True), make(False)
     da, db = a.diagnostics(), b.diagnostics()
     assert da["nalive"][0] == n == db["nalive"][0]
+    # _id rides through the tile sort (core/sort/cpu3d.c:214-299 permutes every attribute, _id included): the sorted
+    # store holds the same particle under the same id as the never-sorted one
+    pa, pb = a.download_species(0), b.download_species(0)
+    ia, ib = pa["_id"].view(np.uint64), pb["_id"].view(np.uint64)
+    assert np.unique(ia).size == n and np.array_equal(np.sort(ia), np.sort(ib))
+    assert not np.array_equal(ia, ib)                      # the tiled store really was permuted
+    oa, ob = np.argsort(ia), np.argsort(ib)
+    for k in ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w"):
+        assert np.abs(pa[k][oa] - pb[k][ob]).max() <= 1e-9 * np.abs(pb[k]).max(), k
     assert da["charge"] == pytest.approx(n * q * w, rel=1e-12)
     assert da["field_energy"] == pytest.approx(db["field_energy"], rel=1e-10)
     assert da["kinetic"][0] == pytest.approx(db["kinetic"][0], rel=1e-12)
@@ -247,6 +256,33 @@ def test_guard_wrap_and_current_fold_3d_vs_reference_golden(golden):
         assert np.array_equal(eng.download_field(a), g["out_" + a]), a
     for a in ("jx", "jy", "jz", "rho"):
         assert_close(eng.download_field(a), g["out_" + a], 1e-14, what=a)
+
+
+def test_resident_engine_carries_ids_vs_reference_golden(golden):
+    """g14 through the RESIDENT engine: the reference's 3-D particle sync on a self-periodic patch keeps every live
+    particle under its ``_id`` and folds its coordinates into the box (core/patch/sync_particles_3d.c:484-...).  The
+    engine takes the bag (``is_dead`` honoured, ``_id`` uploaded), pushes with a vanishing dt (positions do not
+    move by a bit, the fused kernel's periodic fold still applies) and hands the particles back: compared per id,
+    bit exact, with the reference's output"""
+    from lambdapic_amd.particles import ParticlesBase
+    g = golden("g14_sync_particles_3d")
+    n3 = [int(g[k]) for k in ("nx", "ny", "nz")]
+    d3 = [float(g[k]) for k in ("dx", "dy", "dz")]
+    p = ParticlesBase(0, 0)
+    p.initialize(g["pin_x"].size)
+    for a in ("x", "y", "z", "ux", "w", "_id", "is_dead"):
+        getattr(p, a)[:] = g["pin_" + a]
+    p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2)
+    eng = PicEngine3D(*n3, *d3, 3, tiled=False)
+    eng.add_species(-oracle.E_CHARGE, oracle.M_E, p)
+    eng.push_deposit(0, 1e-40)
+    got = eng.download_species(0)
+    live_ref = ~g["pout_is_dead"]
+    assert got["x"].size == int(live_ref.sum())
+    o, r = np.argsort(got["_id"].view(np.uint64)), np.argsort(g["pout__id"][live_ref].view(np.uint64))
+    assert np.array_equal(got["_id"].view(np.uint64)[o], g["pout__id"][live_ref].view(np.uint64)[r])
+    for a in ("x", "y", "z", "ux", "w"):
+        assert np.array_equal(got[a][o], g["pout_" + a][live_ref][r]), a
 
 
 def test_periodic_fold_3d_vs_reference_golden(golden):

@@ -360,7 +360,9 @@ def _run_3d(rank, world, port, q):
     cap = 3 * k + eng.arrival_area()
     data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device="cuda:0")
     data[:, :k] = torch.from_numpy(np.concatenate([pos[:, mine], u[:, mine], ig[None, mine], w[None, mine]])).cuda()
-    eng.add_species_device(-1.602176634e-19, 9.1093837139e-31, data, k)
+    # _id = the particle's index in the global arrays: the same particle has the same id whatever the decomposition
+    eng.add_species_device(-1.602176634e-19, 9.1093837139e-31, data, k,
+                           ids=torch.from_numpy(np.nonzero(mine)[0].astype(np.int64)))
     trace = []
     for _ in range(14):
         eng.step(dt)
@@ -368,6 +370,10 @@ def _run_3d(rank, world, port, q):
         trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
     sl = (slice(3, 3 + nx), slice(3, 3 + ny), slice(3, 3 + nz))
     fields = {a: eng.view(a)[sl].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    got = eng.download_species(0)
+    fields["part_id"] = got["_id"].view(np.int64).astype(np.float64)
+    for a in ("x", "y", "z", "ux", "uy", "uz"):
+        fields["part_" + a] = got[a]
     # E and B guards in ONE call (which = 3): six components per face message
     eb = ("ex", "ey", "ez", "bx", "by", "bz")
     for a in eb:
@@ -411,10 +417,19 @@ def test_3d_slabs_match_single_rank():
     np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-12)
     assert np.abs(t2[:, 1] - t1[:, 1]).max() <= 1e-12 * 8192 * 1e27 * 4e-8 * 5e-8 * 6e-8 / 4 * 1.6e-19
     for a in f1:
-        if a.startswith("pad_"):
+        if a.startswith("pad_") or a.startswith("part_"):
             continue
         scale = np.abs(f1[a]).max()
         assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * scale, a
+    # particle identity through 14 steps of slab crossings, box wraps and 4 re-sorts (the reference carries _id in
+    # its migration payload, core/mpi/sync_particles_3d.c, and through its sort, core/sort/cpu3d.c:214-299):
+    # every id exactly once over the two ranks, and the same particle under it as in the single-rank run
+    n = 16 * 8 * 16 * 4
+    for f in (f1, f2):
+        assert np.array_equal(np.sort(f["part_id"]), np.arange(n))
+    o1, o2 = np.argsort(f1["part_id"]), np.argsort(f2["part_id"])
+    for a, scale in (("x", 16 * 4e-8), ("y", 8 * 5e-8), ("z", 16 * 6e-8), ("ux", 1.0), ("uy", 1.0), ("uz", 1.0)):
+        assert np.abs(f2["part_" + a][o2] - f1["part_" + a][o1]).max() <= 1e-9 * scale, a
     for f, world in ((f1, 1), (f2, 2)):                 # x guard planes == the periodic neighbours' interior edges
         nxl = 16 // world
         for a in ("ex", "ey", "ez", "bx", "by", "bz"):

@@ -78,6 +78,45 @@ def test_laser_target_3d_through_the_callback_api():
     assert d2["kinetic"][0] == pytest.approx(d["kinetic"][0], rel=1e-9)
 
 
+def test_mirror_round_trip_is_lossless_and_keeps_ids():
+    """download -> upload through the 3-D patch mirrors must not change the device state, and a particle keeps its
+    ``_id`` through it (`core/particles.py:63-67`: _id is one of the 15 attributes callbacks see; a tracking callback
+    must find the same particle under the same id at every download)"""
+    sim = _sim(npatch_x=2, npatch_y=1, npatch_z=2)
+    sim.run(6)
+    eng = sim.engine
+
+    def by_id(i):
+        d = eng.download_species(i)
+        o = np.argsort(d["_id"].view(np.uint64))
+        return {k: v[o] for k, v in d.items()}
+
+    before = [by_id(i) for i in range(2)]
+    diag0, ex0 = eng.diagnostics(), eng.view("ex").clone()
+    for b in before:
+        ids = b["_id"].view(np.uint64)
+        assert ids.size > 1000 and np.unique(ids).size == ids.size
+    sim.download()
+    seen = np.concatenate([p.particles[0].id for p in sim.patches])           # what a callback sees
+    assert np.array_equal(np.sort(seen), before[0]["_id"].view(np.uint64))
+    sim.upload()
+    diag1 = eng.diagnostics()
+    # (the energy is an atomic sum: equal to an ulp; the arrays themselves are compared bit for bit)
+    assert diag0["field_energy"] == pytest.approx(diag1["field_energy"], rel=1e-14) and diag0["nalive"] == diag1["nalive"]
+    assert (eng.view("ex") - ex0).abs().max().item() == 0.0
+    for i in range(2):
+        after = by_id(i)
+        for k in before[i]:
+            assert np.array_equal(after[k].view(np.uint64), before[i][k].view(np.uint64)), (i, k)
+    sim.run(5)                   # sorts (interval 4) and pushes: ids stay attached
+    sim.download()
+    sim.upload()
+    sim.run(1)
+    for i in range(2):
+        assert np.array_equal(by_id(i)["_id"].view(np.uint64), before[i]["_id"].view(np.uint64))
+    assert sim.itime == 12
+
+
 def test_host_callback_writes_reach_the_device():
     sim = _sim()
     sim.initialize()
