@@ -29,6 +29,22 @@ def current_stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- restart support (RestartDump, `callback/restart.py:13-160`) ---------------------------------------------
+# Device state pickles as HOST arrays of exactly the slots in use (never as torch views: a view would drag its whole
+# storage along), ctypes structs / library handles / streams / process groups are dropped and rebuilt on load.
+# ``RESTORE_DEVICE`` (set by ``RestartDump.load(..., device=...)``) overrides the device a checkpoint was written
+# from -- a restarted rank need not sit on the same GPU index.
+RESTORE_DEVICE = None
+
+
+def restore_device(saved) -> torch.device:
+    return torch.device(RESTORE_DEVICE if RESTORE_DEVICE is not None else saved)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy().copy()
+
+
 class DeviceGrid2D:
     """One rank's slab of the Yee grid in HBM."""
 
@@ -48,6 +64,24 @@ class DeviceGrid2D:
 
     def view(self, name) -> torch.Tensor:
         return self.buf[FIELD_ATTRS.index(name)]
+
+    def __getstate__(self):
+        st = {k: v for k, v in self.__dict__.items() if k not in ("buf", "c")}
+        st["device"], st["buf_host"] = str(self.device), to_host(self.buf)
+        return st
+
+    def __setstate__(self, st):
+        buf = st.pop("buf_host")
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        self.buf = torch.from_numpy(buf).to(self.device)
+        g = _lib.lpa_grid()
+        g.nx, g.ny, g.nz, g.ng = self.nx, self.ny, 1, self.ng
+        g.dx, g.dy, g.dz = self.dx, self.dy, 0.0
+        g.x0, g.y0, g.z0 = self.x0, self.y0, 0.0
+        for k, name in enumerate(FIELD_ATTRS):
+            setattr(g, name, self.buf[k].data_ptr())
+        self.c = g
 
     # ---- host mirrors ---------------------------------------------------------------------------
     def upload(self, name, wrapped: np.ndarray):
@@ -172,6 +206,27 @@ class DeviceParticles:
             s.arr(a)[:n].copy_(torch.from_numpy(np.concatenate(cols[a])))
         s.id[:n].copy_(torch.from_numpy(np.concatenate(ids)))
         self.n, self.n_sorted, self.tiling = n, 0, None
+
+    def __getstate__(self):
+        """slots [0, n) of the current set as host arrays (dead slots included: x = NaN marks them); the tile
+        order is not kept -- the first push after a load re-sorts, like the first push of a run"""
+        st = {k: v for k, v in self.__dict__.items() if k not in ("sets", "tiling", "device")}
+        s = self.cset
+        st.update(device=str(self.device), names=list(s.names), data_host=to_host(s.data[:, : self.n]),
+                  id_host=to_host(s.id[: self.n]))
+        return st
+
+    def __setstate__(self, st):
+        data, ids, names = st.pop("data_host"), st.pop("id_host"), st.pop("names")
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        s = ParticleSet(self.capacity, self.device, self.with_eb)
+        assert s.names == names
+        s.data[:, : self.n].copy_(torch.from_numpy(data))
+        s.id[: self.n].copy_(torch.from_numpy(ids))
+        self.sets, self.cur = [s, None], 0
+        self.n_sorted, self.tiling = 0, None
+        self.steps_since_sort = 1 << 30          # forces the sort before the next tiled push
 
     def download(self):
         """dict of host arrays of the LIVE particles (order = device order)"""

@@ -32,6 +32,28 @@ class SlabComm:
         self.left = (self.rank - 1) % self.size if (periodic or self.rank > 0) else -1
         self.right = (self.rank + 1) % self.size if (periodic or self.rank < self.size - 1) else -1
 
+    def __getstate__(self):
+        """process groups do not pickle (the reference drops and re-Dups its communicators the same way,
+        `core/mpi/mpi_manager.py:35-46`): a restored communicator binds to the default group of the process that
+        loads it; ``rebind`` attaches other groups (e.g. an RCCL group for the face messages)"""
+        st = self.__dict__.copy()
+        st["group"] = st["p2p_group"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        if self.size > 1:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError(f"checkpoint of rank {self.rank} of {self.size}: initialise torch.distributed "
+                                   "with the same world size before loading it")
+            if dist.get_world_size() != self.size or dist.get_rank() != self.rank:
+                raise RuntimeError(f"checkpoint belongs to rank {self.rank} of {self.size}, this process is rank "
+                                   f"{dist.get_rank()} of {dist.get_world_size()}")
+
+    def rebind(self, group=None, p2p_group=None):
+        self.group = group
+        self.p2p_group = p2p_group if p2p_group is not None else group
+
     @property
     def has_left(self):
         return self.size > 1 and self.left >= 0

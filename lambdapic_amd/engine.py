@@ -28,7 +28,7 @@ import torch
 
 from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
-from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr
+from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr, restore_device, to_host
 from .dist import SlabComm, exchange_faces
 
 
@@ -76,6 +76,22 @@ class DevicePML2D:
                     z = lambda: torch.zeros((s1 - s0) * nt, dtype=torch.float64, device=device)
                     self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
                                             psi_a=z(), psi_b=z()))
+        self._coef = {}
+
+    def __getstate__(self):
+        st = {k: v for k, v in self.__dict__.items() if k not in ("kappa", "_coef", "layers")}
+        st["device"] = str(self.device)
+        st["layers_host"] = [{**{k: v for k, v in l.items() if k not in ("psi_a", "psi_b")},
+                              "psi_a": to_host(l["psi_a"]), "psi_b": to_host(l["psi_b"])} for l in self.layers]
+        return st
+
+    def __setstate__(self, st):
+        layers = st.pop("layers_host")
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.kappa = {k: dev(v["kappa"]) for k, v in self.host.items()}
+        self.layers = [{**l, "psi_a": dev(l["psi_a"]), "psi_b": dev(l["psi_b"])} for l in layers]
         self._coef = {}
 
     def coef(self, key, dt, d):
@@ -172,6 +188,25 @@ class PicEngine2D:
         # the fused kernel stores the gathered E/B per particle (the reference's ex_part..bz_part side
         # effect, +48 B/particle) only when asked: callbacks that read them set this
         self.write_part_eb = False
+
+    # ---- restart (RestartDump, `callback/restart.py:88-107`: the reference pickles the whole Simulation) ----
+    _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events")
+
+    def __getstate__(self):
+        """everything but handles and scratch: the library handle, sort workspaces (and with them the tilings),
+        halo buffers, the side stream and cached ctypes descriptors are rebuilt on load; the grid, the particle
+        stores and the CPML layers pickle as host arrays (device.py)"""
+        torch.cuda.synchronize(self.device)
+        st = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+        st["device"] = str(self.device)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.device = restore_device(st["device"])
+        self.L = lib()
+        self._ws, self._halo, self._side, self._axes, self.kernel_events = {}, None, None, {}, None
+        self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
 
     # ---------------------------------------------------------------------------------------------
     @property

@@ -198,6 +198,8 @@ class DevicePatches:
         return iter(self._m)
 
     def __getattr__(self, name):       # nx, ny, dx, dy, n_guard, npatches, xmin_global, ...
+        if name.startswith("_"):       # (un)pickling probes dunder / private names before _m exists
+            raise AttributeError(name)
         return getattr(self._m, name)
 
     def sync_guard_fields(self, attrs=("ex", "ey", "ez", "bx", "by", "bz")):
@@ -550,6 +552,11 @@ class Simulation:
         if host_cbs:
             self.upload()
 
+    def update_lists(self):
+        """the reference re-points its facades at the (possibly re-allocated) per-patch arrays
+        (`simulation/simulation.py:781-824`; called by RestartDump.load).  The facades here hold no array
+        pointers -- every call reads the engine's current stores -- so there is nothing to re-point."""
+
     def sync_currents(self):
         if not self.current_synced:
             self.patches.sync_currents()
@@ -579,6 +586,8 @@ class Simulation:
         # host callbacks may read ex_part..bz_part
         self.engine.write_part_eb = any(not getattr(cb, "device_native", False) for cb in callbacks or [])
         self._run_stage(table, "init")
+        # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
+        restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         for self.istep in range(self.itime, self.itime + nsteps):
@@ -628,6 +637,9 @@ class Simulation:
             self.patches.sync_guard_fields(E)
             self._run_stage(table, "maxwell_2")
             self._run_stage(table, "end")
+            if restart_cb is not None and restart_cb._dump_requested:      # simulation.py:1124-1127
+                restart_cb._call(self)
+                return
             self.time += self.dt
             self.itime += 1
             if stop_callback():
