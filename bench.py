@@ -294,6 +294,7 @@ def extra_c3(steps=400, warm=160):
                         "GaussianLaser2D a0=10, tile sort every 20 steps, moving window at c (Simulation stage loop)",
             "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": ms, "steps": steps,
             "alive": int(alive), "window_shifts": int(getattr(sim, "window_shifts", 0)),
+            "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage.items()},
             "roofline": {"bound": "hbm", "scope": "step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "algorithmic_bytes_per_step": b_fields + b_k1,
@@ -339,7 +340,7 @@ def extra_c5(steps=40, warm=12):
                         "e- + p 8 ppc each for x > 1 um, CPML on 6 faces, GaussianLaser3D a0=10, tile sort every 10 "
                         "steps (Simulation3D stage loop)",
             "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": ms, "steps": steps,
-            "alive": int(alive),
+            "alive": int(alive), "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
             "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_3d", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch_set": b_k1,
                          "achieved": b_k1 / (k_ms * 1e-3) / 1e9, "frac": b_k1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -388,6 +389,10 @@ def main():
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
+    ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
+                    help="rho between two sorts: advanced with the discrete continuity equation (default; the fused "
+                         "kernel skips its rho atomics, a real deposit re-anchors rho on every sort step) or deposited "
+                         "in every step like the reference's kernel")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -436,9 +441,16 @@ def main():
     comm = SlabComm(None, p2p_group=p2p)
     assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
-    eng, dt, n_local = build_engine(args, comm, device)
+    if args.order == "padded" or args.reseat:
+        # the cooperative deposit / the in-kernel re-seating live in the variants build only (A/B use)
+        from lambdapic_amd import _lib
+        with _lib.use_variants():
+            eng, dt, n_local = build_engine(args, comm, device)
+    else:
+        eng, dt, n_local = build_engine(args, comm, device)
     eng.defer_crossers = not args.no_defer
     eng.reseat = args.reseat
+    eng.rho_continuity = args.rho == "continuity"
     for _ in range(args.warmup):
         eng.step(dt)
     # timed region: EXACTLY --steps steps between barrier + synchronize on both sides
@@ -479,7 +491,12 @@ def main():
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
                    "comm": comm_note,
-                   "part_eb_writeback": False},
+                   "part_eb_writeback": False,
+                   # rho between two sorts (lambdapic_amd/rho.py): "continuity" = advanced from the folded currents,
+                   # re-anchored by a real deposit on every sort step; "deposited" = the reference's kernel
+                   "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
+                   "dead_particles": "x = NaN (the resident store has no is_dead array; the 105 B of SURVEY 8(d) "
+                                     "count one byte for it)"},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,

@@ -199,6 +199,24 @@ int lpa_laser_inject_3d(const lpa_grid *g, int laserpos, double dt, double eps0,
 /* ---- zero jx jy jz rho including guards (replaces reset_current_cpu_2d/3d,
  *      core/current/cpu2d.c:19-72, cpu3d.c:185-240) */
 int lpa_reset_current(const lpa_grid *g, void *stream);
+/* the same for jx jy jz only: rho persists between steps when it is advanced by lpa_rho_continuity */
+int lpa_reset_j(const lpa_grid *g, void *stream);
+
+/* ---- rho from the discrete continuity equation (companion of LPA_PUSH_NO_RHO; 2-D when g->nz <= 1).
+ *      lpa_rho_continuity: rho -= dt * (D-x jx + D-y jy [+ D-z jz]) with backward differences, AFTER the currents
+ *        were folded (lpa_current_fold / halo exchange).  Per axis: bit set in `periodic_axes` = folded inside this
+ *        slab: interior nodes only, node 0 takes node n-1 as its lower neighbour; x with split_x != 0 = x is cut
+ *        into slabs: interior nodes only, node 0 takes jx_left_plane[NY(*NZ)] (the left neighbour's folded jx at its
+ *        node nx-1; NULL = no left neighbour: the own guard plane); any other axis is open: every node of the padded
+ *        array, on its torus -- where the deposit itself lands (core/utils/cutils.h:19-26).
+ *      lpa_rho_absorbed: subtract from rho what the particles listed by a LPA_PUSH_NO_RHO kernel (absorbed at an
+ *        open face, mark_out_of_bound_as_dead, core/patch/sync_particles_2d.c:185-202) had deposited there:
+ *        entry = {x1, y1, z1 (deposit end point in cells from node 0), q w / cell volume}; runs before the fold of
+ *        the step after the absorption (the reference's rho of the absorbing step still contains the particle);
+ *        count[0] is consumed (reset to 0), entries beyond `capacity` are added to count[1]. */
+int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axes, int split_x, const double *jx_left_plane,
+                       void *stream);
+int lpa_rho_absorbed(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity, void *stream);
 
 /* ---- periodic guard handling inside one slab (replaces sync_guard_fields_2d and
  *      sync_currents_2d with a self-neighbour table, core/patch/sync_fields2d.c:150-255,43-148).
@@ -248,10 +266,26 @@ typedef struct {
                                   outside [alo, ahi] on that axis after the deposit -- the open / PML
                                   edge rule of mark_out_of_bound_as_dead
                                   (core/patch/sync_particles_2d.c:185-202, bounds core/patch/patch.py:105-148) */
+    int32_t flags;             /* LPA_PUSH_* (0 = the reference's kernel: rho deposited with the currents) */
     double lo[3], hi[3];       /* global particle box: lo = -d/2, hi = L - d/2 */
     double alo[3], ahi[3];     /* absorption bounds (only read where the absorb bit is set) */
+    /* optional (NULL = off; required by LPA_PUSH_NO_RHO when a face absorbs): the particles the kernel absorbs are
+     * appended here (see lpa_rho_absorbed) -- in real-deposit steps too, since the NEXT step may carry rho over;
+     * entries are four doubles each, absorbed_count = uint32[2] {entries, entries that did not fit}, device memory */
+    double *absorbed;
+    uint32_t *absorbed_count;
+    int64_t absorbed_capacity;
 } lpa_push_params;
 #define LPA_ABSORB_X 16
+/* LPA_PUSH_NO_RHO: the fused kernels deposit jx jy jz only.  Esirkepov's deposit satisfies the discrete continuity
+ * equation per particle and node, (rho1 - rho0) / dt + D-x jx + D-y jy + D-z jz = 0 with backward differences
+ * (current/current_deposit.h:185-268,333-440 by construction of the scheme; asserted per node in the tests), so the
+ * caller advances rho with lpa_rho_continuity from the folded currents instead of paying a third (2-D) / a quarter
+ * (3-D) of the LDS atomics for it.  rho then equals the deposited one up to rounding as long as every particle that
+ * contributed to the old rho also contributes its current: the caller re-deposits rho for real (flags = 0, after
+ * lpa_reset_current) whenever particles appear or vanish outside the kernel, and the kernel reports the particles it
+ * absorbs at open faces itself (`absorbed`), whose charge lpa_rho_absorbed takes out of rho before the next update. */
+#define LPA_PUSH_NO_RHO 1
 
 int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                         int64_t first, int64_t count, void *stream);

@@ -24,6 +24,7 @@ LPA_MIG_NATTR = 9
 LPA_HALO_PACK_GUARD_SRC, LPA_HALO_UNPACK_GUARD, LPA_HALO_PACK_CURRENT, LPA_HALO_UNPACK_CURRENT = 0, 1, 2, 3
 LPA_PART_ALL, LPA_PART_EDGE, LPA_PART_INTERIOR = 0, 1, 2
 LPA_ABSORB_X = 16
+LPA_PUSH_NO_RHO = 1
 
 
 class LpaError(RuntimeError):
@@ -61,9 +62,10 @@ class lpa_cpml_axis(C.Structure):
 
 
 class lpa_push_params(C.Structure):
-    _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32),
+    _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32), ("flags", C.c_int32),
                 ("lo", C.c_double * 3), ("hi", C.c_double * 3),
-                ("alo", C.c_double * 3), ("ahi", C.c_double * 3)]
+                ("alo", C.c_double * 3), ("ahi", C.c_double * 3),
+                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64)]
 
 
 
@@ -97,6 +99,9 @@ SIGNATURES = {
     "lpa_cpml_psi_3d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "lpa_laser_inject_3d": (_i, [_G, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "lpa_reset_current": (_i, [_G, _vp]),
+    "lpa_reset_j": (_i, [_G, _vp]),
+    "lpa_rho_continuity": (_i, [_G, _d, _i, _i, _vp, _vp]),
+    "lpa_rho_absorbed": (_i, [_G, _vp, _vp, _i64, _vp]),
     "lpa_guard_wrap": (_i, [_G, _i, _i, _vp]),
     "lpa_current_fold": (_i, [_G, _i, _vp]),
     "lpa_halo_pack_guard_src": (_i, [_G, _i, _i, _vp, _vp]),
@@ -144,6 +149,39 @@ SIGNATURES = {
 }
 
 _LIB = None
+_VARIANTS = None
+VARIANTS_PATH = HERE / "csrc" / "build" / "liblambdapic_amd_variants.so"
+
+
+def _bind(path):
+    L = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise LpaError(f"{path} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+class use_variants:
+    """context manager: inside it ``lib()`` returns the VARIANTS build of the library (same ABI, plus the three
+    measured-slower deposit paths of the 2-D tiled kernel: wave reduce-scatter for CELL_MAJOR stores, in-kernel
+    re-seating, cooperative deposit on PADDED stores).  Engines created inside keep that handle.  Test / A-B use only."""
+
+    def __enter__(self):
+        global _LIB, _VARIANTS
+        if _VARIANTS is None:
+            if not VARIANTS_PATH.exists():
+                raise LpaError(f"{VARIANTS_PATH} not built: run `python -m lambdapic_amd.build`")
+            _VARIANTS = _bind(VARIANTS_PATH)
+        self._saved, _LIB = _LIB, _VARIANTS
+        return _VARIANTS
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._saved
+        return False
 
 
 def lib():
@@ -154,15 +192,8 @@ def lib():
     if not LIB_PATH.exists():
         raise LpaError(f"{LIB_PATH} not built: run `python -m lambdapic_amd.build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    L = C.CDLL(str(LIB_PATH))
-    for name, (res, args) in SIGNATURES.items():
-        try:
-            fn = getattr(L, name)
-        except AttributeError as e:
-            raise LpaError(f"{LIB_PATH} does not export {name}") from e
-        fn.restype, fn.argtypes = res, args
-    _LIB = L
-    return L
+    _LIB = _bind(LIB_PATH)
+    return _LIB
 
 
 def check(status: int, what: str = ""):

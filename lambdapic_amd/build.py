@@ -14,7 +14,8 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "liblambdapic_amd.so"
-SOURCES = ["lpa_fields.hip", "lpa_particles.hip", "lpa_particles3d.hip", "lpa_sort.hip", "lpa_patches.hip"]
+SOURCES = ["lpa_fields.hip", "lpa_particles.hip", "lpa_particles3d.hip", "lpa_sort.hip", "lpa_patches.hip",
+           "lpa_rho.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 
@@ -34,6 +35,19 @@ def build_variant(name: str, defines) -> Path:
            "-o", str(out)]
     subprocess.run(cmd, check=True)
     return out
+
+
+VARIANTS_LIB = CSRC / "build" / "liblambdapic_amd_variants.so"
+
+
+def build_variants(force: bool = False) -> Path:
+    """the same library with the three measured-slower deposit paths of the 2-D tiled kernel compiled in
+    (-DLPA_K1_VARIANTS=1: wave reduce-scatter, in-kernel re-seating, cooperative deposit); loaded by the tests that
+    pin those paths (``_lib.use_variants()``) and by ``bench.py --order padded / --reseat``, never by the product"""
+    srcs = [CSRC / s for s in SOURCES] + list(CSRC.glob("*.hpp")) + [HERE.parent / "include" / "lambdapic_amd.h"]
+    if not force and VARIANTS_LIB.exists() and VARIANTS_LIB.stat().st_mtime >= max(f.stat().st_mtime for f in srcs):
+        return VARIANTS_LIB
+    return build_variant("variants", ["LPA_K1_VARIANTS=1"])
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
@@ -65,3 +79,4 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))
+    print(build_variants(force="--force" in sys.argv))

@@ -7,11 +7,12 @@
 //  K1-tiled   particles binned by 8x32-cell tiles (lpa_sort.hip).  One workgroup per work block of
 //             a tile: the tile's E/B (+4-node halo) are staged once in LDS, particles stream through
 //             in SoA order (fully coalesced 512-B wave loads), J/rho accumulate in an LDS tile with
-//             ds_add_f64 and are flushed with one global atomic per touched cell.  Two deposit forms,
-//             chosen by the order the sort produced (LPA_ORDER_*): STRIPED stores put the lanes of a
-//             half-wave in consecutive y-cells (conflict-free LDS atomics and gather reads);
-//             CELL_MAJOR stores put a wave in one cell and sum the deposit windows across the wave in
-//             registers (permlane-swap / DPP reduce-scatter) before one LDS atomic per lane.
+//             ds_add_f64 and are flushed with one global atomic per touched cell.  The product build has ONE
+//             deposit path: per-lane LDS atomics, conflict free on STRIPED stores (the lanes of a half-wave sit
+//             in consecutive y-cells), cell-crossers deposited in a dense second pass.  Three measured-slower
+//             alternatives are compiled only with -DLPA_K1_VARIANTS=1 into
+//             csrc/build/liblambdapic_amd_variants.so: the wave reduce-scatter deposit of CELL_MAJOR stores, the
+//             in-kernel re-seating (slot classes) and the cooperative deposit of PADDED stores.
 //
 // Restates unified_boris_pusher_cpu_2d (core/pusher/unified/unified_pusher_2d.c:157-365).
 #include "lpa_common.hpp"
@@ -22,7 +23,25 @@ struct PushK {
     int wrap;
     double lo[3], hi[3], alo[3], ahi[3];
     DepK dep;      // deposit factors of the fused (FAST) grouping; valid when the grid was given to make_pushk
+    // LPA_PUSH_NO_RHO: rho is not deposited (lpa_rho_continuity advances it); `absorbed` (optional, any mode): the
+    // particles absorbed at an open face are reported there (lpa_rho_absorbed), see lpa_particles3d.hip
+    int flags;
+    double *absorbed;
+    uint32_t *absorbed_count;
+    long absorbed_cap;
 };
+
+#ifndef LPA_K1_VARIANTS
+#define LPA_K1_VARIANTS 0
+#endif
+
+__device__ __forceinline__ void report_absorbed_2d(const PushK &k, double o1x, double o1y, double cd) {
+    const uint32_t slot = atomicAdd(k.absorbed_count, 1u);
+    if ((long)slot < k.absorbed_cap) {
+        double *e = k.absorbed + 4 * (long)slot;
+        e[0] = o1x; e[1] = o1y; e[2] = 0.0; e[3] = cd;
+    }
+}
 
 static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
     PushK k;
@@ -37,6 +56,8 @@ static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) 
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
     k.cdt_half = LPA_C * 0.5 * pp->dt;
     k.wrap = pp->wrap;
+    k.flags = pp->flags;
+    k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
     for (int a = 0; a < 3; a++) {
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
         k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
@@ -46,13 +67,14 @@ static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) 
 
 // periodic fold and / or absorption of the advanced position (what sync_particles does after the
 // deposit: core/patch/sync_particles_2d.c:168-202); an absorbed particle becomes a dead slot (NaN)
-__device__ __forceinline__ void finish_position_2d(double &x, double &y, const PushK &k) {
+__device__ __forceinline__ bool finish_position_2d(double &x, double &y, const PushK &k) {
     double L;
     if (k.wrap & 1) { L = k.hi[0] - k.lo[0]; if (x > k.hi[0]) x -= L; if (x < k.lo[0]) x += L; }
     if (k.wrap & 2) { L = k.hi[1] - k.lo[1]; if (y > k.hi[1]) y -= L; if (y < k.lo[1]) y += L; }
     bool dead = ((k.wrap & LPA_ABSORB_X) && (x < k.alo[0] || x > k.ahi[0])) ||
                 ((k.wrap & (LPA_ABSORB_X << 1)) && (y < k.alo[1] || y > k.ahi[1]));
     if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; }
+    return dead;
 }
 
 // periodic fold of a coordinate into [lo, hi] (sync_particles_2d.c:168-182 with a self neighbour)
@@ -105,7 +127,7 @@ __device__ __forceinline__ void gather_global_2d(const GridV &g, double xo, doub
 template <bool FAST>
 __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, double y, double ux,
                                                   double uy, double uz, double ig, double w, double q,
-                                                  double dt, const DepK *pre = nullptr) {
+                                                  double dt, const DepK *pre = nullptr, bool rho = true) {
     double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
     AxisW ax, ay;
     axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
@@ -122,7 +144,7 @@ __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, doub
                            if (djx != 0.0) atomicAdd(&g.jx[idx], djx);
                            if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
                            if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
-                           if (drho != 0.0) atomicAdd(&g.rho[idx], drho);
+                           if (rho && drho != 0.0) atomicAdd(&g.rho[idx], drho);
                        }, pre);
 }
 
@@ -142,8 +164,11 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     boris(ux, uy, uz, ig, eb[0], eb[1], eb[2], eb[3], eb[4], eb[5], k.efactor, k.bfactor);
     x += k.cdt_half * ig * ux;
     y += k.cdt_half * ig * uy;
-    deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt, &k.dep);
-    finish_position_2d(x, y, k);
+    deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt, &k.dep, !(k.flags & LPA_PUSH_NO_RHO));
+    const double xe = x, ye = y;
+    if (finish_position_2d(x, y, k) && k.absorbed)     // deposit end point = r + v dt / 2, v = u c / gamma
+        report_absorbed_2d(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
+                           (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy), k.dep.c_rho * w);
     p.x[ip] = x; p.y[ip] = y;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
@@ -232,8 +257,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // minimum number of lanes sharing one deposit window for the wave reduction to pay; smaller groups go
 // straight to LDS atomics
-constexpr int WR_MIN_GROUP = 12;
-constexpr int WR_MAX_ROUNDS = 2;
+[[maybe_unused]] constexpr int WR_MIN_GROUP = 12;
+[[maybe_unused]] constexpr int WR_MAX_ROUNDS = 2;
 
 // Window row 3 / column 3 only receive something from a particle that changed cell during the step (a few
 // per cent of the lanes), yet a wave has to issue those 28 ds_add_f64 whenever ANY of its 64 lanes did.
@@ -265,8 +290,8 @@ struct Reloc {
     uint32_t *stats;         // optional [4]: parked, movers, movers that left their slot, movers without a slot of their class
     int init;                // first push after a sort: the classes are (re)written, not read (host side: selects the instantiation)
 };
-constexpr int RL_CLASSES = 32, RL_DEPTH = 16;
-constexpr uint32_t RL_DEP = 1u, RL_MOV = 2u;
+[[maybe_unused]] constexpr int RL_CLASSES = 32, RL_DEPTH = 16;
+[[maybe_unused]] constexpr uint32_t RL_DEP = 1u, RL_MOV = 2u;
 
 // RELOC_MODE: 0 = off, 1 = on, 2 = on and this is the first push after a sort (the classes are written, not read:
 // its own instantiation, the 16-bit store in the loop costs the steady-state kernel 44 spilled VGPRs otherwise)
@@ -283,7 +308,10 @@ struct Coop {
     const int32_t *pad_ranks;   // [ntiles] full stripes per tile
 };
 
-template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE, bool COOP = false>
+// Template parameters of the product build: WRITE_EB (store the gathered E / B per particle), DEFER (second pass for
+// the cell-crossers), RHO (deposit rho; false = LPA_PUSH_NO_RHO).  WAVE_REDUCE / RELOC_MODE / COOP select the variant
+// deposit paths and are false / 0 unless LPA_K1_VARIANTS (their code is fenced by `#if LPA_K1_VARIANTS`).
+template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE, bool COOP, bool RHO>
 __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
@@ -296,11 +324,16 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     constexpr bool RELOC = RELOC_MODE != 0, RL_INIT = RELOC_MODE == 2;
     static_assert(!RELOC || (DEFER && !WAVE_REDUCE && !WRITE_EB), "RELOC rides on the parked-crosser pass");
     static_assert(!COOP || (DEFER && !WAVE_REDUCE), "COOP parks what it cannot deposit");
+    static_assert(LPA_K1_VARIANTS || (!WAVE_REDUCE && !RELOC && !COOP), "variant paths need -DLPA_K1_VARIANTS=1");
+    static_assert(RHO || (!WAVE_REDUCE && !COOP), "the variant deposits always carry rho");
+    constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho)
     __shared__ __attribute__((aligned(16))) double s_eb[RSZ];
-    __shared__ double s_j[4][RSZJ];
+    __shared__ double s_j[NJ][RSZJ];
     __shared__ int s_ncross;
+#if LPA_K1_VARIANTS
     __shared__ int s_stk_cnt[RELOC ? RL_CLASSES : 1], s_stk[RELOC ? RL_CLASSES * RL_DEPTH : 1];
     __shared__ int s_hl_dst[RELOC ? RL_CLASSES * RL_DEPTH : 1], s_nhl;
+#endif
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), work blocks
     // are in tile order: give every XCD a contiguous run of them, so that neighbouring tiles -- which
     // share halo rows of E / B and flush into the same J lines -- meet in one L2 (measured effect on C2:
@@ -321,16 +354,18 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
     // COOP: first slot of the tile and one past its last full-stripe slot (both multiples of 64, like `begin`)
+    if (DEFER && threadIdx.x == 0) s_ncross = 0;
+#if LPA_K1_VARIANTS
     [[maybe_unused]] int tile_first = 0, pad_end = 0;
     if (COOP) {
         tile_first = co.tile_off[tile];
         pad_end = tile_first + co.pad_ranks[tile] * 256;
     }
-    if (DEFER && threadIdx.x == 0) s_ncross = 0;
     if (RELOC) {
         if (threadIdx.x < RL_CLASSES) s_stk_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_nhl = 0;
     }
+#endif
 
     // ---- stage E/B (along an open axis nodes outside the padded array are never touched by a fast-path
     //      particle)
@@ -355,7 +390,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             row[EB_EZ + ly] = v[2];
             row[EB_BZ + ly] = v[5];
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_j[c][lx * RSJ + ly] = 0.0;
+            for (int c = 0; c < NJ; c++) s_j[c][lx * RSJ + ly] = 0.0;
         }
     }
     __syncthreads();
@@ -481,6 +516,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 const double d1x = ix1 - (x + vx * 0.5 * k.dt - g.x0) * inv_dx;
                 const double d1y = iy1 - (y + vy * 0.5 * k.dt - g.y0) * inv_dy;
                 cross = !(d1x > -0.5 && d1x <= 0.5 && d1y > -0.5 && d1y <= 0.5);
+#if LPA_K1_VARIANTS
                 if (RELOC) {
                     // nearest node of the advanced deposit end point = the gather cell of the NEXT step
                     const int jy = iy1 + (int)floor(0.5 - d1y);
@@ -495,6 +531,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                     mover = false;
 #endif
                 }
+#endif
                 tsc3(d1x, ax.S1);
                 tsc3(d1y, ay.S1);
 #pragma unroll
@@ -513,7 +550,9 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             int bx = clampi(ax.base - rx0, 0, RWX - 4), by = clampi(ay.base - ry0, 0, RWY - 4);
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
-            finish_position_2d(xs, ys, k);
+            if (finish_position_2d(xs, ys, k) && k.absorbed)    // rare: a particle reached an open face
+                report_absorbed_2d(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
+                                   k.dep.c_rho * w);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)ip * 8u;
             st(p.x, o, xs); st(p.y, o, ys);
@@ -527,6 +566,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             ax.base = ay.base = 0;
             ax.tail_zero = ay.tail_zero = false;
         }
+#if LPA_K1_VARIANTS
         if (COOP && it + 64 <= pad_end) {      // wave-uniform: this wave walks 64 slots of a full stripe
             const int cn = (ip - tile_first) & 255;                 // the cell this lane owns
             const int lxn = cn >> 5, lyn = cn & 31;
@@ -562,14 +602,14 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 }
                 const int o = bn + kk * RSJ;
                 // own middle column + the left neighbour's upper column + the right neighbour's lower column
-                atomicAdd(&s_j[3][o], fma(mn, wr_dpp<0x130>(vrh[0]), fma(mp, wr_dpp<0x138>(vrh[2]), vrh[1])));
+                atomicAdd(&s_j[NJ - 1][o], fma(mn, wr_dpp<0x130>(vrh[0]), fma(mp, wr_dpp<0x138>(vrh[2]), vrh[1])));
                 atomicAdd(&s_j[2][o], fma(mn, wr_dpp<0x130>(vjz[0]), fma(mp, wr_dpp<0x138>(vjz[2]), vjz[1])));
                 atomicAdd(&s_j[1][o], fma(mn, wr_dpp<0x130>(vjy[0]), vjy[1]));           // (column 2 of jy is the null run)
                 if (kk < 2) atomicAdd(&s_j[0][o], fma(mn, wr_dpp<0x130>(vjx[0]), fma(mp, wr_dpp<0x138>(vjx[2]), vjx[1])));
                 if (edge) {                    // nobody owns the column beyond the row end
                     const int oe = be + kk * RSJ;
                     const bool lo = lyn == 0;
-                    atomicAdd(&s_j[3][oe], lo ? vrh[0] : vrh[2]);
+                    atomicAdd(&s_j[NJ - 1][oe], lo ? vrh[0] : vrh[2]);
                     atomicAdd(&s_j[2][oe], lo ? vjz[0] : vjz[2]);
                     if (lo) atomicAdd(&s_j[1][oe], vjy[0]);
                     if (kk < 2) atomicAdd(&s_j[0][oe], lo ? vjx[0] : vjx[2]);
@@ -577,6 +617,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             }
             continue;
         }
+#endif
 
         if (!WAVE_REDUCE) {
             // ---- deposit, STRIPED order: the lanes of a half-wave sit in consecutive y-cells, so each
@@ -618,15 +659,14 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                        if (on_y) atomicAdd(&s_j[1][o], djy);
                                        if (on) {
                                            atomicAdd(&s_j[2][o], djz);
-#ifndef LPA_ABLATE_NO_RHO   // diagnostic build: what depositing rho costs (open items)
-                                           atomicAdd(&s_j[3][o], drho);
-#endif
+                                           if (RHO) atomicAdd(&s_j[NJ - 1][o], drho);
                                        }
 #endif
                                    }, &k.dep);
             }
             continue;
         }
+#if LPA_K1_VARIANTS
         // ---- deposit.  Particles are cell sorted, so most lanes of the wave share one 4x4 window:
         // those are summed across the wave in registers (reduce-scatter: lane L ends with the total
         // of window value L = quantity*16 + kx*4 + ly) and leave ONE ds_add_f64 per lane, all to
@@ -669,12 +709,13 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                            if (djx != 0.0) atomicAdd(&s_j[0][o], djx);
                                            if (djy != 0.0) atomicAdd(&s_j[1][o], djy);
                                            if (djz != 0.0) atomicAdd(&s_j[2][o], djz);
-                                           if (drho != 0.0) atomicAdd(&s_j[3][o], drho);
+                                           if (drho != 0.0) atomicAdd(&s_j[NJ - 1][o], drho);
                                        });
                 }
                 todo = 0;
             }
         }
+#endif
     }
     if (DEFER) {
         // ---- the particles that changed cell: the general 4 x 4 window, every lane busy
@@ -701,6 +742,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             const uint32_t o = (uint32_t)(begin + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
                          uz = ld(sc.a[4], o), ig = ld(sc.a[5], o), w = ld(sc.a[6], o);
+#if LPA_K1_VARIANTS
 #ifdef LPA_RL_NO_PHASES   // diagnostic build: movers are parked but stay where they are
             if (false) {
 #else
@@ -721,6 +763,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                     atomicSub(&s_stk_cnt[c], 1);
                 }
             }
+#endif
             if (info & RL_DEP) {
                 const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
                 AxisW ax, ay;
@@ -736,11 +779,12 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                            atomicAdd(&s_j[0][oo], djx);
                                            atomicAdd(&s_j[1][oo], djy);
                                            atomicAdd(&s_j[2][oo], djz);
-                                           atomicAdd(&s_j[3][oo], drho);
+                                           if (RHO) atomicAdd(&s_j[NJ - 1][oo], drho);
                                        }
                                    }, &k.dep);
             }
         }
+#if LPA_K1_VARIANTS
         if (RELOC) {
             // the mover's state (as parked: before the periodic fold) goes to slot `dst`
             auto seat = [&](int dst) {
@@ -785,6 +829,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             __syncthreads();
             if (mh >= 0) seat(s_hl_dst[mh]);
         }
+#endif
     }
     __syncthreads();
 #if defined(LPA_ABLATE_NO_ATOMICS) || defined(LPA_ABLATE_NO_GATHER) || defined(LPA_RL_NO_PARK)
@@ -804,7 +849,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if ((unsigned)cx >= (unsigned)g.NX || (unsigned)cy >= (unsigned)g.NY) continue;
             long gi = (long)cx * g.NY + cy;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < NJ; c++) {
                 double v = s_j[c][lx * RSJ + ly];
                 if (v != 0.0) atomicAdd(&dst[c][gi], v);
             }
@@ -856,6 +901,9 @@ static int check_push(const lpa_grid *g, const lpa_particles *p, const lpa_push_
     LPA_REQUIRE(lpa_grid_ok(g, 2, 1), "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(p, 2), "%s: bad particle store", name);
     LPA_REQUIRE(pp && pp->dt > 0 && pp->m > 0, "%s: dt and m must be > 0", name);
+    LPA_REQUIRE(!(pp->flags & LPA_PUSH_NO_RHO) || !(pp->wrap & (3 * LPA_ABSORB_X)) || pp->absorbed,
+                "%s: LPA_PUSH_NO_RHO with absorbing faces needs the absorbed list", name);
+    LPA_REQUIRE(!pp->absorbed || (pp->absorbed_count && pp->absorbed_capacity > 0), "%s: bad absorbed list", name);
     return LPA_OK;
 }
 
@@ -915,38 +963,51 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     GridV gv = make_gridv(g, 2);
     PartV pv = make_partv(p);
     PushK k = make_pushk(pp, g);
-    // CELL_MAJOR stores use the wave reduce-scatter deposit, STRIPED stores the conflict-free atomics
-    const bool eb = p->part_eb[0] != nullptr, wr = t->order == LPA_ORDER_CELL_MAJOR;
+    const bool eb = p->part_eb[0] != nullptr, rho = !(pp->flags & LPA_PUSH_NO_RHO);
     Scratch7 sc;
-    bool defer = !wr;
+    bool defer = true;
     for (int c = 0; c < 7; c++) {
         sc.a[c] = t->scratch[c];
         defer = defer && sc.a[c] != nullptr;
     }
-    // the in-kernel re-seating needs the slot classes, two uint32 scratch arrays and (when ids are carried) an
-    // 8-byte one
     Reloc rl{t->slot_class, t->aux_slot, t->aux_info, (unsigned long long *)t->scratch[7], t->reloc_stats,
              t->class_init};
-    const bool reloc = defer && !eb && rl.cls && rl.aux_slot && rl.aux_info && (rl.aux_id || !pv.id);
     Coop co{t->tile_off, t->pad_ranks};
-    const bool coop = t->order == LPA_ORDER_PADDED && defer && !eb && t->pad_ranks && t->tile_off;
-    LPA_REQUIRE(t->order != LPA_ORDER_PADDED || !reloc, "lpa_push_deposit_tiled_2d: slot classes and the padded order exclude each other");
-#define LPA_LAUNCH_TILED(E, W, D, R)                                                                    \
-    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
-                       (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks, \
+#define LPA_LAUNCH_TILED(E, W, D, R, CO, RH)                                                                  \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R, CO, RH>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
+                       (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks,   \
                        t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl, co)
-    if (coop)
-        hipLaunchKernelGGL((k_push_deposit_tiled_2d<false, false, true, 0, true>), dim3(t->max_blocks),
-                           dim3(K1_THREADS), 0, (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end,
-                           t->n_blocks, t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl, co);
-    else if (eb && wr) LPA_LAUNCH_TILED(true, true, false, 0);
-    else if (wr) LPA_LAUNCH_TILED(false, true, false, 0);
-    else if (eb && defer) LPA_LAUNCH_TILED(true, false, true, 0);
-    else if (eb) LPA_LAUNCH_TILED(true, false, false, 0);
-    else if (reloc && rl.init) LPA_LAUNCH_TILED(false, false, true, 2);
-    else if (reloc) LPA_LAUNCH_TILED(false, false, true, 1);
-    else if (defer) LPA_LAUNCH_TILED(false, false, true, 0);
-    else LPA_LAUNCH_TILED(false, false, false, 0);
+#if LPA_K1_VARIANTS
+    // CELL_MAJOR stores use the wave reduce-scatter deposit, PADDED stores the cooperative one; with slot classes the
+    // striped path re-seats its movers.  The variant deposits always carry rho.
+    const bool wr = t->order == LPA_ORDER_CELL_MAJOR;
+    defer = defer && !wr;
+    // the in-kernel re-seating needs the slot classes, two uint32 scratch arrays and (when ids are carried) an
+    // 8-byte one
+    const bool reloc = defer && !eb && rho && rl.cls && rl.aux_slot && rl.aux_info && (rl.aux_id || !pv.id);
+    const bool coop = t->order == LPA_ORDER_PADDED && defer && !eb && rho && t->pad_ranks && t->tile_off;
+    LPA_REQUIRE(t->order != LPA_ORDER_PADDED || !reloc, "lpa_push_deposit_tiled_2d: slot classes and the padded order exclude each other");
+    LPA_REQUIRE(rho || !wr, "lpa_push_deposit_tiled_2d: LPA_PUSH_NO_RHO is not available for CELL_MAJOR stores");
+    if (coop) LPA_LAUNCH_TILED(false, false, true, 0, true, true);
+    else if (eb && wr) LPA_LAUNCH_TILED(true, true, false, 0, false, true);
+    else if (wr) LPA_LAUNCH_TILED(false, true, false, 0, false, true);
+    else if (reloc && rl.init) LPA_LAUNCH_TILED(false, false, true, 2, false, true);
+    else if (reloc) LPA_LAUNCH_TILED(false, false, true, 1, false, true);
+    else
+#else
+    // the product build has one deposit path (per-lane LDS atomics + the dense second pass); it is correct for every
+    // order the sort can produce (holes of a PADDED store are dead slots), only the STRIPED one makes it conflict free
+    LPA_REQUIRE(!t->slot_class, "lpa_push_deposit_tiled_2d: the in-kernel re-seating (slot classes) is compiled only "
+                                "into the variants library (-DLPA_K1_VARIANTS=1)");
+#endif
+    if (eb && defer && rho) LPA_LAUNCH_TILED(true, false, true, 0, false, true);
+    else if (eb && defer) LPA_LAUNCH_TILED(true, false, true, 0, false, false);
+    else if (eb && rho) LPA_LAUNCH_TILED(true, false, false, 0, false, true);
+    else if (eb) LPA_LAUNCH_TILED(true, false, false, 0, false, false);
+    else if (defer && rho) LPA_LAUNCH_TILED(false, false, true, 0, false, true);
+    else if (defer) LPA_LAUNCH_TILED(false, false, true, 0, false, false);
+    else if (rho) LPA_LAUNCH_TILED(false, false, false, 0, false, true);
+    else LPA_LAUNCH_TILED(false, false, false, 0, false, false);
 #undef LPA_LAUNCH_TILED
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_2d");
     return LPA_OK;

@@ -15,7 +15,23 @@ struct PushK3 {
     // 14 VGPRs for the whole particle loop, spilled to scratch and reloaded 13 times per particle
     double inv_d[3];        // 1 / dx, 1 / dy, 1 / dz
     double c_rho, c_j[3];   // q / (dx dy dz),  q / (dy dz dt), q / (dx dz dt), q / (dx dy dt)
+    // LPA_PUSH_NO_RHO: rho is not deposited (the caller advances it with lpa_rho_continuity).  `absorbed` (optional,
+    // any mode): particles absorbed at an open face are reported there, so that lpa_rho_absorbed can take their
+    // charge out of a rho that is carried over to the next step
+    int flags;
+    double *absorbed;
+    uint32_t *absorbed_count;
+    long absorbed_cap;
 };
+
+// the deposit end point (cells from node 0) and charge density factor of a particle that was just absorbed
+__device__ __forceinline__ void report_absorbed(const PushK3 &k, double o1x, double o1y, double o1z, double cd) {
+    const uint32_t slot = atomicAdd(k.absorbed_count, 1u);
+    if ((long)slot < k.absorbed_cap) {
+        double *e = k.absorbed + 4 * (long)slot;
+        e[0] = o1x; e[1] = o1y; e[2] = o1z; e[3] = cd;
+    }
+}
 
 struct GIdx3 { long r[3]; int c[3]; int d[3]; };
 
@@ -173,7 +189,7 @@ __device__ __forceinline__ void esirkepov_3d_lean(const AxisW &ax, const AxisW &
 
 __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, double y, double z,
                                                   double ux, double uy, double uz, double ig, double w,
-                                                  double q, double dt) {
+                                                  double q, double dt, bool rho = true) {
     double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
     AxisW ax, ay, az;
     axis_window(ax, x - vx * 0.5 * dt - g.x0, x + vx * 0.5 * dt - g.x0, 1.0 / g.dx);
@@ -198,7 +214,7 @@ __device__ __forceinline__ void deposit_global_3d(const GridV &g, double x, doub
             long idx = rows[i] + cols[j] + deps[k];
             if (djy != 0.0) atomicAdd(&g.jy[idx], djy);
             if (djz != 0.0) atomicAdd(&g.jz[idx], djz);
-            if (dr != 0.0) atomicAdd(&g.rho[idx], dr);
+            if (rho && dr != 0.0) atomicAdd(&g.rho[idx], dr);
         });
 }
 
@@ -210,7 +226,7 @@ __device__ __forceinline__ double fold3(double v, double lo, double hi) {
 }
 
 // periodic fold and / or absorption of the advanced position (sync_particles_3d with a self neighbour)
-__device__ __forceinline__ void finish_position_3d(double &x, double &y, double &z, const PushK3 &k) {
+__device__ __forceinline__ bool finish_position_3d(double &x, double &y, double &z, const PushK3 &k) {
     if (k.wrap & 1) x = fold3(x, k.lo[0], k.hi[0]);
     if (k.wrap & 2) y = fold3(y, k.lo[1], k.hi[1]);
     if (k.wrap & 4) z = fold3(z, k.lo[2], k.hi[2]);
@@ -220,6 +236,7 @@ __device__ __forceinline__ void finish_position_3d(double &x, double &y, double 
     for (int a = 0; a < 3; a++)
         dead = dead || ((k.wrap & (LPA_ABSORB_X << a)) && (c3[a] < k.alo[a] || c3[a] > k.ahi[a]));
     if (dead) { x = __longlong_as_double(0x7ff8000000000000ll); y = x; z = x; }
+    return dead;
 }
 
 // the whole per-particle update on global memory
@@ -241,8 +258,15 @@ __device__ __forceinline__ void update_global_3d(const GridV &g, const PartV &p,
     x += k.cdt_half * ig * ux;
     y += k.cdt_half * ig * uy;
     z += k.cdt_half * ig * uz;
-    deposit_global_3d(g, x, y, z, ux, uy, uz, ig, w, k.q, k.dt);
-    finish_position_3d(x, y, z, k);
+    const bool no_rho = k.flags & LPA_PUSH_NO_RHO;
+    deposit_global_3d(g, x, y, z, ux, uy, uz, ig, w, k.q, k.dt, !no_rho);
+    const double xe = x, ye = y, ze = z;
+    if (finish_position_3d(x, y, z, k) && k.absorbed) {
+        // deposit_global_3d: end point = r + v dt / 2 with v = u c / gamma
+        report_absorbed(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
+                        (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy),
+                        (ze + uz * LPA_C * ig * 0.5 * k.dt - g.z0) * (1.0 / g.dz), (k.q / (g.dx * g.dy * g.dz)) * w);
+    }
     p.x[ip] = x; p.y[ip] = y; p.z[ip] = z;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
@@ -402,12 +426,13 @@ __device__ __forceinline__ int clamp3(int v, int hi) { return v < 0 ? 0 : (v > h
 #ifndef LPA_K13_PERSIST
 #define LPA_K13_PERSIST 0
 #endif
-template <bool DEFER>
+template <bool DEFER, bool RHO>
 __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
     uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols, Scratch8 sc) {
-    __shared__ double s_j[4][R3N];
+    constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho): without rho the image is 58 KB instead of 77 KB
+    __shared__ double s_j[NJ][R3N];
     __shared__ double s_eb[3 * EBN];     // see eb_base()
     __shared__ int s_ncross;
 #if LPA_K13_PERSIST
@@ -444,7 +469,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     if (DEFER && threadIdx.x == 0) s_ncross = 0;
     for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) s_j[c][t] = 0.0;
+        for (int c = 0; c < NJ; c++) s_j[c][t] = 0.0;
     }
     const int e0[3] = {t0[0] - G3L, t0[1] - G3L, t0[2] - G3L};    // first node of the E/B image
     {
@@ -612,7 +637,9 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         }
         {
             double xs = x, ys = y, zs = z;
-            finish_position_3d(xs, ys, zs, k);
+            if (finish_position_3d(xs, ys, zs, k) && k.absorbed)    // rare: a particle reached an open face
+                report_absorbed(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
+                                (z + vz * 0.5 * k.dt - g.z0) * inv_dz, k.c_rho * w);
             const uint32_t o = (uint32_t)ip * 8u;
             st(p.x, o, xs); st(p.y, o, ys); st(p.z, o, zs);
             st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
@@ -657,9 +684,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
 #else
                     if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][o], djy);
                     if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][o], djz);
-#ifndef LPA_ABLATE_NO_RHO   // diagnostic build: what depositing rho costs (open items)
-                    atomicAdd(&s_j[3][o], dr);
-#endif
+                    if (RHO) atomicAdd(&s_j[NJ - 1][o], dr);
 #endif
                 }
             });
@@ -699,9 +724,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                         int oo = b0 + (ii * R3Y + j) * R3ZS + kk;
                         if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][oo], djy);
                         if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][oo], djz);
-#ifndef LPA_ABLATE_NO_RHO
-                        atomicAdd(&s_j[3][oo], dr);
-#endif
+                        if (RHO) atomicAdd(&s_j[NJ - 1][oo], dr);
                     }
                 });
         }
@@ -724,7 +747,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                        node_index(r0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
                       node_index(r0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < NJ; c++) {
                 double v = s_j[c][t];
                 if (v != 0.0) atomicAdd(&dst[c][gi], v);
             }
@@ -751,6 +774,8 @@ static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr
     k.bfactor = pp->q * pp->dt / (2 * pp->m);
     k.cdt_half = LPA_C * 0.5 * pp->dt;
     k.wrap = pp->wrap;
+    k.flags = pp->flags;
+    k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
     for (int a = 0; a < 3; a++) {
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
         k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
@@ -784,6 +809,9 @@ static int check_push3(const lpa_grid *g, const lpa_particles *p, const lpa_push
     LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(p, 3), "%s: bad particle store", name);
     LPA_REQUIRE(pp && pp->dt > 0 && pp->m > 0, "%s: dt and m must be > 0", name);
+    LPA_REQUIRE(!(pp->flags & LPA_PUSH_NO_RHO) || !(pp->wrap & (7 * LPA_ABSORB_X)) || pp->absorbed,
+                "%s: LPA_PUSH_NO_RHO with absorbing faces needs the absorbed list", name);
+    LPA_REQUIRE(!pp->absorbed || (pp->absorbed_count && pp->absorbed_capacity > 0), "%s: bad absorbed list", name);
     return LPA_OK;
 }
 
@@ -875,16 +903,16 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
 #if LPA_K13_PERSIST
     if (grid > 256u * LPA_K13_PERSIST) grid = 256u * LPA_K13_PERSIST;
 #endif
-    if (defer)
-        hipLaunchKernelGGL(k_push_deposit_tiled_3d<true>, dim3(grid), dim3(K13_THREADS), 0,
-                           (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
-                           t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
-                           part, t->tiles_x, edge_cols, sc);
-    else
-        hipLaunchKernelGGL(k_push_deposit_tiled_3d<false>, dim3(grid), dim3(K13_THREADS), 0,
-                           (hipStream_t)stream, make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile,
-                           t->blk_begin, t->blk_end, t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count,
-                           part, t->tiles_x, edge_cols, sc);
+    const bool rho = !(pp->flags & LPA_PUSH_NO_RHO);
+#define LPA_LAUNCH_TILED3(D, R)                                                                                     \
+    hipLaunchKernelGGL((k_push_deposit_tiled_3d<D, R>), dim3(grid), dim3(K13_THREADS), 0, (hipStream_t)stream,       \
+                       make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile, t->blk_begin, t->blk_end,   \
+                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols, sc)
+    if (defer && rho) LPA_LAUNCH_TILED3(true, true);
+    else if (defer) LPA_LAUNCH_TILED3(true, false);
+    else if (rho) LPA_LAUNCH_TILED3(false, true);
+    else LPA_LAUNCH_TILED3(false, false);
+#undef LPA_LAUNCH_TILED3
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
     return LPA_OK;
 }

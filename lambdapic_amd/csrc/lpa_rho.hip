@@ -1,0 +1,128 @@
+// lpa_rho.hip -- rho from the discrete continuity equation: the grid-side companions of the LPA_PUSH_NO_RHO form of the
+// fused particle kernels (lpa_particles.hip, lpa_particles3d.hip).
+//
+// The reference deposits rho together with the currents (current/current_deposit.h:180,  :436-439: `rho += q w /
+// (dx dy [dz]) S1x S1y [S1z]`).  Esirkepov's scheme is built so that this rho and the deposited currents satisfy
+//     (rho1 - rho0) / dt + (jx[i] - jx[i-1]) / dx + (jy[j] - jy[j-1]) / dy [+ (jz[k] - jz[k-1]) / dz] = 0
+// per particle and per node (rho0 = the same particle's shape at the start of the step).  On the device the rho
+// atomics are 9 of the 30 (2-D) / 27 of the 81 (3-D) LDS atomics of the kernel that decides the step time, so between
+// two real deposits rho is advanced from the folded currents here -- streaming kernels over the grid, 5-6 doubles per
+// node, against 27 LDS atomics per particle.
+#include "lpa_common.hpp"
+
+// ---- jx jy jz = 0 (rho persists) ---------------------------------------------------------------------------------
+extern "C" int lpa_reset_j(const lpa_grid *g, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz, "lpa_reset_j: bad grid");
+    const size_t cnt = (size_t)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) * (g->nz > 1 ? (size_t)(g->nz + 2 * g->ng) : 1);
+    const size_t n = cnt * sizeof(double);
+    double *a[3] = {g->jx, g->jy, g->jz};
+    if (a[1] == a[0] + cnt && a[2] == a[1] + cnt) {  // one allocation: one memset
+        if (hipMemsetAsync(a[0], 0, 3 * n, (hipStream_t)stream) != hipSuccess) {
+            lpa_set_error("lpa_reset_j: hipMemsetAsync failed");
+            return LPA_ERR_HIP;
+        }
+        return LPA_OK;
+    }
+    for (int c = 0; c < 3; c++)
+        if (hipMemsetAsync(a[c], 0, n, (hipStream_t)stream) != hipSuccess) {
+            lpa_set_error("lpa_reset_j: hipMemsetAsync failed");
+            return LPA_ERR_HIP;
+        }
+    return LPA_OK;
+}
+
+// ---- rho -= dt div J -------------------------------------------------------------------------------------------------
+// mode per axis: 0 = open (every padded node, torus neighbour), 1 = folded inside the slab (interior nodes, node 0 ->
+// node n - 1), 2 = split over ranks (interior nodes, node 0 -> the left neighbour's plane, or the own guard)
+__device__ __forceinline__ bool rho_axis(int c, int n, int ng, int N, int mode, int &prev) {
+    if (mode == 0) {
+        prev = c == 0 ? N - 1 : c - 1;
+        return true;
+    }
+    if (c < ng || c >= ng + n) return false;
+    prev = (mode == 1 && c == ng) ? ng + n - 1 : c - 1;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_rho_continuity(GridV g, double dtdx, double dtdy, double dtdz, int mx, int my,
+                                                        int mz, const double *__restrict__ left) {
+    const bool d3 = g.NZ > 1;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;  // fastest axis
+    if (f >= (d3 ? g.NZ : g.NY)) return;
+    const int cx = d3 ? blockIdx.z : blockIdx.y, cy = d3 ? (int)blockIdx.y : f, cz = d3 ? f : 0;
+    int px, py, pz = 0;
+    if (!rho_axis(cx, g.nx, g.ng, g.NX, mx, px) || !rho_axis(cy, g.ny, g.ng, g.NY, my, py)) return;
+    if (d3 && !rho_axis(cz, g.nz, g.ng, g.NZ, mz, pz)) return;
+    const long sX = (long)g.NY * g.NZ, sY = g.NZ;
+    const long c = cx * sX + cy * sY + cz;
+    const double jxp = (mx == 2 && cx == g.ng && left) ? left[cy * sY + cz] : g.jx[px * sX + cy * sY + cz];
+    double div = (g.jx[c] - jxp) * dtdx + (g.jy[c] - g.jy[cx * sX + py * sY + cz]) * dtdy;
+    if (d3) div += (g.jz[c] - g.jz[cx * sX + cy * sY + pz]) * dtdz;
+    g.rho[c] -= div;
+}
+
+extern "C" int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axes, int split_x,
+                                  const double *jx_left_plane, void *stream) {
+    const int dim = g && g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(lpa_grid_ok(g, dim, 1) && dt > 0, "lpa_rho_continuity: bad args");
+    LPA_REQUIRE(!(split_x && (periodic_axes & 1)), "lpa_rho_continuity: x is either folded locally or split");
+    GridV v = make_gridv(g, dim);
+    const int mx = split_x ? 2 : (periodic_axes & 1), my = (periodic_axes >> 1) & 1, mz = (periodic_axes >> 2) & 1;
+    dim3 grid = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
+    hipLaunchKernelGGL(k_rho_continuity, grid, dim3(256), 0, (hipStream_t)stream, v, dt / g->dx, dt / g->dy,
+                       dim == 3 ? dt / g->dz : 0.0, mx, my, mz, jx_left_plane);
+    LPA_CHECK_LAUNCH("lpa_rho_continuity");
+    return LPA_OK;
+}
+
+// ---- the charge of absorbed particles leaves rho -----------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rho_absorbed(GridV g, const double *__restrict__ list,
+                                                      const uint32_t *__restrict__ count, long capacity) {
+    const long n = min((long)count[0], capacity);
+    const bool d3 = g.NZ > 1;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const double *e = list + 4 * t;
+        const double cd = e[3];
+        int i1[3];
+        double s[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            i1[a] = ifloor(e[a] + 0.5);
+            tsc3(i1[a] - e[a], s[a]);     // the new shape S1 of the deposit (current_deposit.h:7-35)
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const long r = (long)torus(i1[0] - 1 + i + g.ng, g.NX) * g.NY;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const long rc = (r + torus(i1[1] - 1 + j + g.ng, g.NY)) * g.NZ;
+                if (!d3) {
+                    atomicAdd(&g.rho[rc], -(cd * s[0][i] * s[1][j]));
+                    continue;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++)
+                    atomicAdd(&g.rho[rc + torus(i1[2] - 1 + kk + g.ng, g.NZ)], -(cd * s[0][i] * s[1][j] * s[2][kk]));
+            }
+        }
+    }
+}
+
+__global__ void k_rho_absorbed_done(uint32_t *count, long capacity) {
+    const uint32_t n = count[0];
+    if ((long)n > capacity) count[1] += (uint32_t)((long)n - capacity);
+    count[0] = 0;
+}
+
+extern "C" int lpa_rho_absorbed(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity,
+                                void *stream) {
+    const int dim = g && g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(lpa_grid_ok(g, dim, 1) && list && count && capacity > 0, "lpa_rho_absorbed: bad args");
+    // absorptions are rare (particles reaching an open face): a small fixed grid walks whatever the list holds
+    hipLaunchKernelGGL(k_rho_absorbed, dim3(64), dim3(256), 0, (hipStream_t)stream, make_gridv(g, dim), list, count,
+                       (long)capacity);
+    LPA_CHECK_LAUNCH("lpa_rho_absorbed");
+    hipLaunchKernelGGL(k_rho_absorbed_done, dim3(1), dim3(1), 0, (hipStream_t)stream, count, (long)capacity);
+    LPA_CHECK_LAUNCH("lpa_rho_absorbed_done");
+    return LPA_OK;
+}

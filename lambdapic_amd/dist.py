@@ -194,11 +194,15 @@ def exchange_faces(comm: SlabComm, pack, unpack, bufs, pack2=None, unpack2=None)
     """
     single = comm.size == 1 and comm.periodic
     got_lo, got_hi = comm.has_left or single, comm.has_right or single   # nothing arrives through an open face
+    # (nothing leaves through an open face either: its guard planes are left alone -- a packed current plane is
+    # zeroed, and the open end of a chain must keep what was deposited there exactly like a single slab does)
     if pack2 is not None:
-        pack2(bufs["s_lo"], bufs["s_hi"])
+        pack2(bufs["s_lo"] if got_lo else None, bufs["s_hi"] if got_hi else None)
     else:
-        pack(0, bufs["s_lo"])
-        pack(1, bufs["s_hi"])
+        if got_lo:
+            pack(0, bufs["s_lo"])
+        if got_hi:
+            pack(1, bufs["s_hi"])
     comm.exchange(bufs["s_lo"], bufs["s_hi"], bufs["r_lo"], bufs["r_hi"])
     if unpack2 is not None:
         unpack2(bufs["r_lo"] if got_lo else None, bufs["r_hi"] if got_hi else None)

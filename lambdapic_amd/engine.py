@@ -30,6 +30,7 @@ from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr, restore_device, to_host
 from .dist import SlabComm, exchange_faces
+from .rho import RhoContinuityMixin
 
 
 class DevicePML2D:
@@ -108,7 +109,7 @@ class DevicePML2D:
         return self._coef[k]
 
 
-class PicEngine2D:
+class PicEngine2D(RhoContinuityMixin):
     def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
                  x0=0.0, y0=0.0, sort_interval=8, block_particles=8192, migrate_capacity=32768,
                  boundary_conditions=None, cpml_thickness=6, order=_lib.LPA_ORDER_STRIPED):
@@ -188,9 +189,24 @@ class PicEngine2D:
         # the fused kernel stores the gathered E/B per particle (the reference's ex_part..bz_part side
         # effect, +48 B/particle) only when asked: callbacks that read them set this
         self.write_part_eb = False
+        self._rho_init()     # rho from the continuity equation between two real deposits: see rho.py
+
+    def _rho_available(self):
+        # the variant deposit paths (CELL_MAJOR / PADDED stores, re-seating) always carry rho
+        return self.order == _lib.LPA_ORDER_STRIPED and not self.reseat
+
+    def _rho_sort_due(self):
+        return any(sp.tiling is None or sp.steps_since_sort >= self.sort_interval for sp in self.species if sp.n)
+
+    def _rho_particle_slots(self):
+        return sum(sp.capacity for sp in self.species)
+
+    def _rho_last_jx_plane(self):
+        return self.grid.view("jx")[self.ng + self.nx - 1]
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`: the reference pickles the whole Simulation) ----
-    _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events")
+    _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed", "_jx_plane",
+                  "_one")
 
     def __getstate__(self):
         """everything but handles and scratch: the library handle, sort workspaces (and with them the tilings),
@@ -207,6 +223,7 @@ class PicEngine2D:
         self.L = lib()
         self._ws, self._halo, self._side, self._axes, self.kernel_events = {}, None, None, {}, None
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._rho_restore()
 
     # ---------------------------------------------------------------------------------------------
     @property
@@ -349,7 +366,9 @@ class PicEngine2D:
 
     # ---- currents (CurrentDeposition2D.reset, Patches.sync_currents + MPIManager.sync_currents_*) --
     def reset_current(self):
-        check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
+        """`CurrentDeposition2D.reset` (core/current/cpu2d.c:19-72); also decides this step's rho mode (rho.py): a real
+        deposit zeroes jx jy jz rho, a continuity step zeroes the currents only"""
+        self._begin_deposit_step()
 
     def sync_currents(self):
         st = self.stream
@@ -364,6 +383,7 @@ class PicEngine2D:
                                       "lpa_halo_unpack_current"),
                 h, pack2=self._faces(_lib.LPA_HALO_PACK_CURRENT), unpack2=self._faces(_lib.LPA_HALO_UNPACK_CURRENT))
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        self._finish_rho()
 
     # ---- sort (ParticleSort2D.__call__, core/sort/particle_sort.py:196-211) ------------------------
     def _sort_ws(self, sp: DeviceParticles):
@@ -436,6 +456,7 @@ class PicEngine2D:
             ws["tiling"].class_init = 0
         sp.tiling = ws["tiling"]
         sp.steps_since_sort = 0
+        self._rho_sorted()
         self._reset_free_slots(ws, ws["tiling"].tiles_x, ws["tiling"].tiles_y, _lib.LPA_TILE_X)
 
     FREE_SLOT_DEPTH = 64
@@ -476,6 +497,7 @@ class PicEngine2D:
         pp.lo[0], pp.hi[0] = self.x0_global - self.dx / 2, self.x0_global + self.Lx - self.dx / 2
         pp.lo[1], pp.hi[1] = self.y0 - self.dy / 2, self.y0 + self.Ly - self.dy / 2
         pp.lo[2], pp.hi[2] = 0.0, 0.0
+        self._push_flags(pp, dt, self.absorb)
         return pp
 
     def push_deposit(self, ispec, dt, tiled=True, part=_lib.LPA_PART_ALL, edge_cols=0):
@@ -561,7 +583,8 @@ class PicEngine2D:
             self._side.wait_event(ready)
             for i in range(len(self.species)):
                 self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
-            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
+            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"] if self.comm.has_left else None,
+                                                    h["s_hi"] if self.comm.has_right else None)
             self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
             done.record(self._side)
         for i in range(len(self.species)):
@@ -570,6 +593,7 @@ class PicEngine2D:
         self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
                                                   h["r_hi"] if self.comm.has_right else None)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
+        self._finish_rho()
         return True
 
     # ---- split kernels: the path the reference takes when a callback sits in a pusher stage --------
@@ -596,6 +620,9 @@ class PicEngine2D:
     def deposit(self, ispec, dt):
         """standalone Esirkepov deposit + the periodic position fold the fused kernel applies itself"""
         sp = self.species[ispec]
+        if self._no_rho:
+            raise _lib.LpaError("the standalone deposit carries rho: set rho_continuity_blocked (or rho_continuity = "
+                                "False) before reset_current() when the split pusher path is used")
         pc = sp.cset.cstruct(sp.n)
         check(self.L.lpa_deposit_2d(self._g(), C.byref(pc), dt, sp.q, self.stream), "lpa_deposit_2d")
         pp = self._push_params(sp, dt)
@@ -673,7 +700,8 @@ class PicEngine2D:
             self.sync_currents()
             return
         h = self._halo_views(4 * self.ng * self.grid.NY)
-        self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
+        self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"] if self.comm.has_left else None,
+                                                    h["s_hi"] if self.comm.has_right else None)
         packed = [self._mig_pack(i) for i in range(len(self.species)) if self.species[i].n]
         idx = [i for i in range(len(self.species)) if self.species[i].n]
         self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])] +
@@ -681,6 +709,7 @@ class PicEngine2D:
         self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
                                                   h["r_hi"] if self.comm.has_right else None)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
+        self._finish_rho()
         for i, (m, fs) in zip(idx, packed):
             self._mig_unpack(i, m, fs)
 

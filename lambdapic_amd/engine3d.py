@@ -25,6 +25,7 @@ from ._lib import LPA_MIG_NATTR, check, lib
 from .device import restore_device, to_host
 from .dist import SlabComm, exchange_faces
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
+from .rho import RhoContinuityMixin
 
 ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
 # the resident store is float64[NROWS3][capacity]: the eight attributes + the bit pattern of ParticlesBase._id
@@ -111,7 +112,7 @@ class DevicePML3D:
         return self._coef[k]
 
 
-class PicEngine3D:
+class PicEngine3D(RhoContinuityMixin):
     def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
                  block_particles=4096, comm=None, migrate_capacity=32768, boundary_conditions=None,
                  cpml_thickness=6):
@@ -191,9 +192,23 @@ class PicEngine3D:
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every launch of the
         # tiled push+deposit kernel on the stream it runs on
         self.kernel_events = None
+        self._rho_init()     # rho from the continuity equation between two real deposits: see rho.py
+
+    def _rho_available(self):
+        return self.tiled
+
+    def _rho_sort_due(self):
+        return any(sp["tiling"] is None or sp["since"] >= self.sort_interval for sp in self.species)
+
+    def _rho_particle_slots(self):
+        return sum(int(sp["data"].shape[1]) for sp in self.species)
+
+    def _rho_last_jx_plane(self):
+        return self.view("jx")[self.ng + self.n[0] - 1]
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`) ------------------------------------------------
-    _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events")
+    _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed",
+                  "_jx_plane", "_one")
 
     def __getstate__(self):
         """see PicEngine2D.__getstate__: fields and the slots in use of every store as host arrays, handles,
@@ -220,6 +235,7 @@ class PicEngine3D:
         self.c = g
         self._halo, self._side, self._axes, self.kernel_events = None, None, {}, None
         self._diag = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._rho_restore()
         self.species = []
         for h in species:
             data = torch.full((NROWS3, h["capacity"]), float("nan"), dtype=torch.float64, device=self.device)
@@ -364,6 +380,7 @@ class PicEngine3D:
             ws["tiling"].scratch[c] = sp["alt"][c].data_ptr() if self.defer_crossers else None
         sp["tiling"] = ws["tiling"]
         sp["since"] = 0
+        self._rho_sorted()
         self._reset_free_slots(ws)
 
     FREE_SLOT_DEPTH = 64
@@ -439,6 +456,7 @@ class PicEngine3D:
                                       "lpa_halo_unpack_current"),
                 h, pack2=self._faces(_lib.LPA_HALO_PACK_CURRENT), unpack2=self._faces(_lib.LPA_HALO_UNPACK_CURRENT))
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
+        self._finish_rho()
 
     def sync_particles(self, i):
         """leavers travel to the ring neighbours in one fixed-size message per face (count in band)"""
@@ -652,6 +670,7 @@ class PicEngine3D:
         # before the shift: re-sort before the next push, whether or not anything arrived or was injected
         for sp in self.species:
             sp["since"] = 1 << 30
+        self._anchor_pending = True
 
     def append_device(self, i, rows, ids=None):
         """append particles (device tensor [NROWS3][k]: ATTRS3 order + id row; or [8][k] with ``ids`` int64[k],
@@ -679,9 +698,12 @@ class PicEngine3D:
         sp["n"] += k
         sp["c"] = self._cstruct(sp["data"], sp["n"])
         sp["since"] = 1 << 30
+        self._anchor_pending = True
 
     def reset_current(self):
-        check(self.L.lpa_reset_current(self._g(), self.stream), "lpa_reset_current")
+        """`CurrentDeposition3D.reset` (core/current/cpu3d.c:185-240); also decides this step's rho mode (rho.py): a
+        real deposit zeroes jx jy jz rho, a continuity step zeroes the currents only"""
+        self._begin_deposit_step()
 
     # ---- one step --------------------------------------------------------------------------------------
     def push_deposit(self, i, dt, part=_lib.LPA_PART_ALL, edge_cols=0):
@@ -693,6 +715,9 @@ class PicEngine3D:
         for a in range(3):
             pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.Lbox[a] - self.d[a] / 2
             pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
+        if self._no_rho and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
+            raise _lib.LpaError("a store needs sorting inside a continuity step: call reset_current() first")
+        self._push_flags(pp, dt, self.absorb)
         if not self.tiled:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
             return
@@ -755,7 +780,8 @@ class PicEngine3D:
             self._side.wait_event(ready)
             for i in range(len(self.species)):
                 self.push_deposit(i, dt, part=_lib.LPA_PART_EDGE, edge_cols=cols)
-            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"], h["s_hi"])
+            self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"] if self.comm.has_left else None,
+                                                    h["s_hi"] if self.comm.has_right else None)
             self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
             done.record(self._side)
         for i in range(len(self.species)):
@@ -764,6 +790,7 @@ class PicEngine3D:
         self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
                                                   h["r_hi"] if self.comm.has_right else None)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
+        self._finish_rho()
         return True
 
     def step(self, dt, laser=None):

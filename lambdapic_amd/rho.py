@@ -1,0 +1,159 @@
+"""rho from the discrete continuity equation between two real deposits -- the host side shared by ``PicEngine2D`` and
+``PicEngine3D`` (device side: ``LPA_PUSH_NO_RHO`` in the fused kernels + csrc/lpa_rho.hip).
+
+The reference deposits rho with the currents in every step (`current/current_deposit.h:180`, `:436-439`).  Esirkepov's
+currents satisfy ``(rho1 - rho0) / dt + div J = 0`` per particle and node, so between two real deposits the engines
+advance rho from the folded currents and the fused kernel drops its rho atomics (9 of 30 in 2-D, 27 of 81 in 3-D -- the
+LDS array is what bounds those kernels).  Rules:
+
+* a REAL deposit (the reference's kernel, everything zeroed first) re-anchors rho in every step in which a store is
+  sorted -- which includes the step after an upload from the host mirrors, an append / injection and a window shift,
+  all of which force a sort -- and in every step while ``rho_continuity_blocked`` is set (a callback reads per-species
+  rho between the species' deposits, or the split pusher path deposits with the standalone kernel);
+* particles the kernels absorb at open faces are reported on the device (``lpa_push_params.absorbed``) in every step and
+  their charge leaves rho at the start of the next continuity step (``lpa_rho_absorbed``) -- exactly when the
+  reference's next deposit no longer contains them.  The list holds 1/32 of the particle slots (at least 65 536
+  entries); the step after a real deposit reads its fill level (one 8-byte read, the sort of that step synchronised the
+  host anyway) and deposits for real again when it did not suffice -- the first step of a run absorbs whatever was
+  loaded inside the layers, millions of particles at C5's size.  An overflow inside a run of continuity steps is
+  reported at the next sort (rho, not the fields, was off until that re-anchoring step) and the list grows;
+* between slabs the backward difference of jx at a slab's node 0 needs the left neighbour's folded jx at its last node:
+  one plane per step travels to the right.
+
+A step is bracketed by ``reset_current()`` (decides the mode) and the fold of the currents (``sync_currents`` & co, which
+end with ``_finish_rho``); ``_phase`` is "idle" outside that bracket.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class RhoContinuityMixin:
+    ABSORBED_MIN_CAPACITY = 1 << 16
+
+    def _rho_init(self):
+        self.rho_continuity = True
+        self.rho_continuity_blocked = False
+        self._anchor_pending = True     # the next reset_current starts a real-deposit step
+        self._phase = "idle"            # "anchor" / "continuity" between reset_current and the fold
+        self._prev_phase = "idle"       # the kind of the last step that started
+        self.rho_steps = {"anchor": 0, "continuity": 0}     # steps of each kind so far (bench / tests)
+        self._dt_step = 0.0
+        self._absorbed = None
+        self._jx_plane = None
+
+    def _rho_restore(self):             # after unpickling: scratch is rebuilt, the next step re-anchors
+        self._absorbed, self._jx_plane = None, None
+        self._anchor_pending, self._phase, self._prev_phase = True, "idle", "idle"
+
+    # ---- hooks the engines provide ------------------------------------------------------------------------------
+    def _rho_available(self) -> bool:
+        return True
+
+    def _rho_sort_due(self) -> bool:
+        raise NotImplementedError
+
+    def _rho_last_jx_plane(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _rho_particle_slots(self) -> int:
+        raise NotImplementedError
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def rho_mode(self):
+        return "continuity" if (self.rho_continuity and self._rho_available()) else "deposited"
+
+    @property
+    def _no_rho(self):
+        return self._phase == "continuity"
+
+    def _absorbed_bufs(self):
+        """device list of the particles the kernels absorbed in the current step: [capacity][4] doubles + uint32
+        {entries, entries lost}"""
+        want = max(self.ABSORBED_MIN_CAPACITY, self._rho_particle_slots() // 32)
+        if self._absorbed is None:
+            self._new_absorbed(want)
+        elif self._absorbed[2] < want and self._phase == "idle":     # (never swapped inside a step)
+            self._new_absorbed(max(want, 2 * self._absorbed[2]))
+            self._anchor_pending = True      # the fresh list knows nothing of the last step's absorptions
+        return self._absorbed
+
+    def _new_absorbed(self, cap):
+        self._absorbed = (torch.zeros(4 * cap, dtype=torch.float64, device=self.device),
+                          torch.zeros(2, dtype=torch.int32, device=self.device), int(cap))
+
+    def _check_absorbed(self):
+        """(at a sort: the host is synchronised anyway) absorbed particles that did not fit the list kept their
+        charge in rho until this re-anchoring step"""
+        if self._absorbed is not None:
+            lost = int(self._absorbed[1][1].item())
+            if lost:
+                import warnings
+                cap = self._absorbed[2]
+                self.ABSORBED_MIN_CAPACITY = 4 * cap
+                self._new_absorbed(4 * cap)
+                self._anchor_pending = True
+                warnings.warn(f"{lost} absorbed particles exceeded the device list of {cap} per step: rho (not the "
+                              f"fields) missed their removal since the last sort; this step re-deposits rho and the "
+                              f"list grows to {4 * cap}", RuntimeWarning, stacklevel=3)
+
+    def _rho_sorted(self):
+        """called by sort(): a sort at the sorter stage (before reset_current) makes this step a real-deposit step"""
+        if self._phase == "idle":
+            self._anchor_pending = True
+        self._check_absorbed()
+
+    def _begin_deposit_step(self, force_anchor=False):
+        """the body of reset_current(): decide the mode and zero what this step deposits"""
+        anchor = force_anchor or not (self.rho_continuity and self._rho_available()) or self.rho_continuity_blocked \
+            or self._anchor_pending or self._rho_sort_due()
+        if not anchor and self._prev_phase == "anchor" and self._absorbed is not None and self.absorb:
+            # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval)
+            anchor = int(self._absorbed[1][0].item()) > self._absorbed[2]
+        self._anchor_pending = False
+        g, st = self._g(), self.stream
+        if anchor:
+            check(self.L.lpa_reset_current(g, st), "lpa_reset_current")
+            if self._absorbed is not None:
+                self._absorbed[1][:1].zero_()       # the real deposit does not contain them anyway
+        else:
+            if self.absorb:
+                lst, cnt, cap = self._absorbed_bufs()
+                # the particles last step's kernels absorbed: their charge leaves rho now (it travels through this
+                # step's fold like any deposit)
+                check(self.L.lpa_rho_absorbed(g, lst.data_ptr(), cnt.data_ptr(), cap, st), "lpa_rho_absorbed")
+            check(self.L.lpa_reset_j(g, st), "lpa_reset_j")
+        self._phase = self._prev_phase = "anchor" if anchor else "continuity"
+        self.rho_steps[self._phase] += 1
+        self._dt_step = 0.0          # set by the pushes of this step
+
+    def _push_flags(self, pp, dt, absorbing):
+        """rho mode of one push launch (``pp``: lpa_push_params)"""
+        self._dt_step = dt
+        if self._no_rho:
+            pp.flags = _lib.LPA_PUSH_NO_RHO
+        if absorbing and self.rho_continuity and self._rho_available():
+            # absorbed particles are reported in every step: the next one may carry this step's rho over
+            lst, cnt, cap = self._absorbed_bufs()
+            pp.absorbed, pp.absorbed_count, pp.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
+
+    def _finish_rho(self):
+        """after the currents were folded: rho^{n+1} = rho^n - dt div J on a continuity step"""
+        phase, self._phase = self._phase, "idle"
+        if phase != "continuity" or self._dt_step <= 0.0:     # (no push ran: J = 0, rho stays)
+            return
+        left = None
+        if self.comm.size > 1:
+            # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step
+            send = self._rho_last_jx_plane().reshape(-1)
+            if self._jx_plane is None:
+                self._jx_plane = torch.zeros_like(send)
+                self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
+            self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
+            left = self._jx_plane if self.comm.has_left else None
+        check(self.L.lpa_rho_continuity(self._g(), self._dt_step, self.local_axes, int(self.comm.size > 1),
+                                        left.data_ptr() if left is not None else None, self.stream),
+              "lpa_rho_continuity")

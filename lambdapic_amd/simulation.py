@@ -585,10 +585,13 @@ class Simulation:
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
         # host callbacks may read ex_part..bz_part
         self.engine.write_part_eb = any(not getattr(cb, "device_native", False) for cb in callbacks or [])
+        unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
+        # rho between two sorts comes from the continuity equation (rho.py) unless a callback reads per-species rho
+        # between the species' deposits, or the split path deposits with the standalone kernel
+        self.engine.rho_continuity_blocked = bool(table.get("current_deposition")) or not unified
         self._run_stage(table, "init")
         # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
-        unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         for self.istep in range(self.itime, self.itime + nsteps):
             self._run_stage(table, "start")

@@ -41,9 +41,32 @@ def test_struct_layout_matches_header():
     # field counts / sizes of the POD structs (x86-64 SysV, natural alignment)
     assert ctypes.sizeof(_lib.lpa_grid) == 4 * 4 + 6 * 8 + 10 * 8
     assert ctypes.sizeof(_lib.lpa_particles) == 8 + 8 * 8 + 6 * 8 + 8 + 8
-    assert ctypes.sizeof(_lib.lpa_push_params) == 3 * 8 + 8 + 12 * 8
+    assert ctypes.sizeof(_lib.lpa_push_params) == 3 * 8 + 8 + 12 * 8 + 3 * 8      # wrap + flags share 8 bytes
     # 2 i32, i64, 2 i32, 5 pointers, 2 i32, 8 pointers, 5 pointers, 2 i32
     assert ctypes.sizeof(_lib.lpa_tiling) == 8 + 8 + 8 + 5 * 8 + 8 + 8 * 8 + 5 * 8 + 8
+
+
+def test_struct_layout_matches_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every struct of the header as gcc lays them out == the ctypes mirror"""
+    import subprocess
+    structs = {"lpa_grid": _lib.lpa_grid, "lpa_particles": _lib.lpa_particles, "lpa_tiling": _lib.lpa_tiling,
+               "lpa_push_params": _lib.lpa_push_params, "lpa_cpml_axis": _lib.lpa_cpml_axis,
+               "lpa_free_slots": _lib.lpa_free_slots}
+    lines = []
+    for name, cls in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in cls._fields_:
+            lines.append(f'printf("{name}.{f[0]} %zu\\n", offsetof({name}, {f[0]}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lambdapic_amd.h"\nint main(void) {\n'
+                   + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(out[name]) == ctypes.sizeof(cls), name
+        for f in cls._fields_:
+            assert int(out[f"{name}.{f[0]}"]) == getattr(cls, f[0]).offset, (name, f[0])
 
 
 def test_bad_arguments_are_reported_not_crashed():

@@ -140,6 +140,7 @@ def test_tiled_equals_global_and_conserves_charge_full_size():
     assert res.abs().max().item() <= 1e-10 * rho.abs().max().item() / dt
 
 
+@pytest.mark.k1_variants
 def test_in_kernel_reseat_keeps_particles_and_physics():
     """the in-kernel cell-index sort (`lpa_tiling.slot_class`, off by default) permutes particles between slots
     inside a work block every step: nothing may be lost, doubled or detached from its id, and the physics must not
@@ -192,3 +193,68 @@ def test_in_kernel_reseat_keeps_particles_and_physics():
     assert np.array_equal(da["_id"].view(np.uint64)[oa], np.arange(n, dtype=np.uint64) + 1000)
     for k in ("x", "y", "ux", "uy", "uz", "inv_gamma", "w"):
         np.testing.assert_allclose(da[k][oa], db[k][ob], rtol=1e-9, atol=1e-9 * np.abs(db[k]).max(), err_msg=k)
+
+
+# ---- rho from the continuity equation (LPA_PUSH_NO_RHO + lpa_rho_continuity) against the deposited rho ------------
+@pytest.mark.parametrize("bc", ["periodic", "pml", "x-pml"])
+def test_rho_from_continuity_matches_deposited_rho(bc):
+    """Two engines, same particles, same steps: one deposits rho in every step (the reference's kernel,
+    current/current_deposit.h:180), the other only on sort steps and advances it with the discrete continuity equation in
+    between (LPA_PUSH_NO_RHO, lpa_rho_continuity; rho.py).  rho agrees on every node of the padded array to 1e-12 of its
+    maximum at every step.  'pml' / 'x-pml' (x open, y periodic: the absorbed particles' charge crosses the y fold):
+    hot electrons are absorbed at the open faces and their charge has to leave rho one step after their last deposit"""
+    from lambdapic_amd.particles import ParticlesBase
+    nx, ny = 48, 64
+    dx = dy = 4e-8
+    c = 299792458.0
+    dt = 0.95 / (c * np.sqrt(dx ** -2 + dy ** -2))
+    per = "periodic"
+    bcs = {"periodic": dict(xmin=per, xmax=per, ymin=per, ymax=per), "pml": dict(xmin="pml", xmax="pml", ymin="pml", ymax="pml"),
+           "x-pml": dict(xmin="pml", xmax="pml", ymin=per, ymax=per)}[bc]
+    qe, me = -oracle.E_CHARGE, oracle.M_E
+    x_lo, x_hi = (0, nx) if bc == "periodic" else (7, 41)      # 3 cells inside the absorbing bounds
+    y_lo, y_hi = (7, 57) if bc == "pml" else (0, ny)
+
+    def block(rng, ppc, uth):
+        cells = np.array([(i, j) for i in range(x_lo, x_hi) for j in range(y_lo, y_hi)])
+        n = len(cells) * ppc
+        p = ParticlesBase(0, 0)
+        p.initialize(n)
+        pos = (np.repeat(cells, ppc, axis=0) + rng.uniform(-0.5, 0.5, (n, 2))) * dx
+        p.x[:], p.y[:] = pos.T
+        for a in ("ux", "uy", "uz"):
+            getattr(p, a)[:] = rng.normal(size=n) * uth
+        p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+        p.w[:] = 1e27 * dx * dy / ppc
+        return p
+
+    def make(cont):
+        eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", sort_interval=6, block_particles=1024,
+                          boundary_conditions=bcs, cpml_thickness=4)
+        eng.rho_continuity = cont
+        rng = np.random.default_rng(9)
+        for k, (q, m, ppc, uth) in enumerate(((qe, me, 12, 0.4), (-qe, 1836 * me, 6, 0.002))):
+            p = block(rng, ppc, uth)
+            eng.add_species(q, m, capacity=2 * p.npart)
+            eng.species[k].upload([p])
+        return eng
+
+    a, b = make(True), make(False)
+    n_e = a.species[0].n
+    assert a.rho_mode() == "continuity" and b.rho_mode() == "deposited"
+    for it in range(20):
+        a.step(dt)
+        b.step(dt)
+        ra, rb = a.grid.view("rho"), b.grid.view("rho")
+        err = (ra - rb).abs().max().item() / rb.abs().max().item()
+        assert err <= 1e-12, (it, err)
+        for name in ("jx", "jy", "jz", "ex", "ey", "bz"):
+            va, vb = a.grid.view(name), b.grid.view(name)
+            assert (va - vb).abs().max().item() <= 1e-11 * vb.abs().max().item(), (it, name)
+    da, db = a.diagnostics(), b.diagnostics()
+    assert da["nalive"] == db["nalive"]
+    assert a.rho_steps == {"anchor": 4, "continuity": 16} and b.rho_steps["continuity"] == 0
+    if bc == "periodic":
+        assert da["nalive"][0] == n_e
+    else:
+        assert da["nalive"][0] < n_e - 100           # electrons were absorbed: the correction path ran

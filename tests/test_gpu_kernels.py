@@ -227,6 +227,7 @@ def test_boundary_wrap_deposits_through_the_torus():
     assert_close(p.x, po.x, 1e-13)
 
 
+@pytest.mark.k1_variants
 def test_empty_and_all_dead_inputs():
     dx = dy = 1e-8
     f = Fields2D(8, 8, dx, dy, 0.0, 0.0, 3)
@@ -265,6 +266,7 @@ def test_split_kernels_vs_oracle():
     assert not f.jx.any() and not f.rho.any()
 
 
+@pytest.mark.k1_variants
 def test_wave_reduce_scatter_selftest():
     """the DPP / permlane reduce-scatter used by the tiled deposit: lane L must end with the sum
     over lanes of value L (all 64 x 64 inputs distinct)"""
@@ -373,6 +375,7 @@ def test_cell_sort_properties(order):
         assert np.array_equal(before[a][ib], out3[a][ia])
 
 
+@pytest.mark.k1_variants
 def test_staggered_constant_fields_known_answer():
     """reference tests/core/interpolation/test_field_interpolation_2d.py:322-359: constant fields are
     gathered exactly wherever the particle sits, despite the Yee staggering (TSC weights sum to one on the
@@ -447,6 +450,7 @@ def test_known_answer_charge_and_current_3d():
         assert f.jz.sum() == pytest.approx(QE * n * v[2], rel=1e-10)
 
 
+@pytest.mark.k1_variants
 def test_padded_order_layout():
     """LPA_ORDER_PADDED: in every tile the leading ranks that at least 192 of the 256 cells have are FULL stripes --
     slot = tile start + rank * 256 + cell, holes (NaN) where a cell has no such particle --, tile starts are
@@ -507,6 +511,7 @@ def test_padded_order_layout():
     check()
 
 
+@pytest.mark.k1_variants
 def test_wave_shift_selftest():
     """DPP wave_shr:1 / wave_shl:1 as the cooperative deposit uses them: lane l reads lane l - 1 / l + 1 across the
     four 16-lane rows of the wave, the ends read zero"""
@@ -523,6 +528,7 @@ def test_wave_shift_selftest():
     assert np.array_equal(out[64:], np.concatenate([a[1:], [0.0]]))
 
 
+@pytest.mark.k1_variants
 def test_cooperative_deposit_vs_oracle():
     """the cooperative deposit (LPA_ORDER_PADDED store, neighbour exchange, row-end lanes, parked misfits) against the
     oracle's fused kernel on a multi-tile patch: hot enough for cell changes, ragged cell counts, dead slots"""

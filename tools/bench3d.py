@@ -18,12 +18,15 @@ ap.add_argument("--global", dest="glob", action="store_true"); ap.add_argument("
 ap.add_argument("--block-particles", type=int, default=4096)
 ap.add_argument("--order", default="striped", choices=["striped", "padded"])
 ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (gamma beta)")
+ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
+                help="rho between two sorts: from the continuity equation (default) or deposited in every step")
 a = ap.parse_args()
 lam = 0.8e-6
 dx, dy, dz = lam / 20, lam / 10, lam / 10                 # example/laser-target-3d.py:26-31
 dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
 eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3, tiled=not a.glob, sort_interval=a.sort_interval,
                   block_particles=a.block_particles)
+eng.rho_continuity = a.rho == "continuity"
 n = a.nx * a.ny * a.nz * a.ppc
 if a.order == "padded":
     eng.order = _lib.LPA_ORDER_PADDED
@@ -54,7 +57,8 @@ ov = int(eng.species[0]["ws"]["count"].item()) if eng.species[0]["ws"] else None
 k_ms = sum(x.elapsed_time(y) for x, y in eng.kernel_events) / a.steps if eng.kernel_events else None
 print(json.dumps({"metric": "particle-updates/sec (3-D, %s kernel)" % ("global-memory" if a.glob else "LDS-tiled"),
                   "k1_3d_ms": k_ms, "k1_3d_frac_of_hbm": (121.0 * n / (k_ms * 1e-3) / 8e12) if k_ms else None,
-                  "overflow_last_step": ov, "sort_interval": a.sort_interval, "value": n * a.steps / el,
+                  "overflow_last_step": ov, "sort_interval": a.sort_interval, "rho": eng.rho_mode(),
+                  "rho_steps": eng.rho_steps, "value": n * a.steps / el,
                   "ms_per_step": 1e3 * el / a.steps, "particles": n, "cells": [a.nx, a.ny, a.nz],
                   "algorithmic_GBps": (121.0 * n) * a.steps / el / 1e9, "alive": d["nalive"][0],
                   "charge_rel_err": abs(d["charge"] / (n * float(data[7][0]) * -constants.E_CHARGE) - 1)}))
