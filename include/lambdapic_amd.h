@@ -359,8 +359,13 @@ int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_par
 int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
                       int32_t order, lpa_tiling *out, void *stream);
-/* number of live particles after the last sort (device pointer inside the workspace) */
+/* number of live particles after the last sort (device pointer inside the workspace); for LPA_ORDER_PADDED: the slots
+ * of the order (live + holes + the 64-slot rounding of every tile -- up to 4/3 n + 63 per tile) */
 const int32_t *lpa_sort_live_count(void *workspace);
+/* device flag of the last sort, non-zero = NOTHING was moved: bit 0 = the sorted order needs more slots than dst->n
+ * (only a padded order can: size its stores for 4/3 n + 64 per tile), bit 1 = more work blocks than the table holds.
+ * The caller reads it together with the live count and treats it as an error. */
+const int32_t *lpa_sort_overflow(void *workspace);
 
 /* ---- particle ownership along x for the slab decomposition (replaces get_npart_to_extend_2d +
  *      fill_particles_from_boundary_2d, core/patch/sync_particles_2d.c:204-518 and the MPI twins

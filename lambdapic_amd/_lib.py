@@ -129,6 +129,7 @@ SIGNATURES = {
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
+    "lpa_sort_overflow": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp, _vp]),
     "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp, _vp]),
     "lpa_migrate_unpack_tiled": (_i, [_P, _G, _T, _FS, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
@@ -194,6 +195,24 @@ def lib():
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     _LIB = _bind(LIB_PATH)
     return _LIB
+
+
+def sort_result(L, wsbuf):
+    """live count (slots, for a padded order) of the tile sort that just ran through workspace ``wsbuf`` (a device
+    uint8 tensor); raises when the device refused the sort (``lpa_sort_overflow``).  One host sync."""
+    ptr = wsbuf.data_ptr()
+    hdr = wsbuf[:64].view(_torch().int32).tolist()
+    ovf = hdr[(L.lpa_sort_overflow(ptr) - ptr) // 4]
+    if ovf:
+        raise LpaError("tile sort refused (nothing was moved): " +
+                       ("the sorted order needs more slots than the destination holds -- a padded order stores up to "
+                        "4/3 n + 64 slots per tile" if ovf & 1 else "work-block table too small"))
+    return hdr[(L.lpa_sort_live_count(ptr) - ptr) // 4]
+
+
+def _torch():
+    import torch
+    return torch
 
 
 def check(status: int, what: str = ""):

@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         // the slot's class: issued here, consumed after the Boris rotation (not carried across iterations: the
         // loop has no VGPR to spare at 4 waves per SIMD)
         [[maybe_unused]] uint32_t ccls = 0;
-        if (RELOC && !RL_INIT && valid) ccls = rl.cls[ip];
+        if (RELOC && !RL_INIT && valid) ccls = rl.cls[ip] & 31u;   // (slots never classified hold whatever: 5 bits)
         {
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {

@@ -130,8 +130,15 @@ constexpr int BS_CHUNK = 4096;   // slots per workgroup of the inheritance pass 
 // bucket of a LIVE particle (core/sort/cpu2d.c:20-43, cpu3d.c:22-47): floor((r - r0) / d) per axis; out of
 // range -> last bucket (or clamped when the x order is mirrored)
 __device__ __forceinline__ long bucket_of(double x, double y, double z, const BucketGeom &g) {
-    long ix = (long)floor((x - g.x0) / g.dx), iy = (long)floor((y - g.y0) / g.dy);
-    long iz = g.nz > 1 ? (long)floor((z - g.z0) / g.dz) : 0;
+    // a live slot with a non-finite position: the reference's cast of NaN / inf to a C integer yields the most
+    // negative value on x86-64 (cvttsd2si), i.e. out of range -> last bucket (cpu2d.c:38-42), or index 0 of that axis
+    // after the clamp of the mirrored order (:25-32); the device conversion would give 0 / saturate -- made explicit
+    auto cell = [](double r, double r0, double d) {
+        const double c = floor((r - r0) / d);
+        return isfinite(c) ? (long)c : (long)0x8000000000000000ull;
+    };
+    long ix = cell(x, g.x0, g.dx), iy = cell(y, g.y0, g.dy);
+    long iz = g.nz > 1 ? cell(z, g.z0, g.dz) : 0;
     if (g.reverse_x) {
         ix = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
         iy = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
@@ -310,6 +317,10 @@ extern "C" int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead
                     nattrs >= 0 && nattrs <= 32 && (nattrs == 0 || attrs) && bucket_count && bucket_bound_min &&
                     bucket_bound_max && workspace && nbuf && (npart == 0 || (x && y && is_dead)),
                 "lpa_bucket_sort: bad args");
+    // validated before anything is launched: a null entry found half way would leave the attributes it follows
+    // permuted and the rest (and is_dead) not
+    LPA_REQUIRE(nattrs == 0 || attrs, "lpa_bucket_sort: null attribute list");
+    for (int a = 0; a < nattrs; a++) LPA_REQUIRE(attrs[a], "lpa_bucket_sort: null attribute %d", a);
     const int64_t nbin = nx * ny * nz;
     BucketWs w;
     const int64_t need = bucket_ws_layout(npart, nbin, (char *)workspace, &w);
@@ -352,7 +363,6 @@ extern "C" int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead
         bool has_x = false, has_y = false, has_z = false;
         // `attrs` is a HOST array of device pointers (like the reference's attrs list)
         for (int a = 0; a < nattrs; a++) {
-            LPA_REQUIRE(attrs[a], "lpa_bucket_sort: null attribute");
             has_x = has_x || attrs[a] == x; has_y = has_y || attrs[a] == y; has_z = has_z || attrs[a] == z;
             move(attrs[a]);
         }

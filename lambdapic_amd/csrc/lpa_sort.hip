@@ -36,8 +36,13 @@ struct SortHdr {      // first 64 bytes of the workspace
     // the tiling the SOURCE of the running sort was left in by the previous sort through this
     // workspace (the engines ping-pong two stores): a work partition for the tile-staged scatter
     int32_t magic, prev_ntiles, prev_n, prev_valid;
-    int32_t pad[10];
+    // set by k_tile_scan, read by the scatter kernels (which then move nothing) and by the caller after the sort:
+    // bit 0 = the slots of the sorted order (live + the holes and 64-slot rounding of LPA_ORDER_PADDED) exceed the
+    // destination's capacity; bit 1 = more work blocks than the table holds
+    int32_t overflow;
+    int32_t pad[9];
 };
+constexpr int32_t SORT_OVF_SLOTS = 1, SORT_OVF_BLOCKS = 2;
 constexpr int32_t SORT_MAGIC = 0x4c504131;
 
 struct SortWs {
@@ -95,6 +100,10 @@ extern "C" int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity)
 
 extern "C" const int32_t *lpa_sort_live_count(void *workspace) {
     return workspace ? &((SortHdr *)workspace)->n_live : nullptr;
+}
+
+extern "C" const int32_t *lpa_sort_overflow(void *workspace) {
+    return workspace ? &((SortHdr *)workspace)->overflow : nullptr;
 }
 
 constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;
@@ -207,7 +216,8 @@ __global__ void __launch_bounds__(256) k_tile_sum(const int32_t *__restrict__ ce
 // one workgroup: exclusive scan of the tile totals + the work-block table
 __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *tile_cnt, int32_t *tile_off,
                                                     int32_t *blk_tile, int32_t *blk_begin, int32_t *blk_end,
-                                                    SortHdr *hdr, int block_particles, int max_blocks) {
+                                                    SortHdr *hdr, int block_particles, int max_blocks,
+                                                    long dst_capacity) {
     __shared__ int32_t s_part[1024], s_blk[1024];
     int tid = threadIdx.x;
     int per = (ntiles + 1023) / 1024;
@@ -248,6 +258,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
         tile_off[ntiles] = s_part[1023];
         hdr->n_live = s_part[1023];
         hdr->n_blocks = min(s_blk[1023], max_blocks);
+        // a PADDED order stores up to 4/3 n + 63 slots per tile: it may not fit a destination sized for the live
+        // count; nothing is scattered then (every slot beyond the capacity would be an out-of-bounds store)
+        hdr->overflow = ((long)s_part[1023] > dst_capacity ? SORT_OVF_SLOTS : 0) |
+                        (s_blk[1023] > max_blocks ? SORT_OVF_BLOCKS : 0);
     }
 }
 
@@ -340,6 +354,7 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
                                                  const SortHdr *hdr) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
+    if (hdr->overflow) return;                         // the destination cannot hold the order: see SortHdr
     if (hdr->prev_valid && ip < hdr->prev_n) return;   // moved by k_scatter_tiled
     uint32_t ck = key[ip];
     if (ck == KEY_DEAD) return;
@@ -424,7 +439,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped) {
     __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
-    if (!hdr->prev_valid) return;
+    if (!hdr->prev_valid || hdr->overflow) return;
     const int t = blockIdx.x;
     const int sb = tile_off_prev[t], se = tile_off_prev[t + 1];
     const int db0 = tile_off[t], de0 = tile_off[t + 1];   // destination range of the same tile
@@ -513,7 +528,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     lpa_grid gg = *g;
     if (dim == 2) gg.nz = 1;
     SortWs w;
-    int64_t need = ws_layout(&gg, src->n, block_particles, (char *)workspace, &w);
+    // the work-block table is sized for the slots the DESTINATION can hold (a padded order has more slots than src->n)
+    int64_t need = ws_layout(&gg, dst->n, block_particles, (char *)workspace, &w);
     if (need > workspace_bytes) {
         lpa_set_error("%s: workspace %lld B < %lld B", name, (long long)workspace_bytes, (long long)need);
         return LPA_ERR_WORKSPACE;
@@ -565,7 +581,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         LPA_CHECK_LAUNCH("k_tile_sum");
     }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.ntiles, w.tile_cnt, w.tile_off, w.blk_tile,
-                       w.blk_begin, w.blk_end, w.hdr, (int)block_particles, w.max_blocks);
+                       w.blk_begin, w.blk_end, w.hdr, (int)block_particles, w.max_blocks, (long)dst->n);
     LPA_CHECK_LAUNCH("k_tile_scan");
     if (order == LPA_ORDER_STRIPED)
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre,

@@ -414,15 +414,13 @@ class PicEngine2D(RhoContinuityMixin):
         check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), bp, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
-        hdr = ws["sort"][:8].view(torch.int32)
-        n_live = int(hdr[0].item())                      # sync point (once per sort_interval steps)
+        n_live = _lib.sort_result(self.L, ws["sort"])    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]
         if arrivals > ws["area"]:
             raise _lib.LpaError(f"arrival area overflow: {arrivals} > {ws['area']} (raise migrate_capacity)")
         if surplus > 0:
-            raise _lib.LpaError(f"migration message overflow: {surplus} leavers beyond migrate_capacity="
-                                f"{self.migrate_capacity} since the last sort stayed outside the slab (raise migrate_capacity)")
+            raise _lib.LpaError(self._surplus_message(surplus))
         sp.cur = 1 - sp.cur
         sp.n_sorted = n_live
         area = ws["area"]
@@ -443,7 +441,7 @@ class PicEngine2D(RhoContinuityMixin):
         # classes
         if self.reseat and self.defer_crossers and self.order == _lib.LPA_ORDER_STRIPED:
             if ws.get("cls") is None or ws["cls"].numel() < sp.capacity:
-                ws["cls"] = torch.empty(sp.capacity, dtype=torch.int16, device=self.device)
+                ws["cls"] = torch.zeros(sp.capacity, dtype=torch.int16, device=self.device)
             ws["tiling"].scratch[7] = idle.id.data_ptr()
             ws["tiling"].slot_class = ws["cls"].data_ptr()
             ws["tiling"].class_init = 1
@@ -877,11 +875,27 @@ class PicEngine2D(RhoContinuityMixin):
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(E)
 
+    def _surplus_message(self, surplus):
+        return (f"migration message overflow: {surplus} leaver-steps beyond migrate_capacity={self.migrate_capacity} "
+                "(a leaver that did not fit stays outside the slab, deposits through the torus wrap and is counted "
+                "again every step until it leaves; raise migrate_capacity)")
+
+    def check_migration(self):
+        """leavers that did not fit a face message since the last sort (device counter, one host read): checked at
+        every sort and by ``diagnostics()`` -- also when the sorter is disabled or its interval is long"""
+        for sp in self.species:
+            ws = self._ws.get(id(sp))
+            if ws is not None and self.comm.size > 1:
+                surplus = int(ws["counters"][3].item())
+                if surplus > 0:
+                    raise _lib.LpaError(self._surplus_message(surplus))
+
     # ---- diagnostics ------------------------------------------------------------------------------
     def diagnostics(self, reduce=False):
         """dict of field energy (E, B parts), total charge, current sums, kinetic energy and live
         count per species -- local to this rank; ``reduce=True`` sums over the ranks (one all-reduce)."""
         st = self.stream
+        self.check_migration()
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), st), "diag")
         out = {}

@@ -24,6 +24,7 @@ from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import restore_device, to_host
 from .dist import SlabComm, exchange_faces
+from .engine import PicEngine2D
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 from .rho import RhoContinuityMixin
 
@@ -357,14 +358,13 @@ class PicEngine3D(RhoContinuityMixin):
         check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), self.block_particles, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
-        n_live = int(ws["sort"][:4].view(torch.int32)[0].item())
+        n_live = _lib.sort_result(self.L, ws["sort"])
         area = self.arrival_area()
         cnts = ws["counters"].tolist()
         if cnts[1] > area:
             raise _lib.LpaError("arrival area overflow (raise migrate_capacity)")
         if cnts[3] > 0:
-            raise _lib.LpaError(f"migration message overflow: {cnts[3]} leavers beyond migrate_capacity="
-                                f"{self.migrate_capacity} since the last sort stayed outside the slab (raise migrate_capacity)")
+            raise _lib.LpaError(self._surplus_message(cnts[3]))
         if n_live + area > cap:
             raise _lib.LpaError(f"particle capacity {cap} < live {n_live} + arrival area {area}")
         sp["data"], sp["alt"] = sp["alt"], sp["data"]
@@ -815,8 +815,19 @@ class PicEngine3D(RhoContinuityMixin):
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)
 
+    _surplus_message = PicEngine2D._surplus_message
+
+    def check_migration(self):
+        """see PicEngine2D.check_migration"""
+        for sp in self.species:
+            if sp["ws"] is not None and self.comm.size > 1:
+                surplus = int(sp["ws"]["counters"][3].item())
+                if surplus > 0:
+                    raise _lib.LpaError(self._surplus_message(surplus))
+
     def diagnostics(self, reduce=False):
         """this rank's share; ``reduce=True`` sums over the ranks (one all-reduce)"""
+        self.check_migration()
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), self.stream), "diag")
         f = self._diag.cpu().numpy().copy()

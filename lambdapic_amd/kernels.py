@@ -159,7 +159,7 @@ def _unified_tiled_patch(L, dev, g, p, pp, block_particles=1024, order=_lib.LPA_
     st = _stream(dev)
     check(L.lpa_sort_tiles_2d(g.ref(), C.byref(ps), C.byref(pd), ws.data_ptr(), nbytes, block_particles,
                               order, C.byref(tiling), st), "lpa_sort_tiles_2d")
-    n_slots = int(ws[:4].view(torch.int32)[0].item())          # live particles (+ holes of the padded order)
+    n_slots = _lib.sort_result(L, ws)                          # live particles (+ holes of the padded order)
     assert n_slots == nl or (padded and nl <= n_slots <= cap)
     tiling.n_sorted = n_slots
     pd.n = n_slots

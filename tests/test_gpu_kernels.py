@@ -559,3 +559,36 @@ def test_cooperative_deposit_vs_oracle():
         assert_close(getattr(p, a)[live], getattr(po, a)[live], 1e-12, what=a)
     for a in ("rho", "jx", "jy", "jz"):
         assert_close(getattr(f, a), getattr(fo, a), 1e-12, what=a)
+
+
+@pytest.mark.k1_variants
+def test_padded_sort_refuses_a_store_that_is_too_small():
+    """LPA_ORDER_PADDED stores full stripes with holes and rounds every tile to 64 slots: up to 4/3 n + 63 per tile.  A
+    destination sized for the live count cannot hold that; the device compares the slot total with dst->n after its
+    scan, moves NOTHING and flags the sort (lpa_sort_overflow) instead of scattering past the arrays"""
+    from lambdapic_amd import _lib
+    from lambdapic_amd.engine import PicEngine2D
+    nx, ny, ppc = 32, 64, 12
+    dx = dy = 4e-8
+    rng = np.random.default_rng(5)
+    n = nx * ny * ppc
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx          # Poisson occupancies: plenty of holes in the full stripes
+    p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    p.inv_gamma[:] = 1.0
+    p.w[:] = 1.0
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024, order=2)
+    eng.add_species(QE, ME, capacity=n + 64)            # fits the live particles, not their padded order
+    eng.species[0].upload([p])
+    before = eng.species[0].download()
+    with pytest.raises(_lib.LpaError, match="more slots"):
+        eng.sort(0)
+    after = eng.species[0].download()                   # the source store is untouched and still current
+    for k in before:
+        assert np.array_equal(before[k].view(np.uint64), after[k].view(np.uint64)), k
+    roomy = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024, order=2)
+    roomy.add_species(QE, ME, capacity=2 * n)
+    roomy.species[0].upload([p])
+    roomy.sort(0)
+    assert roomy.species[0].n_sorted >= n and roomy.diagnostics()["nalive"][0] == n
