@@ -467,6 +467,49 @@ int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead, double *c
                     int64_t *bucket_bound_min, int64_t *bucket_bound_max, void *workspace,
                     int64_t workspace_bytes, int64_t *nbuf, void *stream);
 
+/* ---- one time step of ONE slab in one host call: the no-callback stage sequence of Simulation.run
+ *      (simulation/simulation.py:937-1122) -- E half step + E guards, B half step + B guards, current reset, fused push +
+ *      deposit of every species (tiled kernel + overflow list + loose particles, or the global kernel for an unsorted
+ *      store), current fold, B half step, ['_laser' stage: between LPA_STAGE_B2 and LPA_STAGE_B2_GUARD the caller may
+ *      inject], B guards, E half step + E guards.  Enqueues exactly the launches the per-stage entry points above
+ *      would, in that order; `first_stage .. last_stage` (inclusive) selects a sub-range, so a caller with a callback
+ *      at some stage splits the step there.  Not included: the sort (it needs the host for the live count -- the
+ *      caller sorts before the step when due), slab-to-slab exchanges (single slab only) and anything a callback does.
+ *      `continuity` != 0: this is a step between two real deposits, see LPA_PUSH_NO_RHO (the kernels skip rho,
+ *      LPA_STAGE_RESET keeps it and takes out the absorbed particles' charge, LPA_STAGE_FOLD advances it).
+ *      ev_start / ev_stop (optional): hipEvent_t recorded on `stream` around the species' tiled launch. */
+typedef struct {
+    lpa_particles p;            /* the store as of this step (p.n = slots in use) */
+    const lpa_tiling *t;        /* NULL: unsorted store, everything through the global kernel */
+    int64_t n_sorted;           /* slots [0, n_sorted) are tile ordered, [n_sorted, p.n) loose */
+    lpa_push_params pp;         /* q, m, wrap, lo / hi, alo / ahi; dt, flags and the absorbed list are set by lpa_step */
+    uint32_t *overflow, *overflow_count;
+    void *ev_start, *ev_stop;
+} lpa_step_species;
+
+typedef struct {
+    lpa_grid grid;
+    int32_t dim;                /* 2 or 3 */
+    int32_t local_axes;         /* bit a: axis a is periodic inside this slab (guard wrap, current fold) */
+    double dt, eps0;
+    const lpa_cpml_axis *e_axes[3], *b_axes[3];   /* all NULL: plain Yee update; else the fused CPML descriptors */
+    int32_t nspecies, continuity;
+    const lpa_step_species *species;
+    double *absorbed;           /* see lpa_push_params.absorbed (NULL: no face absorbs) */
+    uint32_t *absorbed_count;
+    int64_t absorbed_capacity;
+} lpa_step_desc;
+
+#define LPA_STAGE_E1 0
+#define LPA_STAGE_B1 1
+#define LPA_STAGE_RESET 2
+#define LPA_STAGE_PUSH 3
+#define LPA_STAGE_FOLD 4
+#define LPA_STAGE_B2 5
+#define LPA_STAGE_B2_GUARD 6
+#define LPA_STAGE_E2 7
+int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage, void *stream);
+
 /* ---- diagnostics the parity contract is stated on (field energy, kinetic energy, total
  *      charge; reference tests/test_numerical_heating.py:19-50).  out[] is device memory and is
  *      accumulated into (zero it first).

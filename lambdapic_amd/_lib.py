@@ -74,6 +74,21 @@ class lpa_free_slots(C.Structure):
     _fields_ = [("count", C.c_void_p), ("slot", C.c_void_p), ("edge_cols", C.c_int32), ("depth", C.c_int32)]
 
 
+class lpa_step_species(C.Structure):
+    _fields_ = [("p", lpa_particles), ("t", C.POINTER(lpa_tiling)), ("n_sorted", C.c_int64), ("pp", lpa_push_params),
+                ("overflow", C.c_void_p), ("overflow_count", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+
+
+class lpa_step_desc(C.Structure):
+    _fields_ = [("grid", lpa_grid), ("dim", C.c_int32), ("local_axes", C.c_int32), ("dt", C.c_double), ("eps0", C.c_double),
+                ("e_axes", C.POINTER(lpa_cpml_axis) * 3), ("b_axes", C.POINTER(lpa_cpml_axis) * 3),
+                ("nspecies", C.c_int32), ("continuity", C.c_int32), ("species", C.POINTER(lpa_step_species)),
+                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64)]
+
+
+LPA_STAGE_E1, LPA_STAGE_B1, LPA_STAGE_RESET, LPA_STAGE_PUSH, LPA_STAGE_FOLD, LPA_STAGE_B2, LPA_STAGE_B2_GUARD, \
+    LPA_STAGE_E2 = range(8)
+
 _G, _P, _T, _PP = C.POINTER(lpa_grid), C.POINTER(lpa_particles), C.POINTER(lpa_tiling), C.POINTER(lpa_push_params)
 _FS = C.POINTER(lpa_free_slots)
 _vp, _d, _i, _i64 = C.c_void_p, C.c_double, C.c_int, C.c_int64
@@ -143,6 +158,7 @@ SIGNATURES = {
     "lpa_bucket_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "lpa_bucket_sort": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int32, _i64, _i64, _i64, _i64, _d, _d, _d,
                              _d, _d, _d, C.c_int32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "lpa_step": (_i, [C.POINTER(lpa_step_desc), _i, _i, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
     "lpa_selftest_wave_reduce": (_i, [_vp, _vp, _vp]),

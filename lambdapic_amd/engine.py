@@ -31,6 +31,7 @@ from ._lib import LPA_MIG_NATTR, check, lib
 from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr, restore_device, to_host
 from .dist import SlabComm, exchange_faces
 from .rho import RhoContinuityMixin
+from .step import FusedStepMixin
 
 
 class DevicePML2D:
@@ -109,7 +110,9 @@ class DevicePML2D:
         return self._coef[k]
 
 
-class PicEngine2D(RhoContinuityMixin):
+class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
+    dim = 2
+
     def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
                  x0=0.0, y0=0.0, sort_interval=8, block_particles=8192, migrate_capacity=32768,
                  boundary_conditions=None, cpml_thickness=6, order=_lib.LPA_ORDER_STRIPED):
@@ -206,7 +209,7 @@ class PicEngine2D(RhoContinuityMixin):
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`: the reference pickles the whole Simulation) ----
     _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed", "_jx_plane",
-                  "_one")
+                  "_one", "_step_keep")
 
     def __getstate__(self):
         """everything but handles and scratch: the library handle, sort workspaces (and with them the tilings),
@@ -846,8 +849,37 @@ class PicEngine2D(RhoContinuityMixin):
             else torch.zeros(k, dtype=torch.int64)
         self._append_device(sp, rows.to(self.device), ids.to(self.device))
 
+    # ---- hooks of FusedStepMixin (step.py: the whole stage sequence in one lpa_step call) -------------
+    def _grid_struct(self):
+        return self.grid.c
+
+    def sort_due_species(self):
+        return [i for i, sp in enumerate(self.species)
+                if sp.tiling is None or sp.steps_since_sort >= self.sort_interval]
+
+    def _species_entries(self, dt):
+        for sp in self.species:
+            if sp.n == 0:
+                continue
+
+            def after(sp=sp):
+                sp.steps_since_sort += 1
+                if sp.tiling is not None:
+                    sp.tiling.class_init = 0
+
+            pp = self._push_params(sp, dt)
+            pc = sp.cset.cstruct(sp.n, eb=self.write_part_eb)
+            if sp.tiling is not None and sp.n_sorted > 0:
+                ws = self._sort_ws(sp)
+                yield pc, sp.tiling, sp.n_sorted, pp, ws["overflow"], ws["counters"][0:1], after
+            else:
+                yield pc, None, 0, pp, None, None, after
+
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
     def step(self, dt, tiled=True):
+        if tiled and self.can_fuse():
+            self.step_fused(dt)
+            return
         E, B = ("ex", "ey", "ez"), ("bx", "by", "bz")
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(E)

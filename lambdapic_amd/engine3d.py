@@ -27,6 +27,7 @@ from .dist import SlabComm, exchange_faces
 from .engine import PicEngine2D
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 from .rho import RhoContinuityMixin
+from .step import FusedStepMixin
 
 ATTRS3 = ("x", "y", "z", "ux", "uy", "uz", "inv_gamma", "w")
 # the resident store is float64[NROWS3][capacity]: the eight attributes + the bit pattern of ParticlesBase._id
@@ -113,7 +114,9 @@ class DevicePML3D:
         return self._coef[k]
 
 
-class PicEngine3D(RhoContinuityMixin):
+class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
+    dim = 3
+
     def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
                  block_particles=4096, comm=None, migrate_capacity=32768, boundary_conditions=None,
                  cpml_thickness=6):
@@ -209,7 +212,7 @@ class PicEngine3D(RhoContinuityMixin):
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`) ------------------------------------------------
     _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed",
-                  "_jx_plane", "_one")
+                  "_jx_plane", "_one", "_step_keep")
 
     def __getstate__(self):
         """see PicEngine2D.__getstate__: fields and the slots in use of every store as host arrays, handles,
@@ -710,11 +713,7 @@ class PicEngine3D(RhoContinuityMixin):
         """``part``: LPA_PART_EDGE = edge tile columns + overflow list + arrival area (everything that can
         deposit into the x guard planes), LPA_PART_INTERIOR = the remaining tiles (+ their overflow)"""
         L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
-        pp = _lib.lpa_push_params()
-        pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes | self.absorb
-        for a in range(3):
-            pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.Lbox[a] - self.d[a] / 2
-            pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
+        pp = self._push_params(sp, dt)
         if self._no_rho and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
             raise _lib.LpaError("a store needs sorting inside a continuity step: call reset_current() first")
         self._push_flags(pp, dt, self.absorb)
@@ -793,9 +792,41 @@ class PicEngine3D(RhoContinuityMixin):
         self._finish_rho()
         return True
 
+    # ---- hooks of FusedStepMixin (step.py) -------------------------------------------------------------------
+    def _grid_struct(self):
+        return self.c
+
+    def sort_due_species(self):
+        if not self.tiled:
+            return []
+        return [i for i, sp in enumerate(self.species) if sp["tiling"] is None or sp["since"] >= self.sort_interval]
+
+    def _push_params(self, sp, dt):
+        pp = _lib.lpa_push_params()
+        pp.dt, pp.q, pp.m, pp.wrap = dt, sp["q"], sp["m"], self.local_axes | self.absorb
+        for a in range(3):
+            pp.lo[a], pp.hi[a] = -self.d[a] / 2, self.Lbox[a] - self.d[a] / 2
+            pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
+        return pp
+
+    def _species_entries(self, dt):
+        for sp in self.species:
+            def after(sp=sp):
+                sp["since"] += 1
+
+            pp = self._push_params(sp, dt)
+            if self.tiled and sp["tiling"] is not None:
+                ws = sp["ws"]
+                yield sp["c"], sp["tiling"], sp["n_sorted"], pp, ws["overflow"], ws["count"], after
+            else:
+                yield sp["c"], None, 0, pp, None, None, after
+
     def step(self, dt, laser=None):
         """``laser``: optional callable ``laser(engine, dt)`` run at the reference's '_laser' stage
         (between the second B half step and its guard sync, simulation.py:1098-1112)"""
+        if self.can_fuse():
+            self.step_fused(dt, laser)
+            return
         L, st, g = self.L, self.stream, self._g()
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)

@@ -106,14 +106,25 @@ class RhoContinuityMixin:
             self._anchor_pending = True
         self._check_absorbed()
 
-    def _begin_deposit_step(self, force_anchor=False):
-        """the body of reset_current(): decide the mode and zero what this step deposits"""
-        anchor = force_anchor or not (self.rho_continuity and self._rho_available()) or self.rho_continuity_blocked \
-            or self._anchor_pending or self._rho_sort_due()
-        if not anchor and self._prev_phase == "anchor" and self._absorbed is not None and self.absorb:
+    def _decide_phase(self, force_anchor=False) -> bool:
+        """rho mode of the step that starts now: True = real deposit.  Bookkeeping only, nothing is launched"""
+        enabled = self.rho_continuity and self._rho_available()
+        if enabled and self.absorb:
+            self._absorbed_bufs()            # allocated / grown between steps (growing it forces a real deposit)
+        anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending \
+            or self._rho_sort_due()
+        if not anchor and self._prev_phase == "anchor" and self.absorb:
             # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval)
             anchor = int(self._absorbed[1][0].item()) > self._absorbed[2]
         self._anchor_pending = False
+        self._phase = self._prev_phase = "anchor" if anchor else "continuity"
+        self.rho_steps[self._phase] += 1
+        self._dt_step = 0.0          # set by the pushes of this step
+        return anchor
+
+    def _begin_deposit_step(self, force_anchor=False):
+        """the body of reset_current(): decide the mode and zero what this step deposits"""
+        anchor = self._decide_phase(force_anchor)
         g, st = self._g(), self.stream
         if anchor:
             check(self.L.lpa_reset_current(g, st), "lpa_reset_current")
@@ -121,14 +132,11 @@ class RhoContinuityMixin:
                 self._absorbed[1][:1].zero_()       # the real deposit does not contain them anyway
         else:
             if self.absorb:
-                lst, cnt, cap = self._absorbed_bufs()
+                lst, cnt, cap = self._absorbed
                 # the particles last step's kernels absorbed: their charge leaves rho now (it travels through this
                 # step's fold like any deposit)
                 check(self.L.lpa_rho_absorbed(g, lst.data_ptr(), cnt.data_ptr(), cap, st), "lpa_rho_absorbed")
             check(self.L.lpa_reset_j(g, st), "lpa_reset_j")
-        self._phase = self._prev_phase = "anchor" if anchor else "continuity"
-        self.rho_steps[self._phase] += 1
-        self._dt_step = 0.0          # set by the pushes of this step
 
     def _push_flags(self, pp, dt, absorbing):
         """rho mode of one push launch (``pp``: lpa_push_params)"""

@@ -557,6 +557,31 @@ class Simulation:
         (`simulation/simulation.py:781-824`; called by RestartDump.load).  The facades here hold no array
         pointers -- every call reads the engine's current stores -- so there is nothing to re-point."""
 
+    _INNER_STAGES = ("maxwell_1", "current_deposition", "qed_create_particles")
+
+    def _fused_step(self, table, unified=True):
+        """When no callback is triggered between 'start' and '_laser' / 'maxwell_2' (the predicate the reference uses to
+        skip work around callbacks, ``has_triggered_callbacks``, `simulation/simulation.py:1493-1508`) and every facade is
+        enabled, the whole stage sequence of this step is enqueued by ONE engine call (``lpa_step``, step.py) -- two when a
+        '_laser' callback injects in between.  False: the caller walks the stages one facade call at a time."""
+        eng = self.engine
+        if not (unified and eng.can_fuse()):
+            return False
+        facades = [self.maxwell, *self.pusher, *self.sorter] + \
+            ([self.current_depositor] if hasattr(self, "current_depositor") else [])
+        if not all(f._enabled for f in facades):
+            return False
+        if any(self._triggered(table.get(st, [])) for st in self._INNER_STAGES):
+            return False
+        from . import _lib
+        lasers = bool(self._triggered(table.get("_laser", [])))
+        eng.step_stages(self.dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_B2 if lasers else _lib.LPA_STAGE_E2)
+        self.current_synced, self.ispec = True, None
+        if lasers:
+            self._run_stage(table, "_laser")
+            eng.step_stages(self.dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2)
+        return True
+
     def sync_currents(self):
         if not self.current_synced:
             self.patches.sync_currents()
@@ -595,6 +620,17 @@ class Simulation:
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         for self.istep in range(self.itime, self.itime + nsteps):
             self._run_stage(table, "start")
+            if self._fused_step(table, unified):
+                self._run_stage(table, "maxwell_2")
+                self._run_stage(table, "end")
+                if restart_cb is not None and restart_cb._dump_requested:
+                    restart_cb._call(self)
+                    return
+                self.time += self.dt
+                self.itime += 1
+                if stop_callback():
+                    return "stop by callback"
+                continue
             self.maxwell.update_efield(0.5 * self.dt)
             self.patches.sync_guard_fields(E)
             self.maxwell.update_bfield(0.5 * self.dt)

@@ -17,7 +17,7 @@ from .dist import SlabComm
 from .engine3d import ATTRS3, NROWS3, SIDES3, PicEngine3D
 from .fields import FIELD_ATTRS, Fields3D, from_device_layout, to_device_layout
 from .particles import ParticlesBase
-from .simulation import MPIFacade, Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
+from .simulation import MPIFacade, Simulation, Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
 
 
 class Patch3D:
@@ -298,6 +298,9 @@ class Simulation3D:
         (`simulation/simulation.py:781-824`; called by RestartDump.load).  The facades here hold no array
         pointers -- every call reads the engine's current stores -- so there is nothing to re-point."""
 
+    _INNER_STAGES = Simulation._INNER_STAGES
+    _fused_step = Simulation._fused_step
+
     def sync_currents(self):
         if not self.current_synced:
             self.patches.sync_currents()
@@ -332,6 +335,17 @@ class Simulation3D:
         eng = self.engine
         for self.istep in range(self.itime, self.itime + nsteps):
             self._run_stage(table, "start")
+            if self._fused_step(table):
+                self._run_stage(table, "maxwell_2")
+                self._run_stage(table, "end")
+                if restart_cb is not None and restart_cb._dump_requested:
+                    restart_cb._call(self)
+                    return
+                self.time += self.dt
+                self.itime += 1
+                if stop_callback():
+                    return "stop by callback"
+                continue
             self.maxwell.update_efield(0.5 * self.dt)
             self.patches.sync_guard_fields(E)
             self.maxwell.update_bfield(0.5 * self.dt)

@@ -51,7 +51,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
     import subprocess
     structs = {"lpa_grid": _lib.lpa_grid, "lpa_particles": _lib.lpa_particles, "lpa_tiling": _lib.lpa_tiling,
                "lpa_push_params": _lib.lpa_push_params, "lpa_cpml_axis": _lib.lpa_cpml_axis,
-               "lpa_free_slots": _lib.lpa_free_slots}
+               "lpa_free_slots": _lib.lpa_free_slots, "lpa_step_species": _lib.lpa_step_species,
+               "lpa_step_desc": _lib.lpa_step_desc}
     lines = []
     for name, cls in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

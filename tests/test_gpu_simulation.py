@@ -214,3 +214,65 @@ def test_random_seed_reproducible_loading():
     a, b, c = load(7, 2), load(7, 2), load(8, 2)
     assert np.array_equal(a, b)
     assert a.shape == c.shape and not np.array_equal(a, c)
+
+
+def test_one_call_per_step_equals_the_staged_loop():
+    """``lpa_step`` (one host call per step, two with a '_laser' callback in between) against the same run walked stage
+    by stage through the facades: laser-target with CPML on all sides, two species, a window that shifts, a device-native
+    laser at '_laser', a host callback at 'end' every 7 steps (mirrors refreshed around it), one at 'maxwell_1' every 9
+    (forces the staged path for that step).  Same fields to summation order, same particles per id."""
+    from lambdapic_amd import _lib
+    from lambdapic_amd.laser import GaussianLaser2D
+    from lambdapic_amd.simulation import MovingWindow
+
+    def run(fused):
+        nx, ny = 128, 64
+        dx = dy = LAMBDA / 16
+        sim = Simulation(nx, ny, dx, dy, npatch_x=8, npatch_y=2, cpml_thickness=6, random_seed=11, sort_interval=6)
+        nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / LAMBDA) ** 2 / constants.E_CHARGE ** 2
+        Ly = ny * dy
+        dens = lambda x, y: np.where((x > 40 * dx) & (abs(y - Ly / 2) < 20 * dy), 0.5 * nc, 0.0)
+        sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=0.02))
+        sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=2))
+        sim.initialize()
+        sim.engine.fused_step = fused
+        calls = {"lpa_step": 0, "end": 0, "maxwell_1": 0}
+        inner = sim.engine.step_stages
+
+        def counted(dt, first, last):
+            calls["lpa_step"] += 1
+            return inner(dt, first, last)
+
+        sim.engine.step_stages = counted
+
+        @callback("end", interval=7)
+        def probe(s):
+            calls["end"] += 1
+            assert s.patches[0].fields.ey.shape == (16 + 6, 32 + 6)
+
+        @callback("maxwell_1", interval=9)
+        def inner_cb(s):
+            calls["maxwell_1"] += 1
+
+        cbs = [GaussianLaser2D(a0=2.0, l0=LAMBDA, w0=1.2e-6, ctau=1.0e-6, x0=1.5e-6),
+               MovingWindow(velocity=C, start_time=0.25 * sim.Lx / C), probe, inner_cb]
+        sim.run(90, callbacks=cbs)
+        return sim, calls
+
+    a, ca = run(True)
+    b, cb = run(False)
+    assert cb["lpa_step"] == 0 and ca["end"] == cb["end"] == 13 and ca["maxwell_1"] == cb["maxwell_1"] == 10
+    # 80 of the 90 steps went through lpa_step: two calls while the laser injects, one once it is disabled (the window
+    # removed the x-min layer), none in the 10 steps with the 'maxwell_1' callback
+    assert 80 <= ca["lpa_step"] <= 160 and a.window_shifts == b.window_shifts >= 2
+    for name in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+        va, vb = a.engine.grid.view(name), b.engine.grid.view(name)
+        assert (va - vb).abs().max().item() <= 1e-9 * max(vb.abs().max().item(), 1e-300), name
+    assert a.engine.grid.view("ey").abs().max().item() > 0
+    assert a.engine.rho_steps == b.engine.rho_steps and a.engine.rho_steps["continuity"] > 40
+    for sa, sb in zip(a.engine.species, b.engine.species):
+        da, db = sa.download(), sb.download()
+        oa, ob = np.argsort(da["_id"].view(np.uint64)), np.argsort(db["_id"].view(np.uint64))
+        assert np.array_equal(da["_id"].view(np.uint64)[oa], db["_id"].view(np.uint64)[ob])
+        for k in ("x", "y", "ux", "uy", "uz"):
+            assert np.abs(da[k][oa] - db[k][ob]).max() <= 1e-9 * max(np.abs(db[k]).max(), 1e-300), k
