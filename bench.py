@@ -35,11 +35,12 @@ BYTES_PER_PARTICLE = 105.0     # 7 f64 + is_dead read, 6 f64 wri
 GATHER_SCATTER_BYTES_PER_CELL = 112.0  # 6 arrays read + 4 arrays RMW
 
 
-def build_engine(args, comm, device):
+def build_engine(args, comm, device, nx=None):
+    """``nx``: cells of THIS rank's slab along x (default: args.nx, the weak-scaling slab)"""
     from lambdapic_amd import constants
     from lambdapic_amd.engine import PicEngine2D
 
-    nx, ny, ppc = args.nx, args.ny, args.ppc
+    nx, ny, ppc = (args.nx if nx is None else nx), args.ny, args.ppc
     dx = dy = LAMBDA0 / 20                                  # example/ring.py:34-40
     dt = 0.95 / (C_LIGHT * np.sqrt(dx ** -2 + dy ** -2))    # simulation.py:219
     q, m = -constants.E_CHARGE, constants.M_E
@@ -382,6 +383,244 @@ def recorded_traffic_3d():
         return {"traffic_per_algorithmic_byte": None, "traffic_source": f"no 3-D traffic profile ({e.__class__.__name__})"}
 
 
+# ---- N > 1: the configs BASELINE.json defines on several GPUs, fixed-size problems cut into N slabs (strong scaling) ----
+def _allsum(vals):
+    """sum of a list of python numbers over the ranks (control plane: the gloo default group)"""
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return t.tolist()
+
+
+def _allmax(v):
+    import torch.distributed as dist
+    t = torch.tensor([float(v)], dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _gather(v):
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [v]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, v)
+    return out
+
+
+def _timed(comm, device, step, nsteps):
+    """EXACTLY ``nsteps`` calls of ``step`` between barrier + synchronize on both sides; max over the ranks"""
+    torch.cuda.synchronize(device)
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize(device)
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    return _allmax(time.perf_counter() - t0)
+
+
+def _k1_roofline(eng, nsteps, bytes_local, kernel):
+    """roofline object of a slab leg: the ranks' algorithmic bytes over the SLOWEST rank's K1 time (edge + interior
+    launches add up), against N x the per-GPU peak"""
+    ev = eng.kernel_events or []
+    k_ms = float(sum(a.elapsed_time(b) for a, b in ev)) / nsteps if ev else float("nan")
+    k_all = _gather(k_ms)
+    tot_bytes = _allsum([bytes_local])[0]
+    worst = max(k_all)
+    n = len(k_all)
+    ach = tot_bytes / (worst * 1e-3) / 1e9 if worst == worst and worst > 0 else float("nan")
+    return {"bound": "hbm", "kernel": kernel, "kernel_ms_per_rank": [round(v, 4) for v in k_all],
+            "algorithmic_bytes_per_step_all_ranks": tot_bytes, "achieved": ach, "peak": HBM_PEAK_GBS * n,
+            "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * n)}
+
+
+def _live_2d(eng):
+    """(sum q w, sum |q| w, count) of this rank's live particles"""
+    qw = qa = 0.0
+    n = 0
+    for sp in eng.species:
+        s_ = sp.cset
+        ok = ~torch.isnan(s_.arr("x")[: sp.n])
+        w = s_.arr("w")[: sp.n][ok].sum().item()
+        qw, qa, n = qw + sp.q * w, qa + abs(sp.q) * w, n + int(ok.sum().item())
+    return qw, qa, n
+
+
+def _live_3d(eng):
+    qw = qa = 0.0
+    n = 0
+    for sp in eng.species:
+        d = sp["data"][:, : sp["n"]]
+        ok = ~torch.isnan(d[0])
+        w = d[7][ok].sum().item()
+        qw, qa, n = qw + sp["q"] * w, qa + abs(sp["q"]) * w, n + int(ok.sum().item())
+    return qw, qa, n
+
+
+def _charge_check(sim, live, rho_sum, cell_volume, cbs, shifts=lambda: 0):
+    """one more step, bracketed: the charge of the padded rho arrays of all ranks (x guard planes between slabs are
+    zero after the fold: counted once) equals sum q w of the particles that were alive when the step deposited, and
+    the live count can only have dropped by what stood next to an absorbing bound.  A step in which the window
+    shifted is skipped (it drops / injects at stage 'start').  Returns (rel. charge error, particles absorbed)"""
+    for _ in range(4):
+        s0 = shifts()
+        qw, qa, n0 = _allsum(list(live(sim.engine)))
+        sim.run(1, callbacks=cbs)
+        if shifts() != s0:
+            continue
+        charge = _allsum([rho_sum(sim.engine) * cell_volume])[0]
+        n1 = _allsum([live(sim.engine)[2]])[0]
+        return abs(charge - qw) / qa, int(n0 - n1)
+    return float("nan"), -1
+
+
+def leg_c2_strong(args, comm, device, steps, warm):
+    """config C2's 1024 x 1024 box at a FIXED size, cut into N x-slabs (strong scaling), next to the weak headline"""
+    nx_loc = 1024 // comm.size
+    if nx_loc * comm.size != 1024 or nx_loc % 8:
+        return {"workload": "C2 strong", "value": None, "error": f"1024 cells do not split into {comm.size} tile-aligned slabs"}
+    a = argparse.Namespace(**vars(args))
+    a.ny, a.ppc = 1024, 64
+    eng, dt, n_local = build_engine(a, comm, device, nx=nx_loc)
+    eng.rho_continuity = args.rho == "continuity"
+    for _ in range(warm):
+        eng.step(dt)
+    eng.kernel_events = []
+    el = _timed(comm, device, lambda: eng.step(dt), steps)
+    d = eng.diagnostics(reduce=True)
+    w = float(eng.species[0].cset.arr("w")[0].item())
+    n_tot = n_local * comm.size
+    from lambdapic_amd import constants
+    charge_err = abs(d["charge"] / (n_tot * w * -constants.E_CHARGE) - 1)
+    assert d["nalive"][0] == n_tot and charge_err < 1e-10, (d["nalive"], n_tot, charge_err)
+    out = {"workload": f"C2 strong: 2-D uniform thermal plasma 1024x1024 cells, 64 ppc, periodic, as {comm.size} x-slabs "
+                       f"of {nx_loc}x1024 (fixed problem size)",
+           "scaling": "strong", "value": n_tot * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
+           "steps": steps, "alive_per_rank": _gather(eng.diagnostics()["nalive"][0]), "charge_rel_err": charge_err,
+           "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+           "roofline": _k1_roofline(eng, steps, BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * nx_loc * 1024,
+                                    "k_push_deposit_tiled_2d")}
+    del eng
+    return out
+
+
+def leg_c4(args, comm, device, steps, warm, p2p):
+    """BASELINE config C4 (2-D LWFA, `example/lwfa.py:30-76`): 4096 x 512 cells, 16 ppc, ne = 0.01 nc for x > 1 um with
+    1 um vacuum margins in y, CPML on all sides, SimpleLaser2D a0 = 2, moving window at c with injection -- as N slabs
+    of (4096 / N) x 512 through the Simulation stage loop (chain: the end ranks own the x layers)"""
+    from lambdapic_amd import constants
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.laser import SimpleLaser2D
+    from lambdapic_amd.simulation import MovingWindow, Simulation, Species
+    nx, ny, ppc = 4096, 512, 16
+    dx = dy = LAMBDA0 / 20
+    nxl = nx // comm.size
+    if nxl * comm.size != nx or nxl % 64:
+        return {"workload": "C4", "value": None, "error": f"4096 cells do not split into {comm.size} slabs of 64-cell patches"}
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
+    chain = SlabComm(None, periodic=False, p2p_group=p2p)
+    sim = Simulation(nx, ny, dx, dy, npatch_x=nxl // 64, npatch_y=ny // 64, random_seed=1, sort_interval=20, comm=chain,
+                     device=str(device))
+    Ly = ny * dy
+    dens = lambda x, y: np.where((x > 1e-6) & (y > 1e-6) & (y < Ly - 1e-6), 0.01 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=ppc))
+    sim.initialize()
+    eng = sim.engine
+    eng.rho_continuity = args.rho == "continuity"
+    ledger = {"dropped": 0, "injected": 0, "shifts": 0}
+    shift, append = eng.shift_window, eng.append_particles_device
+
+    def shift_window(ncells):
+        before = _live_2d(eng)[2]
+        shift(ncells)
+        ledger["dropped"] += before - _live_2d(eng)[2]      # (what a slab hands to its left neighbour arrives there:
+        ledger["shifts"] += 1                                # the sum over the ranks is what left the chain)
+
+    def append_particles_device(ispec, dev):       # (only the injection of fresh columns comes through here)
+        ledger["injected"] += int(dev["x"].numel())
+        append(ispec, dev)
+
+    eng.shift_window, eng.append_particles_device = shift_window, append_particles_device
+    cbs = [SimpleLaser2D(a0=2.0, w0=5e-6, ctau=5e-6, l0=LAMBDA0), MovingWindow(velocity=C_LIGHT, start_time=0.03 * sim.Lx / C_LIGHT)]
+    sim.run(5, callbacks=cbs)          # the cells loaded inside the x-max layer are absorbed by the first step
+    n_init = _allsum([_live_2d(eng)[2]])[0]
+    ledger.update(dropped=0, injected=0)
+    sim.run(warm, callbacks=cbs)
+    eng.kernel_events = []
+    a0 = _allsum([_live_2d(eng)[2]])[0]
+    el = _timed(comm, device, lambda: sim.run(1, callbacks=cbs), steps)
+    a1 = _allsum([_live_2d(eng)[2]])[0]
+    alive = 0.5 * (a0 + a1)
+    roof = _k1_roofline(eng, steps, BYTES_PER_PARTICLE * _live_2d(eng)[2] + GATHER_SCATTER_BYTES_PER_CELL * nxl * ny,
+                        "k_push_deposit_tiled_2d")
+    eng.kernel_events = None
+    g = eng.grid
+    err, absorbed = _charge_check(sim, _live_2d, lambda e: e.grid.view("rho").sum().item(), g.dx * g.dy, cbs,
+                                  lambda: ledger["shifts"])
+    shifts = _gather(ledger["shifts"])
+    dropped, injected = _allsum([ledger["dropped"], ledger["injected"]])
+    n_end = _allsum([_live_2d(eng)[2]])[0]
+    # nothing doubled, nothing from nowhere: the live count follows the ledger up to what the open low-x edge absorbs
+    ok = n_end <= n_init - dropped + injected and n_end >= n_init - dropped + injected - 0.01 * n_init
+    assert ok and err <= 1e-10, (n_init, dropped, injected, n_end, err)
+    return {"workload": f"C4: 2-D LWFA 4096x512 cells (lambda/20), e- 16 ppc at 0.01 nc, CPML, SimpleLaser2D a0=2, moving "
+                        f"window at c with injection, tile sort every 20 steps, as {comm.size} x-slabs of {nxl}x512 "
+                        f"(Simulation stage loop)",
+            "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_2d(eng)[2]), "window_shifts": shifts[0],
+            "ledger": {"initial": int(n_init), "dropped": int(dropped), "injected": int(injected), "final": int(n_end)},
+            "charge_rel_err": err, "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+            "roofline": roof}
+
+
+def leg_c5(args, comm, device, steps, warm, p2p):
+    """BASELINE config C5 (3-D laser-target, `example/laser-target-3d.py:26-60`): 512 x 256 x 256 cells, e- + p at 8 ppc
+    each for x > 1 um, CPML on six faces, GaussianLaser3D a0 = 10 -- as N slabs of (512 / N) x 256 x 256 through the
+    Simulation3D stage loop, the J / rho guard planes travelling behind the interior tiles (overlap on)"""
+    from lambdapic_amd import constants
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.laser import GaussianLaser3D
+    from lambdapic_amd.simulation3d import Simulation3D, Species
+    nx, ny, nz, ppc = 512, 256, 256, 8
+    dx, dy, dz = LAMBDA0 / 20, LAMBDA0 / 10, LAMBDA0 / 10
+    nxl = nx // comm.size
+    if nxl * comm.size != nx or nxl % 32:
+        return {"workload": "C5", "value": None, "error": f"512 cells do not split into {comm.size} slabs of 32-cell patches"}
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
+    chain = SlabComm(None, periodic=False, p2p_group=p2p)
+    sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=nxl // 32, npatch_y=ny // 64, npatch_z=nz // 64, random_seed=1,
+                       sort_interval=10, comm=chain, device=str(device))
+    dens = lambda x, y, z: np.where(x > 1e-6, nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=ppc, momentum_sigma=0.01))
+    sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=ppc))
+    sim.initialize()
+    eng = sim.engine
+    eng.overlap = True
+    eng.rho_continuity = args.rho == "continuity"
+    cbs = [GaussianLaser3D(a0=10.0, l0=LAMBDA0, w0=2e-6, ctau=3e-6, x0=6e-6)]
+    sim.run(warm, callbacks=cbs)
+    eng.kernel_events = []
+    a0 = _allsum([_live_3d(eng)[2]])[0]
+    el = _timed(comm, device, lambda: sim.run(1, callbacks=cbs), steps)
+    a1 = _allsum([_live_3d(eng)[2]])[0]
+    alive = 0.5 * (a0 + a1)
+    roof = _k1_roofline(eng, steps, 121.0 * _live_3d(eng)[2], "k_push_deposit_tiled_3d")
+    eng.kernel_events = None
+    err, absorbed = _charge_check(sim, _live_3d, lambda e: e.view("rho").sum().item(), dx * dy * dz, cbs)
+    assert err <= 1e-10 and 0 <= absorbed <= 0.01 * alive, (err, absorbed)
+    return {"workload": f"C5: 3-D laser-target 512x256x256 cells (dx=lambda/20, dy=dz=lambda/10), e- + p 8 ppc each for "
+                        f"x > 1 um, CPML on 6 faces, GaussianLaser3D a0=10, tile sort every 10 steps, as {comm.size} "
+                        f"x-slabs of {nxl}x256x256 (Simulation3D stage loop)",
+            "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_3d(eng)[2]), "charge_rel_err": err,
+            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap), "roofline": roof}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,7 +635,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5-slab legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5-slab legs (N = 1) / the C2-strong, C4 "
+                                                            "and C5 slab legs (N > 1)")
+    ap.add_argument("--leg-steps", type=int, default=0, help="timed steps of the N > 1 legs (default: 200 / 200 / 20)")
+    ap.add_argument("--legs", default="c2s,c4,c5", help="which N > 1 legs to run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank path with ranks sharing GPUs (buffers staged "
                          "through the host); the driver's runs use nccl (RCCL)")
@@ -518,6 +760,29 @@ def main():
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
                      "traffic_source": traffic_source},
     }
+    if comm.size > 1 and not args.no_extra:
+        # the configs BASELINE.json defines on several GPUs are FIXED-size problems: C2's 1024^2 box (north_star quotes
+        # ">= 6x at 8 GPUs" on it), C4 (4096 x 512 LWFA with window) and C5 (512 x 256 x 256 laser-target) cut into N
+        # slabs -- strong scaling, reported next to the weak-scaled headline.  Every rank runs them; each leg asserts
+        # its bookkeeping (live counts against the ledger, total charge of the padded arrays) before it reports.
+        del eng
+        torch.cuda.empty_cache()
+        legs = []
+        want = set(args.legs.split(","))
+        todo = [("c2s", lambda: leg_c2_strong(args, comm, device, args.leg_steps or 200, 10)),
+                ("c4", lambda: leg_c4(args, comm, device, args.leg_steps or 200, 40, p2p)),
+                ("c5", lambda: leg_c5(args, comm, device, args.leg_steps or 20, 12, p2p))]
+        for name, leg in todo:
+            if name not in want:
+                continue
+            try:
+                r = leg()
+            except Exception as e:   # noqa: BLE001 -- reported; the other ranks run the same code and fail alike
+                r = {"workload": name, "value": None, "error": repr(e)}
+            r.setdefault("comm", comm_note)
+            legs.append(r)
+            torch.cuda.empty_cache()
+        out["extra"] = legs
     if comm.rank == 0 and comm.size == 1 and not args.no_extra:
         # north_star: "uniform-plasma and laser-target configs": the other single-GPU configs, bounded legs
         del eng

@@ -205,10 +205,12 @@ int lpa_reset_j(const lpa_grid *g, void *stream);
 /* ---- rho from the discrete continuity equation (companion of LPA_PUSH_NO_RHO; 2-D when g->nz <= 1).
  *      lpa_rho_continuity: rho -= dt * (D-x jx + D-y jy [+ D-z jz]) with backward differences, AFTER the currents
  *        were folded (lpa_current_fold / halo exchange).  Per axis: bit set in `periodic_axes` = folded inside this
- *        slab: interior nodes only, node 0 takes node n-1 as its lower neighbour; x with split_x != 0 = x is cut
- *        into slabs: interior nodes only, node 0 takes jx_left_plane[NY(*NZ)] (the left neighbour's folded jx at its
- *        node nx-1; NULL = no left neighbour: the own guard plane); any other axis is open: every node of the padded
- *        array, on its torus -- where the deposit itself lands (core/utils/cutils.h:19-26).
+ *        slab: interior nodes only, node 0 takes node n-1 as its lower neighbour; split_x != 0 = x is cut into
+ *        slabs, bit 0 / bit 1 = this slab has a left / right neighbour: the guard planes of such a face were sent
+ *        away (interior nodes only on that side) and node 0 takes jx_left_plane[NY(*NZ)], the left neighbour's
+ *        folded jx at its node nx-1; a face without a neighbour -- every face of an axis that is neither periodic nor
+ *        split, and the outer face of a chain's end slab -- is open: its guard nodes are updated too, on the torus of
+ *        the padded array, where the deposit itself lands (core/utils/cutils.h:19-26).
  *      lpa_rho_absorbed: subtract from rho what the particles listed by a LPA_PUSH_NO_RHO kernel (absorbed at an
  *        open face, mark_out_of_bound_as_dead, core/patch/sync_particles_2d.c:185-202) had deposited there:
  *        entry = {x1, y1, z1 (deposit end point in cells from node 0), q w / cell volume}; runs before the fold of

@@ -32,15 +32,19 @@ extern "C" int lpa_reset_j(const lpa_grid *g, void *stream) {
 }
 
 // ---- rho -= dt div J -------------------------------------------------------------------------------------------------
-// mode per axis: 0 = open (every padded node, torus neighbour), 1 = folded inside the slab (interior nodes, node 0 ->
-// node n - 1), 2 = split over ranks (interior nodes, node 0 -> the left neighbour's plane, or the own guard)
+// mode per axis: bit 0 = folded inside the slab (periodic: interior nodes, node 0 -> node n - 1); else bit 1 / bit 2 =
+// the low / high face has a neighbour slab (its guard planes were sent away: interior nodes on that side, node 0 ->
+// the left neighbour's plane); a face with neither is open: its guard nodes are updated too, on the padded torus --
+// where the deposit itself lands
+constexpr int RHO_PERIODIC = 1, RHO_NB_LO = 2, RHO_NB_HI = 4;
 __device__ __forceinline__ bool rho_axis(int c, int n, int ng, int N, int mode, int &prev) {
-    if (mode == 0) {
-        prev = c == 0 ? N - 1 : c - 1;
+    if (mode & RHO_PERIODIC) {
+        if (c < ng || c >= ng + n) return false;
+        prev = c == ng ? ng + n - 1 : c - 1;
         return true;
     }
-    if (c < ng || c >= ng + n) return false;
-    prev = (mode == 1 && c == ng) ? ng + n - 1 : c - 1;
+    if (((mode & RHO_NB_LO) && c < ng) || ((mode & RHO_NB_HI) && c >= ng + n)) return false;
+    prev = c == 0 ? N - 1 : c - 1;
     return true;
 }
 
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(256) k_rho_continuity(GridV g, double dtdx, do
     if (d3 && !rho_axis(cz, g.nz, g.ng, g.NZ, mz, pz)) return;
     const long sX = (long)g.NY * g.NZ, sY = g.NZ;
     const long c = cx * sX + cy * sY + cz;
-    const double jxp = (mx == 2 && cx == g.ng && left) ? left[cy * sY + cz] : g.jx[px * sX + cy * sY + cz];
+    const double jxp = ((mx & RHO_NB_LO) && cx == g.ng) ? left[cy * sY + cz] : g.jx[px * sX + cy * sY + cz];
     double div = (g.jx[c] - jxp) * dtdx + (g.jy[c] - g.jy[cx * sX + py * sY + cz]) * dtdy;
     if (d3) div += (g.jz[c] - g.jz[cx * sX + cy * sY + pz]) * dtdz;
     g.rho[c] -= div;
@@ -66,8 +70,11 @@ extern "C" int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axe
     const int dim = g && g->nz > 1 ? 3 : 2;
     LPA_REQUIRE(lpa_grid_ok(g, dim, 1) && dt > 0, "lpa_rho_continuity: bad args");
     LPA_REQUIRE(!(split_x && (periodic_axes & 1)), "lpa_rho_continuity: x is either folded locally or split");
+    LPA_REQUIRE(split_x >= 0 && split_x <= 3 && (!(split_x & 1) || jx_left_plane),
+                "lpa_rho_continuity: a slab with a left neighbour needs its jx plane");
     GridV v = make_gridv(g, dim);
-    const int mx = split_x ? 2 : (periodic_axes & 1), my = (periodic_axes >> 1) & 1, mz = (periodic_axes >> 2) & 1;
+    const int mx = split_x ? ((split_x & 1 ? RHO_NB_LO : 0) | (split_x & 2 ? RHO_NB_HI : 0)) : (periodic_axes & 1),
+              my = (periodic_axes >> 1) & 1, mz = (periodic_axes >> 2) & 1;
     dim3 grid = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
     hipLaunchKernelGGL(k_rho_continuity, grid, dim3(256), 0, (hipStream_t)stream, v, dt / g->dx, dt / g->dy,
                        dim == 3 ? dt / g->dz : 0.0, mx, my, mz, jx_left_plane);

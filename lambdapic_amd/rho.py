@@ -162,6 +162,7 @@ class RhoContinuityMixin:
                 self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
             self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
             left = self._jx_plane if self.comm.has_left else None
-        check(self.L.lpa_rho_continuity(self._g(), self._dt_step, self.local_axes, int(self.comm.size > 1),
+        split = ((1 if self.comm.has_left else 0) | (2 if self.comm.has_right else 0)) if self.comm.size > 1 else 0
+        check(self.L.lpa_rho_continuity(self._g(), self._dt_step, self.local_axes, split,
                                         left.data_ptr() if left is not None else None, self.stream),
               "lpa_rho_continuity")
