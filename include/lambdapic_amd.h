@@ -452,6 +452,33 @@ int lpa_sync_particles_fill_2d(double *const *attrs, int32_t nattrs, int32_t iat
                                double xmin_global, double xmax_global, double ymin_global, double ymax_global,
                                double dx, double dy, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- 3-D twins of the patch-list drop-ins: neighbor_ipatch is [npatches][26] in Boundary3D order
+ *      (core/patch/patch.py:37-69: 6 faces, 12 edges xy / xz / yz, 8 vertices), arrays double[NX][NY][NZ] in the
+ *      wrapped guard layout.
+ *      lpa_sync_guard_fields_3d replaces sync_guard_fields_3d(fields_list, patches_list, attrs, npatches, nx, ny, nz, ng)
+ *        (core/patch/sync_fields3d.c:350-612); lpa_sync_currents_3d replaces sync_currents_3d(fields_list,
+ *        patches_list, npatches, nx, ny, nz, ng) (:84-348; the neighbours' guards are added in Boundary3D order like the
+ *        reference's sweep, consumed guards zeroed).
+ *      lpa_sync_particles_count_3d / _fill_3d replace get_npart_to_extend_3d + fill_particles_from_boundary_3d
+ *        (core/patch/sync_particles_3d.c:365-482,484-700): `xyz` = [npatches][3] pointers, `bounds` = [npatches][6]
+ *        xmin xmax ymin ymax zmin zmax WITH the half cell (:392-399), npart_outgoing [npatches][26]; global_min /
+ *        global_max / cell = host double[3]; slot placement and +- L as in the 2-D twins; mark_out_of_bound_as_dead
+ *        of the 3-D file (:324-345) also blanks the positions of slots that are dead already.  Workspace:
+ *        lpa_sync_particles_workspace_bytes. */
+int lpa_sync_guard_fields_3d(double *const *arrays, int32_t ncomp, const int64_t *neighbor_ipatch,
+                             int32_t npatches, int32_t nx, int32_t ny, int32_t nz, int32_t ng, void *stream);
+int lpa_sync_currents_3d(double *const *arrays, const int64_t *neighbor_ipatch, int32_t npatches, int32_t nx,
+                         int32_t ny, int32_t nz, int32_t ng, void *stream);
+int lpa_sync_particles_count_3d(const double *const *xyz, const uint8_t *const *is_dead, const int64_t *npart,
+                                const double *bounds, int32_t npatches, int64_t max_npart,
+                                int64_t *npart_outgoing, int64_t *ndead, void *stream);
+int lpa_sync_particles_fill_3d(double *const *attrs, int32_t nattrs, int32_t iattr_x, int32_t iattr_y,
+                               int32_t iattr_z, uint8_t *const *is_dead, const int64_t *npart, const double *bounds,
+                               const int64_t *neighbor_ipatch, const int64_t *npart_incoming,
+                               const int64_t *npart_outgoing, int32_t npatches, int64_t max_npart,
+                               const double *global_min, const double *global_max, const double *cell,
+                               void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- bucket sort with the reference's bookkeeping, one patch per call: replaces the body of
  *      sort_particles_patches_2d / _3d (core/sort/cpu2d.c:220-303, cpu3d.c) = calculate_bucket_index (:9-54:
  *      bucket = floor((r - r0) / d) per axis, out of range -> last bucket or clamped when reverse_x, a dead

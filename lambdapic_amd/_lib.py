@@ -155,6 +155,12 @@ SIGNATURES = {
     "lpa_sync_particles_workspace_bytes": (_i64, [C.c_int32, _i64]),
     "lpa_sync_particles_fill_2d": (_i, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32,
                                         _i64, _d, _d, _d, _d, _d, _d, _vp, _i64, _vp]),
+    "lpa_sync_guard_fields_3d": (_i, [_vp, C.c_int32, _vp] + [C.c_int32] * 5 + [_vp]),
+    "lpa_sync_currents_3d": (_i, [_vp, _vp] + [C.c_int32] * 5 + [_vp]),
+    "lpa_sync_particles_count_3d": (_i, [_vp, _vp, _vp, _vp, C.c_int32, _i64, _vp, _vp, _vp]),
+    "lpa_sync_particles_fill_3d": (_i, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        C.c_int32, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), _vp, _i64, _vp]),
     "lpa_bucket_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "lpa_bucket_sort": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int32, _i64, _i64, _i64, _i64, _d, _d, _d,
                              _d, _d, _d, C.c_int32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

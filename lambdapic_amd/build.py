@@ -15,7 +15,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "liblambdapic_amd.so"
 SOURCES = ["lpa_fields.hip", "lpa_particles.hip", "lpa_particles3d.hip", "lpa_sort.hip", "lpa_patches.hip",
-           "lpa_rho.hip", "lpa_step.hip"]
+           "lpa_rho.hip", "lpa_step.hip", "lpa_patches3d.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 

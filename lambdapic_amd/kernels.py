@@ -305,10 +305,10 @@ def _patch_arrays_on_device(fields_list, attrs, npatches, dev):
     return buf, ptrs
 
 
-def _neighbor_table(patches_list, npatches, dev):
+def _neighbor_table(patches_list, npatches, dev, nbound=8):
     nb = np.stack([np.asarray(p.neighbor_ipatch, dtype=np.int64) for p in patches_list[:npatches]])
-    if nb.shape != (npatches, 8):
-        raise ValueError("neighbor_ipatch must have the 8 entries of Boundary2D")
+    if nb.shape != (npatches, nbound):
+        raise ValueError(f"neighbor_ipatch must have the {nbound} entries of Boundary{2 if nbound == 8 else 3}D")
     if (nb >= npatches).any():
         raise ValueError("neighbor_ipatch points outside the patch list")
     return torch.from_numpy(nb).to(dev)
@@ -343,6 +343,42 @@ def sync_currents_2d(fields_list, patches_list, npatches, nx, ny, ng):
     nb = _neighbor_table(patches_list, npatches, dev)
     check(L.lpa_sync_currents_2d(ptrs.data_ptr(), nb.data_ptr(), npatches, nx, ny, ng, _stream(dev)),
           "lpa_sync_currents_2d")
+    out = buf.cpu().numpy()
+    for p, f in enumerate(fields_list[:npatches]):
+        for c, a in enumerate(attrs):
+            getattr(f, a)[...] = out[p, c]
+    return None
+
+
+def sync_guard_fields_3d(fields_list, patches_list, attrs, npatches, nx, ny, nz, ng):
+    """GPU drop-in for `core/patch/sync_fields3d.c:350-612`
+    (``sync_guard_fields_3d(fields_list, patches_list, attrs, npatches, nx, ny, nz, ng) -> None``)"""
+    L, dev = lib(), _device()
+    attrs = list(attrs)
+    if npatches <= 0 or not attrs:
+        return None
+    buf, ptrs = _patch_arrays_on_device(fields_list, attrs, npatches, dev)
+    nb = _neighbor_table(patches_list, npatches, dev, 26)
+    check(L.lpa_sync_guard_fields_3d(ptrs.data_ptr(), len(attrs), nb.data_ptr(), npatches, nx, ny, nz, ng,
+                                     _stream(dev)), "lpa_sync_guard_fields_3d")
+    out = buf.cpu().numpy()
+    for p, f in enumerate(fields_list[:npatches]):
+        for c, a in enumerate(attrs):
+            getattr(f, a)[...] = out[p, c]
+    return None
+
+
+def sync_currents_3d(fields_list, patches_list, npatches, nx, ny, nz, ng):
+    """GPU drop-in for `core/patch/sync_fields3d.c:84-348`
+    (``sync_currents_3d(fields_list, patches_list, npatches, nx, ny, nz, ng) -> None``)"""
+    L, dev = lib(), _device()
+    if npatches <= 0:
+        return None
+    attrs = ["jx", "jy", "jz", "rho"]
+    buf, ptrs = _patch_arrays_on_device(fields_list, attrs, npatches, dev)
+    nb = _neighbor_table(patches_list, npatches, dev, 26)
+    check(L.lpa_sync_currents_3d(ptrs.data_ptr(), nb.data_ptr(), npatches, nx, ny, nz, ng, _stream(dev)),
+          "lpa_sync_currents_3d")
     out = buf.cpu().numpy()
     for p, f in enumerate(fields_list[:npatches]):
         for c, a in enumerate(attrs):
@@ -500,6 +536,72 @@ def fill_particles_from_boundary_2d(particles_list, patches_list, npart_incoming
                                        nb.data_ptr(), nin.data_ptr(), nout.data_ptr(), npatches, d.nmax,
                                        xmin_global, xmax_global, ymin_global, ymax_global, dx, dy, ws.data_ptr(),
                                        ws.numel(), _stream(dev)), "lpa_sync_particles_fill_2d")
+    d.download()
+    return None
+
+
+# ---- 3-D twins (core/patch/sync_particles_3d.c) ---------------------------------------------------------------
+def _patch_bounds_3d(patches_list, npatches, d):
+    return np.array([[getattr(p, ax + side) + sg * 0.5 * dd for ax, dd in zip("xyz", d) for side, sg in (("min", -1), ("max", 1))]
+                     for p in patches_list[:npatches]], dtype=np.float64)
+
+
+def _opposite_3d():
+    from .patch import OPPOSITE_3D, Boundary3D
+    return [int(OPPOSITE_3D[b]) for b in Boundary3D]
+
+
+def get_npart_to_extend_3d(particles_list, patch_list, npatches, dx, dy, dz):
+    """GPU drop-in for `core/patch/sync_particles_3d.c:365-482`: returns ``(npart_to_extend, npart_incoming,
+    npart_outgoing, npart_alive)`` (int64 arrays; npart_outgoing is [npatches * 26] in Boundary3D order)"""
+    L, dev = lib(), _device()
+    z = lambda n: np.zeros(n, dtype=np.int64)
+    if npatches <= 0:
+        return z(0), z(0), z(0), z(0)
+    d = _PatchParticlesOnDevice(particles_list, npatches, ["x", "y", "z"], dev)
+    bounds = torch.from_numpy(_patch_bounds_3d(patch_list, npatches, (dx, dy, dz))).to(dev)
+    nout = torch.zeros(npatches * 26, dtype=torch.int64, device=dev)
+    ndead = torch.zeros(npatches, dtype=torch.int64, device=dev)
+    check(L.lpa_sync_particles_count_3d(d.ptrs.data_ptr(), d.dead_ptrs.data_ptr(), d.npart_dev.data_ptr(),
+                                        bounds.data_ptr(), npatches, d.nmax, nout.data_ptr(), ndead.data_ptr(),
+                                        _stream(dev)), "lpa_sync_particles_count_3d")
+    nout_h, ndead_h = nout.cpu().numpy(), ndead.cpu().numpy()
+    opp = _opposite_3d()
+    ext, inc, alive = z(npatches), z(npatches), z(npatches)
+    for ip, p in enumerate(patch_list[:npatches]):        # sync_particles_3d.c:439-476
+        new = sum(int(nout_h[int(nb) * 26 + opp[b]]) for b, nb in enumerate(p.neighbor_ipatch) if nb >= 0)
+        npart = int(d.npart[ip])
+        alive[ip] = npart - int(ndead_h[ip]) + new
+        if new - int(ndead_h[ip]) > 0:
+            ext[ip] = new - int(ndead_h[ip]) + int(npart * 0.25)
+        inc[ip] = new
+    return ext, inc, nout_h, alive
+
+
+def fill_particles_from_boundary_3d(particles_list, patch_list, npart_incoming, npart_outgoing, npatches, dx, dy, dz,
+                                    xmin_global, xmax_global, ymin_global, ymax_global, zmin_global, zmax_global,
+                                    attrs):
+    """GPU drop-in for `core/patch/sync_particles_3d.c:484-700` (arrays are filled / killed in place)"""
+    L, dev = lib(), _device()
+    attrs = list(attrs)
+    if "x" not in attrs or "y" not in attrs or "z" not in attrs:
+        raise ValueError("attrs must contain 'x', 'y', and 'z'")
+    if npatches <= 0:
+        return None
+    d = _PatchParticlesOnDevice(particles_list, npatches, attrs, dev)
+    bounds = torch.from_numpy(_patch_bounds_3d(patch_list, npatches, (dx, dy, dz))).to(dev)
+    nb = _neighbor_table(patch_list, npatches, dev, 26)
+    nin = torch.from_numpy(np.ascontiguousarray(npart_incoming, dtype=np.int64)).to(dev)
+    nout = torch.from_numpy(np.ascontiguousarray(npart_outgoing, dtype=np.int64)).to(dev)
+    nbytes = L.lpa_sync_particles_workspace_bytes(npatches, d.nmax)
+    ws = torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    v3 = lambda *v: (C.c_double * 3)(*[float(x) for x in v])
+    check(L.lpa_sync_particles_fill_3d(d.ptrs.data_ptr(), len(attrs), attrs.index("x"), attrs.index("y"),
+                                       attrs.index("z"), d.dead_ptrs.data_ptr(), d.npart_dev.data_ptr(),
+                                       bounds.data_ptr(), nb.data_ptr(), nin.data_ptr(), nout.data_ptr(), npatches,
+                                       d.nmax, v3(xmin_global, ymin_global, zmin_global),
+                                       v3(xmax_global, ymax_global, zmax_global), v3(dx, dy, dz), ws.data_ptr(),
+                                       ws.numel(), _stream(dev)), "lpa_sync_particles_fill_3d")
     d.download()
     return None
 

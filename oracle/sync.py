@@ -154,6 +154,138 @@ def sync_particles_2d(patches, ispec, dx, dy, attrs=None):
 
 
 # -------------------------------------------------------------------------------------------------
+# 3-D patch lists (core/patch/sync_fields3d.c, core/patch/sync_particles_3d.c): 26 neighbours in Boundary3D order
+# (core/patch/patch.py:37-69).  Checked against the reference's compiled extensions through tests/golden (G16, G17).
+# -------------------------------------------------------------------------------------------------
+def _boundary3(sx, sy, sz):
+    """index in Boundary3D of the neighbour on side (sx, sy, sz); -1 for (0, 0, 0)"""
+    nz = (sx != 0) + (sy != 0) + (sz != 0)
+    if nz == 0:
+        return -1
+    if nz == 1:
+        return int(sx > 0) if sx else (2 + int(sy > 0) if sy else 4 + int(sz > 0))
+    if nz == 3:
+        return 18 + 4 * int(sx > 0) + 2 * int(sy > 0) + int(sz > 0)
+    if sz == 0:
+        return 6 + 4 * int(sx > 0) + int(sy > 0)
+    if sy == 0:
+        return 8 + 4 * int(sx > 0) + int(sz > 0)
+    return 14 + 2 * int(sy > 0) + int(sz > 0)
+
+
+_SIDE3 = [None] * 26
+for _sx in (-1, 0, 1):
+    for _sy in (-1, 0, 1):
+        for _sz in (-1, 0, 1):
+            if _boundary3(_sx, _sy, _sz) >= 0:
+                _SIDE3[_boundary3(_sx, _sy, _sz)] = (_sx, _sy, _sz)
+_OPP3 = [_boundary3(-a, -b, -c) for a, b, c in _SIDE3]      # sync_fields3d.c:52-82
+
+
+def sync_guard_fields_3d(fields_list, patches_list, attrs, npatches, nx, ny, nz, ng):
+    """restates core/patch/sync_fields3d.c:350-612: my guard on side s <- the neighbour's interior edge"""
+    n3 = (nx, ny, nz)
+    for a in attrs:
+        for ip in range(npatches):
+            nb = patches_list[ip].neighbor_ipatch
+            dst = getattr(fields_list[ip], a)
+            for b, side in enumerate(_SIDE3):
+                if nb[b] < 0:
+                    continue
+                src = getattr(fields_list[nb[b]], a)
+                rng = [_rng_guard(s_, n, ng) for s_, n in zip(side, n3)]
+                dst[np.ix_(*[r[0] for r in rng])] = src[np.ix_(*[r[1] for r in rng])]
+
+
+def sync_currents_3d(fields_list, patches_list, npatches, nx, ny, nz, ng):
+    """restates core/patch/sync_fields3d.c:84-348: my interior edge on side s += the neighbour's guard beyond its
+    opposite side, which is zeroed; boundaries in Boundary3D order like the reference's sweep"""
+    n3 = (nx, ny, nz)
+    for a in ("jx", "jy", "jz", "rho"):
+        for ip in range(npatches):
+            nb = patches_list[ip].neighbor_ipatch
+            dst = getattr(fields_list[ip], a)
+            for b, side in enumerate(_SIDE3):
+                if nb[b] < 0:
+                    continue
+                src = getattr(fields_list[nb[b]], a)
+                rng = [_rng_fold(s_, n, ng) for s_, n in zip(side, n3)]
+                si = np.ix_(*[r[1] for r in rng])
+                dst[np.ix_(*[r[0] for r in rng])] += src[si]
+                src[si] = 0.0
+
+
+def _classify3(q, bounds):
+    """Boundary3D id of every live particle outside the bounds, -1 otherwise (sync_particles_3d.c:78-192)"""
+    side = []
+    for a, (lo, hi) in zip("xyz", bounds):
+        v = getattr(q, a)
+        with np.errstate(invalid="ignore"):
+            side.append(np.where(v < lo, -1, np.where(v > hi, 1, 0)))
+    out = np.array([_boundary3(int(a), int(b), int(c)) for a, b, c in zip(*side)], dtype=np.int64) \
+        if q.npart else np.zeros(0, dtype=np.int64)
+    out[q.is_dead] = -1
+    return out
+
+
+def sync_particles_3d(patches, ispec, d, attrs=None):
+    """restates Patches.sync_particles for one species in 3-D (core/patch/patch.py:739-763 driving
+    core/patch/sync_particles_3d.c:365-700): as sync_particles_2d with 26 boundaries; the 3-D
+    mark_out_of_bound_as_dead (:324-345) also blanks the positions of slots that are dead already"""
+    npatches = patches.npatches
+    parts = [p.particles[ispec] for p in patches]
+    attrs = attrs or parts[0].attrs
+    bounds = [[(getattr(p, ax + "min") - 0.5 * dd, getattr(p, ax + "max") + 0.5 * dd) for ax, dd in zip("xyz", d)]
+              for p in patches]
+    cls = [_classify3(q, b) for q, b in zip(parts, bounds)]
+    gmin = [getattr(patches, ax + "min_global") for ax in "xyz"]
+    gmax = [getattr(patches, ax + "max_global") for ax in "xyz"]
+    incoming = []
+    for ip, p in enumerate(patches):
+        rows = []
+        for b in range(26):
+            nb = p.neighbor_ipatch[b]
+            if nb < 0:
+                continue
+            idx = np.nonzero(cls[nb] == _OPP3[b])[0]
+            if idx.size:
+                rows.append(np.stack([getattr(parts[nb], a)[idx] for a in attrs], axis=1))
+        incoming.append(np.concatenate(rows, axis=0) if rows else np.zeros((0, len(attrs))))
+    npart_alive = np.zeros(npatches, dtype=np.int64)
+    for ip, (q, buf) in enumerate(zip(parts, incoming)):
+        nnew, ndead = buf.shape[0], int(q.is_dead.sum())
+        npart_alive[ip] = q.npart - ndead + nnew
+        if nnew - ndead > 0:
+            q.extend(nnew - ndead + int(q.npart * 0.25))
+    for ip, (q, buf) in enumerate(zip(parts, incoming)):
+        if buf.shape[0] == 0:
+            continue
+        buf = buf.copy()
+        for k, ax in enumerate("xyz"):
+            col = buf[:, attrs.index(ax)]
+            orig = col.copy()
+            (lo, hi), L = bounds[ip][k], gmax[k] - gmin[k]
+            if abs(lo - gmin[k]) < d[k]:
+                col[orig > gmax[k]] -= L
+            if abs(hi - gmax[k]) < d[k]:
+                col[orig < gmin[k]] += L
+        slots = np.nonzero(q.is_dead)[0][: buf.shape[0]]
+        for k, a in enumerate(attrs):
+            getattr(q, a)[slots] = buf[:, k]
+        q.is_dead[slots] = False
+    for q, b in zip(parts, bounds):
+        with np.errstate(invalid="ignore"):
+            outside = q.is_dead.copy()
+            for ax, (lo, hi) in zip("xyz", b):
+                v = getattr(q, ax)
+                outside |= (v < lo) | (v > hi)
+        q.is_dead[outside] = True
+        for ax in "xyz":
+            getattr(q, ax)[outside] = np.nan
+    return npart_alive
+
+
+# -------------------------------------------------------------------------------------------------
 # one patch that is its own neighbour on every periodic axis (any dimension): what the sync
 # functions above reduce to for npatch = 1.  Used by the 3-D engine test; pinned to the reference
 # through the 2-D functions above (tests/test_oracle_golden.py::test_periodic_single_patch_twins).

@@ -703,6 +703,83 @@ def g14_sync_particles_3d():
     np.savez_compressed(OUT / "g14_sync_particles_3d.npz", **out)
 
 
+def g16_sync_fields_3d_patches():
+    """3-D guard copy and current fold between DIFFERENT patches: 2 x 2 x 2 periodic patches of 6 x 6 x 7 cells, every
+    one of the 26 neighbour classes is another patch (g13's single self-periodic patch cannot tell a swapped neighbour
+    from the right one).  `core/patch/sync_fields3d.c:84-348,350-612` driven like `Patches.sync_guard_fields /
+    sync_currents` (`core/patch/patch.py:670-703`).  Values are small multiples of 1/64 so that the fixture stores them
+    as int8 / int16 (copies and sums of up to 8 of them are exact in FP64 whatever the order)."""
+    from lambdapic_amd.patch import make_patches_3d
+    sf = oracle.ref_module("patch", "sync_fields3d")
+    rng = np.random.default_rng(SEED + 16)
+    npp, npatch, ng = (6, 6, 7), (2, 2, 2), 3
+    P = make_patches_3d(tuple(a * b for a, b in zip(npp, npatch)), (1e-7, 1.5e-7, 0.8e-7), npatch, ng)
+    guard_attrs, cur_attrs = ["ex", "by", "bz"], ["jx", "jy", "jz", "rho"]
+    out = dict(npp=np.array(npp), npatch=np.array(npatch), ng=ng, scale=64.0,
+               neighbor_ipatch=np.stack([p.neighbor_ipatch for p in P]))
+    for k, p in enumerate(P):
+        for a in guard_attrs + cur_attrs:
+            v = rng.integers(-100, 101, size=p.fields.shape).astype(np.int8)
+            getattr(p.fields, a)[...] = v / 64.0
+            out[f"in{k}_{a}"] = v
+    fl = [p.fields for p in P]
+    sf.sync_guard_fields_3d(fl, list(P), guard_attrs, 8, *npp, ng)
+    sf.sync_currents_3d(fl, list(P), 8, *npp, ng)
+    for k, p in enumerate(P):
+        for a in guard_attrs + cur_attrs:
+            v = getattr(p.fields, a) * 64.0
+            r = np.rint(v)
+            assert np.array_equal(v, r) and np.abs(r).max() < 32000
+            out[f"out{k}_{a}"] = r.astype(np.int16)
+    np.savez_compressed(OUT / "g16_sync_fields_3d_patches.npz", **out)
+
+
+def g17_sync_particles_3d_patches():
+    """3-D particle ownership between DIFFERENT patches: the same 2 x 2 x 2 periodic patches, every particle displaced by
+    up to 0.95 cell per axis so that leavers go through faces, edges and corners into seven different neighbours (and
+    around the box: +- L); dead slots every 11th.  `get_npart_to_extend_3d` + `fill_particles_from_boundary_3d`
+    (`core/patch/sync_particles_3d.c:365-482,484-700`) driven like `Patches.sync_particles` (`core/patch/patch.py:739-763`)."""
+    from lambdapic_amd.patch import make_patches_3d
+    mod = oracle.ref_module("patch", "sync_particles_3d")
+    rng = np.random.default_rng(SEED + 17)
+    npp, npatch = (6, 6, 7), (2, 2, 2)
+    d = (1.0e-7, 1.5e-7, 0.8e-7)
+    P = make_patches_3d(tuple(a * b for a, b in zip(npp, npatch)), d, npatch, 3)
+    out = dict(npp=np.array(npp), npatch=np.array(npatch), d=np.array(d))
+    names = ["x", "y", "z", "ux", "w", "_id", "is_dead"]
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        n = 240 + 7 * k
+        q.initialize(n)
+        for ax, n_ax, dd in zip("xyz", npp, d):
+            getattr(q, ax)[:] = getattr(p, ax + "0") + (rng.uniform(-0.5, n_ax - 0.5, n) + rng.uniform(-0.95, 0.95, n)) * dd
+        q.ux[:] = rng.normal(size=n)
+        q.w[:] = rng.uniform(1, 2, n)
+        q.is_dead[k % 5::11] = True
+        # one sure leaver per neighbour class (corner leavers are rare among the random ones), scattered over the bag
+        from lambdapic_amd.patch import OFFSET_3D, Boundary3D
+        slots = rng.permutation(n)[:26]
+        for b, slot in zip(Boundary3D, slots):
+            for ax, off, n_ax, dd in zip("xyz", OFFSET_3D[b], npp, d):
+                lo = getattr(p, ax + "0")
+                getattr(q, ax)[slot] = lo + {-1: -0.8, 0: 0.5 * (n_ax - 1), 1: n_ax - 0.2}[off] * dd
+            q.is_dead[slot] = False
+        out.update(snap(q, names, f"pin{k}_"))
+    parts = [p.particles[0] for p in P]
+    ext, inc, outg, alive = mod.get_npart_to_extend_3d(parts, list(P), 8, *d)
+    out.update(npart_to_extend=np.asarray(ext).copy(), npart_incoming=np.asarray(inc).copy(),
+               npart_outgoing=np.asarray(outg).copy(), npart_alive=np.asarray(alive).copy())
+    for q, n in zip(parts, ext):
+        if n > 0:
+            q.extend(int(n))
+    mod.fill_particles_from_boundary_3d(parts, list(P), inc, outg, 8, *d, P.xmin_global, P.xmax_global, P.ymin_global,
+                                        P.ymax_global, P.zmin_global, P.zmax_global, parts[0].attrs)
+    for k, q in enumerate(parts):
+        out.update(snap(q, names, f"pout{k}_"))
+    assert int(np.asarray(outg).reshape(8, 26).sum(0).min()) > 0        # every neighbour class is exercised
+    np.savez_compressed(OUT / "g17_sync_particles_3d_patches.npz", **out)
+
+
 def g15_sort_variants():
     """the branches of the reference's sort that g6 does not take, recorded from its compiled extensions:
     (a) sort_particles_patches_3d (core/sort/cpu3d.c) on a 6 x 5 x 4 bucket grid with dead slots and out-of-range
@@ -758,6 +835,10 @@ def main():
     if "--only-g15" in sys.argv:
         g15_sort_variants()
         return
+    if "--only-g16" in sys.argv:
+        g16_sync_fields_3d_patches()
+        g17_sync_particles_3d_patches()
+        sys.exit(0)
     if "--only-g14" in sys.argv:
         g14_sync_particles_3d()
         return
@@ -787,6 +868,8 @@ def main():
     g12_cpml_laser_3d()
     g13_sync_3d()
     g14_sync_particles_3d()
+    g16_sync_fields_3d_patches()
+    g17_sync_particles_3d_patches()
     g15_sort_variants()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -370,3 +370,64 @@ def test_g15_sort_variants(golden):
         # the reference's output: slot s holds input slot tag[s]; every slot holds a particle of its bucket
         src = g[f"{tag}_out_tag"].astype(np.int64)
         assert np.array_equal(np.sort(src), np.arange(src.size)) and np.array_equal(idx[src], ref)
+
+
+# ---- 3-D patch lists: 2 x 2 x 2 periodic patches, every neighbour class another patch (g16 / g17) ----------------
+def _g16_patches(g, prefix):
+    from lambdapic_amd.patch import make_patches_3d
+    npp, npatch, ng = tuple(int(v) for v in g["npp"]), tuple(int(v) for v in g["npatch"]), int(g["ng"])
+    P = make_patches_3d(tuple(a * b for a, b in zip(npp, npatch)), (1e-7, 1.5e-7, 0.8e-7), npatch, ng)
+    assert np.array_equal(np.stack([p.neighbor_ipatch for p in P]), g["neighbor_ipatch"])     # the table the reference got
+    for k, p in enumerate(P):
+        for a in ("ex", "by", "bz", "jx", "jy", "jz", "rho"):
+            getattr(p.fields, a)[...] = g[f"{prefix}{k}_{a}"] / float(g["scale"])
+    return P, npp, ng
+
+
+def test_g16_sync_fields_3d_patch_list(golden):
+    """the oracle's sync_guard_fields_3d / sync_currents_3d against the reference's compiled extension on 2 x 2 x 2
+    periodic patches (core/patch/sync_fields3d.c:84-348,350-612): copies and folds exact"""
+    g = golden("g16_sync_fields_3d_patches")
+    P, npp, ng = _g16_patches(g, "in")
+    fl = [p.fields for p in P]
+    sync.sync_guard_fields_3d(fl, list(P), ["ex", "by", "bz"], 8, *npp, ng)
+    sync.sync_currents_3d(fl, list(P), 8, *npp, ng)
+    for k, p in enumerate(P):
+        for a in ("ex", "by", "bz", "jx", "jy", "jz", "rho"):
+            assert np.array_equal(getattr(p.fields, a) * float(g["scale"]), g[f"out{k}_{a}"].astype(float)), (k, a)
+
+
+def _g17_patches(g):
+    from lambdapic_amd.patch import make_patches_3d
+    npp, npatch, d = tuple(int(v) for v in g["npp"]), tuple(int(v) for v in g["npatch"]), tuple(float(v) for v in g["d"])
+    P = make_patches_3d(tuple(a * b for a, b in zip(npp, npatch)), d, npatch, 3)
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        q.initialize(g[f"pin{k}_x"].size)
+        for a in ("x", "y", "z", "ux", "w", "_id", "is_dead"):
+            getattr(q, a)[:] = g[f"pin{k}_{a}"]
+    return P, d
+
+
+def _check_g17_out(g, P):
+    for k, p in enumerate(P):
+        q = p.particles[0]
+        assert q.npart == g[f"pout{k}_x"].size, k
+        assert np.array_equal(q.is_dead, g[f"pout{k}_is_dead"]), k                # slot for slot
+        live = ~q.is_dead
+        for a in ("x", "y", "z", "ux", "w", "_id"):
+            assert np.array_equal(getattr(q, a)[live].view(np.uint64), g[f"pout{k}_{a}"][live].view(np.uint64)), (k, a)
+        for a in "xyz":                                                           # 3-D: dead slots are blanked
+            assert np.isnan(getattr(q, a)[~live]).all() and np.isnan(g[f"pout{k}_{a}"][~live]).all(), (k, a)
+
+
+def test_g17_sync_particles_3d_patch_list(golden):
+    """the oracle's sync_particles_3d against get_npart_to_extend_3d + fill_particles_from_boundary_3d of the
+    reference (core/patch/sync_particles_3d.c:365-700) on 2 x 2 x 2 periodic patches: counts, slot placement, +- L,
+    is_dead pattern and blanked dead slots bit exact"""
+    g = golden("g17_sync_particles_3d_patches")
+    P, d = _g17_patches(g)
+    alive = sync.sync_particles_3d(P, 0, d)
+    assert np.array_equal(alive, g["npart_alive"])
+    _check_g17_out(g, P)
+    assert int(g["npart_outgoing"].reshape(8, 26).sum(0).min()) > 0              # all 26 classes move particles
