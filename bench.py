@@ -167,18 +167,27 @@ def cpu_baseline(args):
         one_step()
         steps += 1
     el = time.perf_counter() - t0
-    # how the port compares with the reference's own compiled kernel: measured in the build container, where
-    # both exist (oracle/cpu_ratio.py -> profiles/r01_cpu_port_vs_reference.txt); the reference cannot travel
-    ratio = None
+    # how the port compares with the reference's own compiled kernel: measured in the build container, where both
+    # exist (python -m oracle.cpu_ratio -> profiles/r03_cpu_port_vs_reference.txt, which names the sha256 of the
+    # oracle source it timed); the reference cannot travel.  Refused when oracle/picoracle.c changed since.
+    ratio, ratio_src = None, "profiles/r03_cpu_port_vs_reference.txt missing"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_cpu_port_vs_reference.txt")) as fh:
-            ratio = float(fh.read().strip().split("=")[-1])
-    except (OSError, ValueError):
-        pass
+        import hashlib
+        with open(os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.txt")) as fh:
+            txt = fh.read()
+        with open(os.path.join(ROOT, "oracle", "picoracle.c"), "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+        rec = [ln.split("=")[-1].strip() for ln in txt.splitlines() if ln.startswith("oracle/picoracle.c sha256")]
+        if rec and rec[0] == sha:
+            ratio = float(txt.strip().splitlines()[-1].split("=")[-1])
+            ratio_src = (f"recorded in the build container (python -m oracle.cpu_ratio -> "
+                         f"profiles/r03_cpu_port_vs_reference.txt @ oracle/picoracle.c {sha}); the reference cannot travel")
+        else:
+            ratio_src = "recorded ratio is for another oracle/picoracle.c: re-run python -m oracle.cpu_ratio"
+    except (OSError, ValueError) as e:
+        ratio_src = f"no recorded ratio ({e.__class__.__name__})"
     return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "port_over_reference_same_cores": ratio,
-            "port_over_reference_source": "recorded in the build container (oracle/cpu_ratio.py -> "
-                                          "profiles/r01_cpu_port_vs_reference.txt); the reference cannot travel",
+            "port_over_reference_same_cores": ratio, "port_over_reference_source": ratio_src,
             "parity_c1": parity_c1(),
             "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
                       f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
@@ -200,7 +209,7 @@ def recorded_traffic(args, kernel_prefix):
     """HBM bytes of one K1 launch from the committed rocprofv3 --pmc passes (tools/prof_pmc.sh ->
     tools/make_traffic_json.py): counters cannot be read from inside this process.  Refused (None + the reason)
     when the file was recorded for another kernel, another workload or other kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r02_k1_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_k1_traffic.json")
     try:
         with open(path) as fh:
             tr = json.load(fh)
@@ -212,7 +221,7 @@ def recorded_traffic(args, kernel_prefix):
         return None, "traffic profile is for another kernel"
     if tr.get("source_sha256_16") != source_hash():
         return None, "traffic profile predates the current kernel sources: re-run tools/prof_pmc.sh"
-    return tr["traffic_bytes_per_launch"], f"recorded: profiles/r02_k1_traffic.json @ sources {tr['source_sha256_16']}"
+    return tr["traffic_bytes_per_launch"], f"recorded: profiles/r03_k1_traffic.json @ sources {tr['source_sha256_16']}"
 
 
 class StageTimer:
@@ -369,7 +378,7 @@ def recorded_traffic_3d():
     8 ppc slab of tools/bench3d.py -- the same kernel, another particle set than this leg's); refused for other sources"""
     import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_k13d_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_k13d_traffic.json")) as fh:
             tr = json.load(fh)
         h = hashlib.sha256()
         for f in ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp"):
@@ -378,7 +387,7 @@ def recorded_traffic_3d():
         if tr.get("source_sha256_16") != h.hexdigest()[:16]:
             return {"traffic_per_algorithmic_byte": None, "traffic_source": "3-D traffic profile predates the kernel sources"}
         return {"traffic_per_algorithmic_byte": tr["traffic_per_algorithmic_byte"],
-                "traffic_source": f"recorded: profiles/r02_k13d_traffic.json (tools/bench3d.py slab) @ sources {tr['source_sha256_16']}"}
+                "traffic_source": f"recorded: profiles/r03_k13d_traffic.json (tools/bench3d.py slab) @ sources {tr['source_sha256_16']}"}
     except Exception as e:   # noqa: BLE001
         return {"traffic_per_algorithmic_byte": None, "traffic_source": f"no 3-D traffic profile ({e.__class__.__name__})"}
 

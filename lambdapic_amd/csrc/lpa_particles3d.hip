@@ -317,9 +317,11 @@ constexpr int R3X = T3X + 2 * H3, R3Y = T3Y + 2 * H3, R3Z = T3Z + 2 * H3;  // 10
 #ifndef LPA_R3ZS
 #define LPA_R3ZS (LPA_EB_PAIRED ? 22 : 24)
 #endif
-constexpr int R3ZS = LPA_R3ZS;   // z stride of the J image (>= R3Z): 24 makes the x stride (240) a multiple of 16
-                                 // doubles, so a lane that drifted along x keeps its bank (-3 % against 22)
-constexpr int R3N = R3X * R3Y * R3ZS;
+#ifndef LPA_R3ZS_NORHO
+#define LPA_R3ZS_NORHO 32
+#endif
+// (LPA_R3ZS: z stride of the J image (>= R3Z) of the kernel that deposits rho: 24 makes the x stride (240) a multiple
+// of 16 doubles, so a lane that drifted along x keeps its bank (-3 % against 22))
 constexpr int G3L = LPA_TILE3_MARGIN + 2, G3H = LPA_TILE3_MARGIN + 1;      // gather reach below / above the tile
 constexpr int E3X = T3X + G3L + G3H, E3Y = T3Y + G3L + G3H, E3Z = T3Z + G3L + G3H;  // 9 x 9 x 21
 constexpr int E3N = E3X * E3Y * E3Z;                                       // 1701
@@ -431,7 +433,14 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
     const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
     uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols, Scratch8 sc) {
-    constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho): without rho the image is 58 KB instead of 77 KB
+    constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho)
+    // z stride of the J image.  Without rho three components fit at stride LPA_R3ZS_NORHO = 32 (77 KB): y stride 32
+    // and x stride 320 are both 0 mod 16 doubles, so the bank of a ds_add_f64 depends on the lane's z cell alone -- the
+    // 16 lanes of a group conflict only where two of them sit in the same z cell, whatever columns a compacted
+    // (partial) stripe draws them from.  With rho (four components) only stride 24 fits beside the E / B image.
+    constexpr int R3ZS = RHO ? LPA_R3ZS : LPA_R3ZS_NORHO;
+    constexpr int R3N = R3X * R3Y * R3ZS;
+    static_assert(R3ZS >= R3Z, "J image z stride");
     __shared__ double s_j[NJ][R3N];
     __shared__ double s_eb[3 * EBN];     // see eb_base()
     __shared__ int s_ncross;
@@ -468,6 +477,7 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
     const int lane = threadIdx.x & 63;
     if (DEFER && threadIdx.x == 0) s_ncross = 0;
     for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
+        if (R3ZS > R3Z + 2 && t % R3ZS >= R3Z) continue;       // (stride padding is never read)
 #pragma unroll
         for (int c = 0; c < NJ; c++) s_j[c][t] = 0.0;
     }

@@ -53,6 +53,10 @@ def main():
         out[name] = n * steps / el
         print(f"{name:9s}: {out[name]:.3e} particle-updates/s (fused push+deposit only, {n} particles, "
               f"{os.cpu_count()} cpus, {threads} OpenMP threads)")
+    import hashlib
+    from pathlib import Path
+    sha = hashlib.sha256((Path(__file__).resolve().parent / "picoracle.c").read_bytes()).hexdigest()[:16]
+    print(f"oracle/picoracle.c sha256[:16] = {sha}")
     print(f"port / reference = {out['port'] / out['reference']:.3f}")
 
 

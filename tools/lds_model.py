@@ -24,6 +24,9 @@ ap.add_argument("--ebsx", type=int, default=189)
 ap.add_argument("--tiles", type=int, nargs=3, default=[2, 4, 2])
 ap.add_argument("--pad-min", type=int, default=192)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--orders", nargs="*", default=["striped", "padded"],
+                help="striped / padded (the sort's orders) / column (model only: stripes over the 16 z-cells of one "
+                     "(x, y) column at a time, rank after rank, columns one after the other)")
 a = ap.parse_args()
 
 T = np.array([4, 4, 16])
@@ -40,7 +43,7 @@ vel = rng.standard_normal((n, 3)) * 0.0442 * cdt * np.array([20.0, 10.0, 10.0])
 pos = (pos + 40 * vel + 0.5) % ncell - 0.5
 
 
-def order_of(sort_pos, padded):
+def order_of(sort_pos, padded, column=False):
     """returns, per tile, the list of particle indices in slot order (-1 = hole)"""
     node = np.floor(sort_pos + 0.5).astype(int) % ncell
     tile = node // T
@@ -55,6 +58,10 @@ def order_of(sort_pos, padded):
         idx, c = idx[o], c[o]
         first = np.searchsorted(c, c, side="left")
         rank = np.arange(len(c)) - first
+        if column:
+            o2 = np.lexsort((c % 16, rank, c // 16))          # column, then rank, then z
+            out.append((t, idx[o2]))
+            continue
         slots = []
         for r in range(rank.max() + 1):
             m = rank == r
@@ -85,9 +92,10 @@ def group_cost(bank, addr, active, width, same_addr_broadcast):
     return float(np.mean(costs)), len(costs)
 
 
-def run(padded):
-    orders = order_of(pos, padded)
-    print(f"--- {'padded' if padded else 'striped'} order, {a.ppc} ppc, J z stride {a.r3zs}, E/B strides {a.ebsx}/{a.ebsy}")
+def run(kind):
+    padded = kind == "padded"
+    orders = order_of(pos, padded, kind == "column")
+    print(f"--- {kind} order, {a.ppc} ppc, J z stride {a.r3zs}, E/B strides {a.ebsx}/{a.ebsy}")
     for age in a.ages:
         p_mid = pos + (age + 0.5) * vel              # position the gather sees (half step after `age` full steps)
         p_new = pos + (age + 1.0) * vel
@@ -122,5 +130,5 @@ def run(padded):
         print(f"age {age}: stayers {stay / alive:.3f} of alive, lanes used {alive / slots_n:.3f}; cost x ideal: {s}")
 
 
-run(False)
-run(True)
+for kind in a.orders:
+    run(kind)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r02_k1_traffic.json from the 'fetch' and 'write' passes of tools/prof_pmc.sh.
+"""profiles/r03_k1_traffic.json from the 'fetch' and 'write' passes of tools/prof_pmc.sh.
 
 usage: tools/make_traffic_json.py <pmc-outdir> [2d|3d]   (run where the passes were collected, or on their merged
-gpurun_out copy; 3d = the passes of tools/prof_pmc3d.sh -> profiles/r02_k13d_traffic.json).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KB; on gfx950
+gpurun_out copy; 3d = the passes of tools/prof_pmc3d.sh -> profiles/r03_k13d_traffic.json).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KB; on gfx950
 FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md, HBM section).  The file carries the hash of
 the kernel sources it was measured on; bench.py refuses it for any other."""
 import csv, glob, json, os, sys
@@ -31,6 +31,8 @@ out = {"kernel": name.replace("void ", "").split("(")[0].replace(", ", ","),
                  {"nx": 64, "ny": 256, "nz": 256, "ppc": 8, "particles": 33554432, "algorithmic_bytes_per_launch": 121.0 * 33554432},
        "FETCH_SIZE_KB_mean": mean("FETCH_SIZE"), "WRITE_SIZE_KB_mean": mean("WRITE_SIZE"),
        "launches": len(vals["FETCH_SIZE"]),
+       "launch_mix": "mean over every launch of the passes: the first push after the sort deposits rho (real deposit), "
+                     "the others run with LPA_PUSH_NO_RHO (rho from the continuity equation)",
        "correction": "gfx950: FETCH_SIZE x 2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
        "traffic_bytes_per_launch": (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024.0,
        "source_sha256_16": h.hexdigest()[:16],
@@ -39,5 +41,5 @@ out = {"kernel": name.replace("void ", "").split("(")[0].replace(", ", ","),
                  "tools/prof_pmc3d.sh passes 'fetch' and 'write', tools/bench3d.py --steps 4 --warmup 2 (uniform 8 ppc slab)"}
 if mode == "3d":
     out["traffic_per_algorithmic_byte"] = out["traffic_bytes_per_launch"] / out["config"]["algorithmic_bytes_per_launch"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_k1_traffic.json" if mode == "2d" else "r02_k13d_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_k1_traffic.json" if mode == "2d" else "r03_k13d_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
