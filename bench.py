@@ -367,6 +367,8 @@ def extra_c5(steps=40, warm=12):
                         "steps (Simulation3D stage loop)",
             "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": ms, "steps": steps,
             "alive": int(alive), "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
+            "species_launches": "e- and p in ONE K1-3D launch per step (lpa_push_deposit_tiled_multi_3d)"
+                                if eng.fuse_species else "one K1-3D launch per species",
             "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_3d", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch_set": b_k1,
                          "achieved": b_k1 / (k_ms * 1e-3) / 1e9, "frac": b_k1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -374,11 +376,11 @@ def extra_c5(steps=40, warm=12):
 
 
 def recorded_traffic_3d():
-    """HBM bytes per algorithmic byte of K1-3D from the committed counter passes (tools/prof_pmc3d.sh on the uniform
-    8 ppc slab of tools/bench3d.py -- the same kernel, another particle set than this leg's); refused for other sources"""
+    """HBM bytes per algorithmic byte of the K1-3D launch of THIS leg (e- + p in one launch) from the committed counter
+    passes (tools/prof_pmc_c5.sh on tools/bench_c5leg.py -> profiles/r03_k13d_c5_traffic.json); refused for other sources"""
     import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_k13d_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_k13d_c5_traffic.json")) as fh:
             tr = json.load(fh)
         h = hashlib.sha256()
         for f in ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp"):
@@ -387,7 +389,7 @@ def recorded_traffic_3d():
         if tr.get("source_sha256_16") != h.hexdigest()[:16]:
             return {"traffic_per_algorithmic_byte": None, "traffic_source": "3-D traffic profile predates the kernel sources"}
         return {"traffic_per_algorithmic_byte": tr["traffic_per_algorithmic_byte"],
-                "traffic_source": f"recorded: profiles/r03_k13d_traffic.json (tools/bench3d.py slab) @ sources {tr['source_sha256_16']}"}
+                "traffic_source": f"recorded: profiles/r03_k13d_c5_traffic.json (this leg, tools/prof_pmc_c5.sh) @ sources {tr['source_sha256_16']}"}
     except Exception as e:   # noqa: BLE001
         return {"traffic_per_algorithmic_byte": None, "traffic_source": f"no 3-D traffic profile ({e.__class__.__name__})"}
 

@@ -324,6 +324,15 @@ int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_particles *p,
 int lpa_push_deposit_list_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                              const uint32_t *list, const uint32_t *list_count, int64_t max_count,
                              void *stream);
+/* the tiled 3-D kernel for up to four species in ONE launch (the reference pushes its species one after the other,
+ * simulation.py:983-990; with no callback between them the order is immaterial: they add into the same J).  A
+ * workgroup per tile stages the tile's E / B image once, runs every species' particles of that tile and flushes J
+ * once -- the staging is 82 KB per tile, as much as 700 particles.  p / pp / t / overflow / overflow_count are HOST
+ * arrays of `nspecies` pointers; the species share the grid, dt, wrap and flags; each species' overflow list is
+ * finished with lpa_push_deposit_list_3d as after the single-species form. */
+int lpa_push_deposit_tiled_multi_3d(const lpa_grid *g, int32_t nspecies, const lpa_particles *const *p,
+                                    const lpa_push_params *const *pp, const lpa_tiling *const *t,
+                                    uint32_t *const *overflow, uint32_t *const *overflow_count, void *stream);
 
 /* ---- split kernels of the callback-in-pusher-stage path
  *      interpolation_patches_2d (core/interpolation/cpu2d.c:71-136), boris_push_patches
@@ -523,6 +532,8 @@ typedef struct {
     double dt, eps0;
     const lpa_cpml_axis *e_axes[3], *b_axes[3];   /* all NULL: plain Yee update; else the fused CPML descriptors */
     int32_t nspecies, continuity;
+    int32_t fuse_species;       /* 3-D: push all tile-ordered species with ONE lpa_push_deposit_tiled_multi_3d launch */
+    int32_t reserved_;
     const lpa_step_species *species;
     double *absorbed;           /* see lpa_push_params.absorbed (NULL: no face absorbs) */
     uint32_t *absorbed_count;

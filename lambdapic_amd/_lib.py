@@ -82,7 +82,8 @@ class lpa_step_species(C.Structure):
 class lpa_step_desc(C.Structure):
     _fields_ = [("grid", lpa_grid), ("dim", C.c_int32), ("local_axes", C.c_int32), ("dt", C.c_double), ("eps0", C.c_double),
                 ("e_axes", C.POINTER(lpa_cpml_axis) * 3), ("b_axes", C.POINTER(lpa_cpml_axis) * 3),
-                ("nspecies", C.c_int32), ("continuity", C.c_int32), ("species", C.POINTER(lpa_step_species)),
+                ("nspecies", C.c_int32), ("continuity", C.c_int32), ("fuse_species", C.c_int32), ("reserved_", C.c_int32),
+                ("species", C.POINTER(lpa_step_species)),
                 ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64)]
 
 
@@ -132,6 +133,8 @@ SIGNATURES = {
     "lpa_push_deposit_tiled_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _vp]),
     "lpa_push_deposit_tiled_part_3d": (_i, [_G, _P, _PP, _T, _vp, _vp, _i, _i, _vp]),
     "lpa_push_deposit_list_3d": (_i, [_G, _P, _PP, _vp, _vp, _i64, _vp]),
+    "lpa_push_deposit_tiled_multi_3d": (_i, [_G, C.c_int32, C.POINTER(_P), C.POINTER(_PP), C.POINTER(_T),
+                                            C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "lpa_interpolate_2d": (_i, [_G, _P, _vp]),
     "lpa_boris": (_i, [_P, _d, _d, _d, _vp]),
     "lpa_push_position_2d": (_i, [_P, _d, _vp]),

@@ -423,78 +423,85 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
 struct Scratch8 { double *a[8]; };
 __device__ __forceinline__ int clamp3(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
-// LPA_K13_PERSIST = N > 0: the kernel is launched with at most N workgroups per CU-count (256 x N) and every workgroup
-// walks the work blocks wb, wb + gridDim.x, ... instead of one workgroup per work block
-#ifndef LPA_K13_PERSIST
-#define LPA_K13_PERSIST 0
-#endif
-template <bool DEFER, bool RHO>
-__global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
-    GridV g, PartV p, PushK3 k, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
-    const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int tiles_y, int tiles_z,
-    uint32_t *overflow, uint32_t *overflow_count, int part, int tiles_x, int edge_cols, Scratch8 sc) {
-    constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho)
+// ---- the three phases of one workgroup's visit of a tile: images (zero J, stage E / B), the particles of one species,
+// flush.  The single-species kernel runs them once each; the multi-species kernel runs the middle one per species
+// between ONE staging and ONE flush (the E / B image is 82 KB per tile: for two species of 2048 particles per tile it is
+// a quarter of the launch's HBM traffic and most of its per-tile fixed cost).
+template <bool RHO> struct K13Geom {
+    static constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho)
     // z stride of the J image.  Without rho three components fit at stride LPA_R3ZS_NORHO = 32 (77 KB): y stride 32
     // and x stride 320 are both 0 mod 16 doubles, so the bank of a ds_add_f64 depends on the lane's z cell alone -- the
     // 16 lanes of a group conflict only where two of them sit in the same z cell, whatever columns a compacted
     // (partial) stripe draws them from.  With rho (four components) only stride 24 fits beside the E / B image.
-    constexpr int R3ZS = RHO ? LPA_R3ZS : LPA_R3ZS_NORHO;
-    constexpr int R3N = R3X * R3Y * R3ZS;
+    static constexpr int R3ZS = RHO ? LPA_R3ZS : LPA_R3ZS_NORHO;
+    static constexpr int R3N = R3X * R3Y * R3ZS;
     static_assert(R3ZS >= R3Z, "J image z stride");
-    __shared__ double s_j[NJ][R3N];
-    __shared__ double s_eb[3 * EBN];     // see eb_base()
-    __shared__ int s_ncross;
-#if LPA_K13_PERSIST
-    const int nb = *n_blocks;
-    for (int wb = (int)blockIdx.x; wb < nb; wb += (int)gridDim.x) {
-    if (wb != (int)blockIdx.x) __syncthreads();   // the flush of the previous block has read the images
-#endif
-    // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
-    // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
-    // 4.51 ms per step, tools/exp_k13.sh with LPA_XCD_ORDER_3D) and idles XCDs in an edge / interior part launch
-#if !LPA_K13_PERSIST
-    const int nb = *n_blocks, chunk = (nb + 7) >> 3;
-#ifdef LPA_XCD_ORDER_3D
-    const int wb = part ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-#else
-    const int wb = (int)blockIdx.x;
-#endif
-    if ((int)blockIdx.x >= 8 * chunk || wb >= nb) return;  // block-uniform
-#endif
-    const int tile = blk_tile[wb];
-    const int begin = blk_begin[wb], end = blk_end[wb];
-    const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y, tx_ = tile / (tiles_z * tiles_y);
-    if (part) {  // LPA_PART_EDGE / LPA_PART_INTERIOR: see lpa_push_deposit_tiled_part_2d
-        const bool edge = tx_ < edge_cols || tx_ >= tiles_x - edge_cols;
-#if LPA_K13_PERSIST
-        if ((part == LPA_PART_EDGE) != edge) continue;  // block-uniform, before any barrier of this block
-#else
-        if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform, before any barrier
-#endif
-    }
-    const int t0[3] = {tx_ * T3X, ty_ * T3Y, tz_ * T3Z};          // first node of the tile
-    const int r0[3] = {t0[0] - H3, t0[1] - H3, t0[2] - H3};       // first node of the LDS region
-    const int lane = threadIdx.x & 63;
-    if (DEFER && threadIdx.x == 0) s_ncross = 0;
+};
+
+struct TileCtx { int t0[3], r0[3], e0[3]; };   // first node of the tile, of the J region, of the E / B image
+
+__device__ __forceinline__ TileCtx tile_ctx(int tile, int tiles_y, int tiles_z, int &tx_) {
+    const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y;
+    tx_ = tile / (tiles_z * tiles_y);
+    TileCtx c;
+    c.t0[0] = tx_ * T3X; c.t0[1] = ty_ * T3Y; c.t0[2] = tz_ * T3Z;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { c.r0[a] = c.t0[a] - H3; c.e0[a] = c.t0[a] - G3L; }
+    return c;
+}
+
+template <bool RHO>
+__device__ __forceinline__ void tile_images(const GridV &g, int wrap, const TileCtx &tc,
+                                            double (*s_j)[K13Geom<RHO>::R3N], double *s_eb) {
+    constexpr int NJ = K13Geom<RHO>::NJ, R3ZS = K13Geom<RHO>::R3ZS, R3N = K13Geom<RHO>::R3N;
     for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
         if (R3ZS > R3Z + 2 && t % R3ZS >= R3Z) continue;       // (stride padding is never read)
 #pragma unroll
         for (int c = 0; c < NJ; c++) s_j[c][t] = 0.0;
     }
-    const int e0[3] = {t0[0] - G3L, t0[1] - G3L, t0[2] - G3L};    // first node of the E/B image
-    {
-        const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
-        for (int t = threadIdx.x; t < E3N; t += blockDim.x) {
-            int lz = t % E3Z, ly = (t / E3Z) % E3Y, lx = t / (E3Z * E3Y);
-            long gi = ((long)node_index(e0[0] + lx, g.nx, g.ng, g.NX, k.wrap & 1) * g.NY +
-                       node_index(e0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
-                      node_index(e0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
+    const double *src[6] = {g.ex, g.ey, g.ez, g.bx, g.by, g.bz};
+    for (int t = threadIdx.x; t < E3N; t += blockDim.x) {
+        int lz = t % E3Z, ly = (t / E3Z) % E3Y, lx = t / (E3Z * E3Y);
+        long gi = ((long)node_index(tc.e0[0] + lx, g.nx, g.ng, g.NX, wrap & 1) * g.NY +
+                   node_index(tc.e0[1] + ly, g.ny, g.ng, g.NY, wrap & 2)) * g.NZ +
+                  node_index(tc.e0[2] + lz, g.nz, g.ng, g.NZ, wrap & 4);
 #pragma unroll
-            for (int c = 0; c < 6; c++) s_eb[eb_base(c) + lx * EBSX + ly * EBSY + lz] = src[c][gi];
+        for (int c = 0; c < 6; c++) s_eb[eb_base(c) + lx * EBSX + ly * EBSY + lz] = src[c][gi];
+    }
+}
+
+// flush: one FP64 global atomic per touched node and component, on the torus
+template <bool RHO>
+__device__ __forceinline__ void tile_flush(const GridV &g, int wrap, const TileCtx &tc,
+                                           double (*s_j)[K13Geom<RHO>::R3N]) {
+    constexpr int NJ = K13Geom<RHO>::NJ, R3ZS = K13Geom<RHO>::R3ZS, R3N = K13Geom<RHO>::R3N;
+    double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
+    for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
+        int lz = t % R3ZS, ly = (t / R3ZS) % R3Y, lx = t / (R3ZS * R3Y);
+        if (lz >= R3Z) continue;   // stride padding
+        long gi = ((long)node_index(tc.r0[0] + lx, g.nx, g.ng, g.NX, wrap & 1) * g.NY +
+                   node_index(tc.r0[1] + ly, g.ny, g.ng, g.NY, wrap & 2)) * g.NZ +
+                  node_index(tc.r0[2] + lz, g.nz, g.ng, g.NZ, wrap & 4);
+#pragma unroll
+        for (int c = 0; c < NJ; c++) {
+            double v = s_j[c][t];
+            if (v != 0.0) atomicAdd(&dst[c][gi], v);
         }
     }
-    __syncthreads();
+}
 
+// the particles [begin, end) of one species in this tile: main loop (+ the dense second pass of the cell-crossers).
+// On entry the images are ready and *s_ncross == 0 (both behind a barrier); on exit every lane has issued its LDS atomics
+// (the caller puts a barrier before it reads s_j or starts the next species).
+template <bool DEFER, bool RHO>
+__device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, const PushK3 &k, const int begin,
+                                             const int end, const Scratch8 &sc, uint32_t *overflow,
+                                             uint32_t *overflow_count, const TileCtx &tc,
+                                             double (*s_j)[K13Geom<RHO>::R3N], double *s_eb, int *s_ncross_p) {
+    constexpr int NJ = K13Geom<RHO>::NJ, R3ZS = K13Geom<RHO>::R3ZS;
+    const int *t0 = tc.t0, *r0 = tc.r0, *e0 = tc.e0;
+    const int lane = threadIdx.x & 63;
+    int &s_ncross = *s_ncross_p;
     const double inv_dx = k.inv_d[0], inv_dy = k.inv_d[1], inv_dz = k.inv_d[2];
     [[maybe_unused]] double abl3v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // LPA_ABLATE3_* diagnostic builds (independent chains)
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
@@ -739,7 +746,6 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
                 });
         }
     }
-    __syncthreads();
 #ifdef LPA_ABLATE3_NO_ATOMICS
     {
         double abl3 = 0.0;
@@ -747,25 +753,66 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         if (abl3 == 1.2345e-300) s_j[0][0] = abl3;  // keeps the ablated arithmetic alive
     }
 #endif
-    // flush: one FP64 global atomic per touched node and component, on the torus
-    {
-        double *dst[4] = {g.jx, g.jy, g.jz, g.rho};
-        for (int t = threadIdx.x; t < R3N; t += blockDim.x) {
-            int lz = t % R3ZS, ly = (t / R3ZS) % R3Y, lx = t / (R3ZS * R3Y);
-            if (lz >= R3Z) continue;   // stride padding
-            long gi = ((long)node_index(r0[0] + lx, g.nx, g.ng, g.NX, k.wrap & 1) * g.NY +
-                       node_index(r0[1] + ly, g.ny, g.ng, g.NY, k.wrap & 2)) * g.NZ +
-                      node_index(r0[2] + lz, g.nz, g.ng, g.NZ, k.wrap & 4);
-#pragma unroll
-            for (int c = 0; c < NJ; c++) {
-                double v = s_j[c][t];
-                if (v != 0.0) atomicAdd(&dst[c][gi], v);
-            }
-        }
+}
+
+// One kernel, two work partitions.  Work blocks (blk_tile != nullptr; ONE species): a workgroup per (tile, particle
+// range) of the sort's block table -- tiles with more particles than a block get several workgroups, and an edge /
+// interior part launch skips the other part's tiles.  Whole tiles (blk_tile == nullptr; up to four species): a
+// workgroup per tile stages the E / B image once, runs every species' particles of that tile (ranges from the species'
+// own tile_off tables) and flushes J once -- the staging is 82 KB per tile, as much as 700 particles.
+// The per-species arguments live in an array indexed at run time even for one species: taken as plain kernel arguments
+// the compiler keeps all ~60 of them in SGPRs for the whole kernel and spills 90 more (2.89 against 2.62 ms).
+constexpr int K13_MAX_SPECIES = 4;
+struct MultiSp {
+    PartV p;
+    PushK3 k;
+    Scratch8 sc;
+    const int32_t *tile_off;
+    uint32_t *overflow, *overflow_count;
+};
+struct MultiArgs { int ns; MultiSp s[K13_MAX_SPECIES]; };
+
+template <bool DEFER, bool RHO>
+__global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
+    GridV g, MultiArgs m, const int32_t *__restrict__ blk_tile, const int32_t *__restrict__ blk_begin,
+    const int32_t *__restrict__ blk_end, const int32_t *__restrict__ n_blocks, int ntiles, int tiles_y, int tiles_z,
+    int part, int tiles_x, int edge_cols) {
+    __shared__ double s_j[K13Geom<RHO>::NJ][K13Geom<RHO>::R3N];
+    __shared__ double s_eb[3 * EBN];     // see eb_base()
+    __shared__ int s_ncross;
+    // plain order: consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive tiles.  Giving
+    // every XCD a contiguous run of tiles, as the 2-D kernel does, measured 1.2 % SLOWER here (4.57 against
+    // 4.51 ms per step) and idles XCDs in an edge / interior part launch.  (Persistent workgroups walking several
+    // work blocks spilled 163 SGPRs + 35 VGPRs: 3.85 against 3.25 ms, profiles/r02_k13d_ablations.txt.)
+    const int wb = (int)blockIdx.x;
+    int tile = wb, blk_b = 0, blk_e = 0;
+    if (blk_tile) {
+        if (wb >= *n_blocks) return;  // block-uniform
+        tile = blk_tile[wb]; blk_b = blk_begin[wb]; blk_e = blk_end[wb];
+    } else {
+        if (wb >= ntiles) return;
+        bool any = false;                  // an empty tile (vacuum) costs nothing: no staging, no flush
+        for (int s = 0; s < m.ns; s++) any = any || m.s[s].tile_off[tile] < m.s[s].tile_off[tile + 1];
+        if (!any) return;                  // block-uniform
     }
-#if LPA_K13_PERSIST
+    int tx_;
+    const TileCtx tc = tile_ctx(tile, tiles_y, tiles_z, tx_);
+    if (part) {  // LPA_PART_EDGE / LPA_PART_INTERIOR: see lpa_push_deposit_tiled_part_2d
+        const bool edge = tx_ < edge_cols || tx_ >= tiles_x - edge_cols;
+        if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform, before any barrier
     }
-#endif
+    const int wrap = m.s[0].k.wrap;        // the periodic axes are the slab's: the same for every species
+    tile_images<RHO>(g, wrap, tc, s_j, s_eb);
+    for (int s = 0; s < m.ns; s++) {
+        if (threadIdx.x == 0) s_ncross = 0;
+        __syncthreads();                   // images ready / the previous species' second pass has read s_ncross
+        const int begin = blk_tile ? blk_b : m.s[s].tile_off[tile], end = blk_tile ? blk_e : m.s[s].tile_off[tile + 1];
+        if (begin < end)                   // block-uniform
+            species_pass<DEFER, RHO>(g, m.s[s].p, m.s[s].k, begin, end, m.s[s].sc, m.s[s].overflow,
+                                     m.s[s].overflow_count, tc, s_j, s_eb, &s_ncross);
+    }
+    __syncthreads();
+    tile_flush<RHO>(g, wrap, tc, s_j);
 }
 
 static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
@@ -886,6 +933,23 @@ extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles 
     return lpa_push_deposit_tiled_part_3d(g, p, pp, t, overflow, overflow_count, LPA_PART_ALL, 0, stream);
 }
 
+static int launch_tiled_3d(const lpa_grid *g, const MultiArgs &m, const lpa_tiling *t0, bool blocks, bool defer,
+                           bool rho, int part, int edge_cols, void *stream) {
+    const int ntiles = t0->tiles_x * t0->tiles_y * t0->tiles_z;
+    const unsigned grid = blocks ? (unsigned)t0->max_blocks : (unsigned)ntiles;
+#define LPA_LAUNCH_TILED3(D, R)                                                                                     \
+    hipLaunchKernelGGL((k_push_deposit_tiled_3d<D, R>), dim3(grid), dim3(K13_THREADS), 0, (hipStream_t)stream,       \
+                       make_gridv(g, 3), m, blocks ? t0->blk_tile : nullptr, blocks ? t0->blk_begin : nullptr,       \
+                       blocks ? t0->blk_end : nullptr, blocks ? t0->n_blocks : nullptr, ntiles, t0->tiles_y,         \
+                       t0->tiles_z, part, t0->tiles_x, edge_cols)
+    if (defer && rho) LPA_LAUNCH_TILED3(true, true);
+    else if (defer) LPA_LAUNCH_TILED3(true, false);
+    else if (rho) LPA_LAUNCH_TILED3(false, true);
+    else LPA_LAUNCH_TILED3(false, false);
+#undef LPA_LAUNCH_TILED3
+    return LPA_OK;
+}
+
 extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_particles *p,
                                               const lpa_push_params *pp, const lpa_tiling *t,
                                               uint32_t *overflow, uint32_t *overflow_count, int part,
@@ -903,27 +967,58 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
                 "lpa_push_deposit_tiled_3d: tile-binned stores carry no is_dead array (dead = NaN x)");
     if (t->n_sorted == 0) return LPA_OK;
     LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_3d: more than 2^29 particles in one store");
-    Scratch8 sc;
+    MultiArgs m;
+    m.ns = 1;
+    MultiSp &d = m.s[0];
+    d.p = make_partv(p);
+    d.k = make_pushk3(pp, g);
     bool defer = true;
     for (int c = 0; c < 8; c++) {
-        sc.a[c] = t->scratch[c];
-        defer = defer && sc.a[c] != nullptr;
+        d.sc.a[c] = t->scratch[c];
+        defer = defer && d.sc.a[c] != nullptr;
     }
-    unsigned grid = (unsigned)t->max_blocks;
-#if LPA_K13_PERSIST
-    if (grid > 256u * LPA_K13_PERSIST) grid = 256u * LPA_K13_PERSIST;
-#endif
-    const bool rho = !(pp->flags & LPA_PUSH_NO_RHO);
-#define LPA_LAUNCH_TILED3(D, R)                                                                                     \
-    hipLaunchKernelGGL((k_push_deposit_tiled_3d<D, R>), dim3(grid), dim3(K13_THREADS), 0, (hipStream_t)stream,       \
-                       make_gridv(g, 3), make_partv(p), make_pushk3(pp, g), t->blk_tile, t->blk_begin, t->blk_end,   \
-                       t->n_blocks, t->tiles_y, t->tiles_z, overflow, overflow_count, part, t->tiles_x, edge_cols, sc)
-    if (defer && rho) LPA_LAUNCH_TILED3(true, true);
-    else if (defer) LPA_LAUNCH_TILED3(true, false);
-    else if (rho) LPA_LAUNCH_TILED3(false, true);
-    else LPA_LAUNCH_TILED3(false, false);
-#undef LPA_LAUNCH_TILED3
+    d.tile_off = t->tile_off;
+    d.overflow = overflow;
+    d.overflow_count = overflow_count;
+    launch_tiled_3d(g, m, t, true, defer, !(pp->flags & LPA_PUSH_NO_RHO), part, edge_cols, stream);
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_3d");
+    return LPA_OK;
+}
+
+extern "C" int lpa_push_deposit_tiled_multi_3d(const lpa_grid *g, int32_t nspecies, const lpa_particles *const *p,
+                                               const lpa_push_params *const *pp, const lpa_tiling *const *t,
+                                               uint32_t *const *overflow, uint32_t *const *overflow_count,
+                                               void *stream) {
+    LPA_REQUIRE(nspecies >= 1 && nspecies <= K13_MAX_SPECIES && p && pp && t && overflow && overflow_count,
+                "lpa_push_deposit_tiled_multi_3d: 1 .. %d species", K13_MAX_SPECIES);
+    MultiArgs m;
+    m.ns = 0;
+    bool defer = true;
+    for (int s = 0; s < nspecies; s++) {
+        if (int e = check_push3(g, p[s], pp[s], "lpa_push_deposit_tiled_multi_3d")) return e;
+        LPA_REQUIRE(t[s] && t[s]->tile_off && overflow[s] && overflow_count[s], "lpa_push_deposit_tiled_multi_3d: bad tiling");
+        LPA_REQUIRE(t[s]->tiles_x == (g->nx + T3X - 1) / T3X && t[s]->tiles_y == (g->ny + T3Y - 1) / T3Y &&
+                        t[s]->tiles_z == (g->nz + T3Z - 1) / T3Z,
+                    "lpa_push_deposit_tiled_multi_3d: tiling does not match the grid");
+        LPA_REQUIRE(p[s]->is_dead == nullptr && p[s]->n < (1ll << 29),
+                    "lpa_push_deposit_tiled_multi_3d: tile-binned stores carry no is_dead array and hold < 2^29 particles");
+        LPA_REQUIRE(pp[s]->wrap == pp[0]->wrap && pp[s]->flags == pp[0]->flags && pp[s]->dt == pp[0]->dt,
+                    "lpa_push_deposit_tiled_multi_3d: the species of one launch share wrap, flags and dt");
+        if (t[s]->n_sorted == 0) continue;
+        MultiSp &d = m.s[m.ns++];
+        d.p = make_partv(p[s]);
+        d.k = make_pushk3(pp[s], g);
+        for (int c = 0; c < 8; c++) {
+            d.sc.a[c] = t[s]->scratch[c];
+            defer = defer && d.sc.a[c] != nullptr;
+        }
+        d.tile_off = t[s]->tile_off;
+        d.overflow = overflow[s];
+        d.overflow_count = overflow_count[s];
+    }
+    if (m.ns == 0) return LPA_OK;
+    launch_tiled_3d(g, m, t[0], false, defer, !(pp[0]->flags & LPA_PUSH_NO_RHO), LPA_PART_ALL, 0, stream);
+    LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_multi_3d");
     return LPA_OK;
 }
 

@@ -21,15 +21,69 @@ static int step_fields(const lpa_step_desc *d, bool efield, void *st) {
     return cpml ? lpa_fdtd_b_cpml_fused_3d(g, h, ax[0], ax[1], ax[2], st) : lpa_fdtd_b_3d(g, h, st);
 }
 
+static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
+    lpa_push_params pp = sp->pp;
+    pp.dt = d->dt;
+    pp.flags = d->continuity ? LPA_PUSH_NO_RHO : 0;
+    pp.absorbed = d->absorbed; pp.absorbed_count = d->absorbed_count; pp.absorbed_capacity = d->absorbed_capacity;
+    return pp;
+}
+
+// 3-D, fuse_species: the tile-ordered part of every species in one launch (one E / B staging per tile), then each
+// species' overflow list and loose particles; unsorted species take the per-species path below
+static int step_push_fused_3d(const lpa_step_desc *d, void *st, bool *done) {
+    const lpa_grid *g = &d->grid;
+    constexpr int MAXS = 4;
+    const lpa_particles *p[MAXS];
+    const lpa_push_params *ppp[MAXS];
+    const lpa_tiling *t[MAXS];
+    uint32_t *ovf[MAXS], *cnt[MAXS];
+    lpa_push_params pp[MAXS];
+    int idx[MAXS], n = 0;
+    for (int s = 0; s < d->nspecies && n < MAXS; s++) {
+        const lpa_step_species *sp = &d->species[s];
+        if (sp->p.n == 0 || !sp->t || sp->n_sorted <= 0) continue;
+        pp[n] = species_params(d, sp);
+        p[n] = &sp->p; ppp[n] = &pp[n]; t[n] = sp->t; ovf[n] = sp->overflow; cnt[n] = sp->overflow_count; idx[n] = s;
+        n++;
+    }
+    if (n == 0) return LPA_OK;
+    for (int k = 0; k < n; k++)
+        if (hipMemsetAsync(cnt[k], 0, sizeof(uint32_t), (hipStream_t)st) != hipSuccess) {
+            lpa_set_error("lpa_step: memset of the overflow counter failed");
+            return LPA_ERR_HIP;
+        }
+    const lpa_step_species *first = &d->species[idx[0]];
+    if (first->ev_start && hipEventRecord((hipEvent_t)first->ev_start, (hipStream_t)st) != hipSuccess) {
+        lpa_set_error("lpa_step: hipEventRecord failed");
+        return LPA_ERR_HIP;
+    }
+    if (int e = lpa_push_deposit_tiled_multi_3d(g, n, p, ppp, t, ovf, cnt, st)) return e;
+    if (first->ev_stop && hipEventRecord((hipEvent_t)first->ev_stop, (hipStream_t)st) != hipSuccess) {
+        lpa_set_error("lpa_step: hipEventRecord failed");
+        return LPA_ERR_HIP;
+    }
+    for (int k = 0; k < n; k++) {
+        const lpa_step_species *sp = &d->species[idx[k]];
+        if (int e = lpa_push_deposit_list_3d(g, &sp->p, &pp[k], sp->overflow, sp->overflow_count, sp->n_sorted, st)) return e;
+        const int64_t loose = sp->p.n - sp->n_sorted;
+        if (loose > 0)
+            if (int e = lpa_push_deposit_3d(g, &sp->p, &pp[k], sp->n_sorted, loose, st)) return e;
+        done[idx[k]] = true;
+    }
+    return LPA_OK;
+}
+
 static int step_push(const lpa_step_desc *d, void *st) {
     const lpa_grid *g = &d->grid;
+    bool done[64] = {false};
+    if (d->dim == 3 && d->fuse_species && d->nspecies <= 64)
+        if (int e = step_push_fused_3d(d, st, done)) return e;
     for (int s = 0; s < d->nspecies; s++) {
+        if (s < 64 && done[s]) continue;
         const lpa_step_species *sp = &d->species[s];
         if (sp->p.n == 0) continue;
-        lpa_push_params pp = sp->pp;
-        pp.dt = d->dt;
-        pp.flags = d->continuity ? LPA_PUSH_NO_RHO : 0;
-        pp.absorbed = d->absorbed; pp.absorbed_count = d->absorbed_count; pp.absorbed_capacity = d->absorbed_capacity;
+        lpa_push_params pp = species_params(d, sp);
         int e;
         if (sp->t && sp->n_sorted > 0) {
             if (hipMemsetAsync(sp->overflow_count, 0, sizeof(uint32_t), (hipStream_t)st) != hipSuccess) {

@@ -26,6 +26,7 @@ class FusedStepMixin:
     ``_cpml_axes``, ``pml``, ``fused_cpml``, ``local_axes``, ``eps0``, ``absorb`` and the rho mixin"""
 
     fused_step = True          # single-slab steps go through lpa_step (False: the per-stage calls)
+    fuse_species = True        # 3-D: every tile-ordered species in ONE launch (lpa_push_deposit_tiled_multi_3d)
 
     def can_fuse(self):
         return self.fused_step and self.comm.size == 1 and (self.pml is None or self.fused_cpml)
@@ -50,10 +51,12 @@ class FusedStepMixin:
                 self.sort(i)
             self._decide_phase()
         d.continuity = int(self._no_rho)
+        d.fuse_species = int(self.dim == 3 and self.fuse_species)
         if self.absorb and self.rho_continuity and self._rho_available():
             lst, cnt, cap = self._absorbed_bufs()
             d.absorbed, d.absorbed_count, d.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
         timed = self.kernel_events is not None and first <= _lib.LPA_STAGE_PUSH <= last
+        self.kernel_events_step = False    # (fused species: one launch, one event pair -- on the first tiled species)
         entries = list(self._species_entries(dt)) if first <= _lib.LPA_STAGE_PUSH <= last else []
         arr = (_lib.lpa_step_species * max(len(entries), 1))()
         stream = torch.cuda.current_stream(self.device)
@@ -63,12 +66,13 @@ class FusedStepMixin:
             e.t = C.pointer(tiling) if tiling is not None else None
             if ovf is not None:
                 e.overflow, e.overflow_count = ovf.data_ptr(), cnt_t.data_ptr()
-            if timed and tiling is not None and n_sorted > 0:
+            if timed and tiling is not None and n_sorted > 0 and not (d.fuse_species and self.kernel_events_step):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)          # (creates the HIP events; lpa_step records them again around the launch)
                 e1.record(stream)
                 e.ev_start, e.ev_stop = e0.cuda_event, e1.cuda_event
                 self.kernel_events.append((e0, e1))
+                self.kernel_events_step = True
             keep.append((pc, tiling, pp, ovf, cnt_t))
         d.nspecies, d.species = len(entries), arr
         check(self.L.lpa_step(C.byref(d), first, last, stream.cuda_stream), "lpa_step")

@@ -20,6 +20,9 @@ ap.add_argument("--order", default="striped", choices=["striped", "padded"])
 ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (gamma beta)")
 ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
                 help="rho between two sorts: from the continuity equation (default) or deposited in every step")
+ap.add_argument("--no-fuse", action="store_true", help="per-species launches (lpa_push_deposit_tiled_3d) instead of the "
+                                                       "one-launch form (lpa_push_deposit_tiled_multi_3d)")
+ap.add_argument("--species", type=int, default=1, help="split the particles over this many species (same q / m)")
 a = ap.parse_args()
 lam = 0.8e-6
 dx, dy, dz = lam / 20, lam / 10, lam / 10                 # example/laser-target-3d.py:26-31
@@ -27,6 +30,7 @@ dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
 eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3, tiled=not a.glob, sort_interval=a.sort_interval,
                   block_particles=a.block_particles)
 eng.rho_continuity = a.rho == "continuity"
+eng.fuse_species = not a.no_fuse
 n = a.nx * a.ny * a.nz * a.ppc
 if a.order == "padded":
     eng.order = _lib.LPA_ORDER_PADDED
@@ -44,7 +48,13 @@ for k in (3, 4, 5):
 data[6, :n] = 1.0 / torch.sqrt(1 + data[3, :n] ** 2 + data[4, :n] ** 2 + data[5, :n] ** 2)
 omega = 2 * np.pi * 299792458.0 / lam
 data[7, :n] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHARGE ** 2 * dx * dy * dz / a.ppc
-eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
+if a.species == 1:
+    eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
+else:          # the same particles dealt to several species (cell by cell), each in its own store
+    assert a.order == "striped"
+    for k in range(a.species):
+        part = data[:, k:n:a.species].contiguous()
+        eng.add_species_device(-constants.E_CHARGE, constants.M_E, part, part.shape[1])
 for _ in range(a.warmup):
     eng.step(dt)
 eng.kernel_events = []
@@ -58,7 +68,8 @@ k_ms = sum(x.elapsed_time(y) for x, y in eng.kernel_events) / a.steps if eng.ker
 print(json.dumps({"metric": "particle-updates/sec (3-D, %s kernel)" % ("global-memory" if a.glob else "LDS-tiled"),
                   "k1_3d_ms": k_ms, "k1_3d_frac_of_hbm": (121.0 * n / (k_ms * 1e-3) / 8e12) if k_ms else None,
                   "overflow_last_step": ov, "sort_interval": a.sort_interval, "rho": eng.rho_mode(),
-                  "rho_steps": eng.rho_steps, "value": n * a.steps / el,
+                  "rho_steps": eng.rho_steps, "species": a.species, "fused_species_launch": bool(eng.fuse_species),
+                  "value": n * a.steps / el,
                   "ms_per_step": 1e3 * el / a.steps, "particles": n, "cells": [a.nx, a.ny, a.nz],
-                  "algorithmic_GBps": (121.0 * n) * a.steps / el / 1e9, "alive": d["nalive"][0],
+                  "algorithmic_GBps": (121.0 * n) * a.steps / el / 1e9, "alive": sum(d["nalive"]),
                   "charge_rel_err": abs(d["charge"] / (n * float(data[7][0]) * -constants.E_CHARGE) - 1)}))

@@ -12,9 +12,10 @@ sys.path.insert(0, ROOT)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 d, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "2d")
-flt = "k_push_deposit_tiled_3d" if mode == "3d" else "k_push_deposit_tiled_2d"
+flt = "k_push_deposit_tiled_3d" if mode in ("3d", "c5") else "k_push_deposit_tiled_2d"
 SRC = {"2d": ("lambdapic_amd/csrc/lpa_particles.hip", "lambdapic_amd/csrc/lpa_common.hpp"),
-       "3d": ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp")}[mode]
+       "3d": ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp"),
+       "c5": ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp")}[mode]
 vals, name = {}, None
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -41,5 +42,18 @@ out = {"kernel": name.replace("void ", "").split("(")[0].replace(", ", ","),
                  "tools/prof_pmc3d.sh passes 'fetch' and 'write', tools/bench3d.py --steps 4 --warmup 2 (uniform 8 ppc slab)"}
 if mode == "3d":
     out["traffic_per_algorithmic_byte"] = out["traffic_bytes_per_launch"] / out["config"]["algorithmic_bytes_per_launch"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_k1_traffic.json" if mode == "2d" else "r03_k13d_traffic.json"), "w"), indent=1)
+if mode == "c5":
+    # the C5-slab leg (tools/bench_c5leg.py): e- + p in ONE launch; live particles from the leg's own JSON line
+    leg = None
+    for f in glob.glob(d + "/*.log"):
+        for ln in open(f):
+            if ln.startswith("{") and "alive" in ln:
+                leg = json.loads(ln)
+    alive = leg["alive"]
+    out["config"] = {"workload": "C5 slab leg of bench.py (tools/bench_c5leg.py 6 12): 64x256x256 cells, e- + p 8 ppc each, "
+                                 "both species in one launch", "alive": alive, "algorithmic_bytes_per_launch": 121.0 * alive}
+    out["source"] = "tools/prof_pmc_c5.sh passes 'fetch' and 'write', tools/bench_c5leg.py 6 12"
+    out["traffic_per_algorithmic_byte"] = out["traffic_bytes_per_launch"] / (121.0 * alive)
+name = {"2d": "r03_k1_traffic.json", "3d": "r03_k13d_traffic.json", "c5": "r03_k13d_c5_traffic.json"}[mode]
+json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))

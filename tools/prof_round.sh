@@ -15,6 +15,10 @@ echo "[0b] PMC passes (3-D slab)"; tools/prof_pmc3d.sh gpurun_out/prof_round/pmc
 python3 tools/pmc_summary.py gpurun_out/prof_round/pmc3d k_push_deposit_tiled_3d > $OUT/pmc_k13d.txt
 python3 tools/make_traffic_json.py gpurun_out/prof_round/pmc3d 3d > $OUT/traffic3d.log 2>&1
 cp profiles/r03_k13d_traffic.json $OUT/ 2>/dev/null
+echo "[0c] PMC passes (C5 slab leg, e- + p in one launch)"; tools/prof_pmc_c5.sh gpurun_out/prof_round/pmc_c5
+python3 tools/pmc_summary.py gpurun_out/prof_round/pmc_c5 k_push_deposit_tiled_3d > $OUT/pmc_k13d_c5.txt
+python3 tools/make_traffic_json.py gpurun_out/prof_round/pmc_c5 c5 > $OUT/traffic_c5.log 2>&1
+cp profiles/r03_k13d_c5_traffic.json $OUT/ 2>/dev/null
 cd /tmp
 echo "[1] bench.py"; timeout -k 10 500 python3 $ROOT/bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "   exit $?"
 echo "[1b] bench.py --steps 100 --warmup 10 (SURVEY 8d step counts)"; timeout -k 10 300 python3 $ROOT/bench.py --steps 100 --warmup 10 --no-extra --no-cpu-baseline > $OUT/bench_100steps.json.log 2>> $OUT/bench.err; echo "   exit $?"
