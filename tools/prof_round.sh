@@ -22,6 +22,6 @@ cp profiles/r03_k13d_c5_traffic.json $OUT/ 2>/dev/null
 cd /tmp
 echo "[1] bench.py"; timeout -k 10 500 python3 $ROOT/bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "   exit $?"
 echo "[1b] bench.py --steps 100 --warmup 10 (SURVEY 8d step counts)"; timeout -k 10 300 python3 $ROOT/bench.py --steps 100 --warmup 10 --no-extra --no-cpu-baseline > $OUT/bench_100steps.json.log 2>> $OUT/bench.err; echo "   exit $?"
-echo "[2] kernel stats (2-D)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2d -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/stats2d.log 2>&1; tail -1 $OUT/stats2d.log > $OUT/bench_under_rocprof.json.log; echo "   exit $?"
+echo "[2] kernel stats (2-D)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2d -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/stats2d.log 2>&1; grep '^{"metric' $OUT/stats2d.log | tail -1 > $OUT/bench_under_rocprof.json.log; echo "   exit $?"
 echo "[3] kernel stats (3-D slab)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3d -- python3 $ROOT/tools/bench3d.py > $OUT/stats3d.log 2>&1; echo "   exit $?"
 find $OUT -name "*kernel_stats.csv" | head
