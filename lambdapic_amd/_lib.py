@@ -180,6 +180,10 @@ VARIANTS_PATH = HERE / "csrc" / "build" / "liblambdapic_amd_variants.so"
 
 
 def _bind(path):
+    # torch first: it brings its own HIP runtime (libamdhip64), and the library must resolve its HIP symbols against THAT
+    # one -- loaded before torch, the library binds the system runtime and the process ends up with two, of which ours
+    # sees no device ("no ROCm-capable device is detected" from the first hipMemsetAsync)
+    import torch  # noqa: F401
     L = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         try:

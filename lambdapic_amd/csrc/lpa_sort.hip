@@ -541,8 +541,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     } else {
         tiles_x = (g->nx + T3X - 1) / T3X; tiles_y = (g->ny + T3Y - 1) / T3Y; tiles_z = (g->nz + T3Z - 1) / T3Z;
     }
-    if (hipMemsetAsync(w.cell_cnt, 0, sizeof(int32_t) * (size_t)w.ntiles * TCELLS, st) != hipSuccess) {
-        lpa_set_error("%s: memset failed", name);
+    if (hipError_t me = hipMemsetAsync(w.cell_cnt, 0, sizeof(int32_t) * (size_t)w.ntiles * TCELLS, st); me != hipSuccess) {
+        lpa_set_error("%s: memset of the cell counters failed: %s", name, hipGetErrorString(me));
         return LPA_ERR_HIP;
     }
     PartV sv = make_partv(src), dv = make_partv(dst);
