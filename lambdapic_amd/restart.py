@@ -37,60 +37,54 @@ class RestartDump:
     device_native = True            # reads the device state directly: no mirror refresh around it
 
     def __init__(self, out_dir, interval=1000, keep=None, dump_signals=False):
-        self.stage = self.DEFAULT_STAGE
+        self.stage, self.interval, self.keep = self.DEFAULT_STAGE, interval, keep
         self.out_dir = Path(out_dir)
-        self.interval = interval
-        self.keep = keep
         self.out_dir.mkdir(parents=True, exist_ok=True)
-        if dump_signals is False:
-            self.dump_signals = []
-        elif dump_signals is True:
-            self.dump_signals = [signal.SIGINT, signal.SIGTERM]
-        else:
-            self.dump_signals = list(dump_signals)
-        for sig in self.dump_signals:
-            signal.signal(sig, self._dump_handler)
+        # True = the two signals a batch scheduler sends before it kills a job; a sequence = exactly those
+        if isinstance(dump_signals, bool):
+            dump_signals = (signal.SIGINT, signal.SIGTERM) if dump_signals else ()
+        self.dump_signals = list(dump_signals)
         self._dump_requested = False
+        for signum in self.dump_signals:
+            signal.signal(signum, self._dump_handler)
 
     def _dump_handler(self, sig, frame):
-        self._dump_requested = True
+        self._dump_requested = True        # honoured by run() at the end of the current step
 
-    # ---- paths (`restart.py:80-85`) --------------------------------------------------------------------------
+    # ---- where the shards live (`restart.py:80-85`) ---------------------------------------------------------------
     def _ckpt_dir(self, itime: int) -> Path:
-        return self.out_dir / f"ckpt_{itime:06d}"
+        return self.out_dir / ("ckpt_%06d" % itime)
 
     def _rank_shard_path(self, itime: int, rank: int) -> Path:
-        return self._ckpt_dir(itime) / f"rank_{rank:06d}.pkl"
+        return self._ckpt_dir(itime) / ("rank_%06d.pkl" % rank)
 
-    # ---- callback entry (`restart.py:88-107`) ----------------------------------------------------------------
+    # ---- callback entry (`restart.py:88-107`): directory by rank 0, one shard per rank, trim, three barriers -------
     def _call(self, sim):
-        comm, rank = sim.mpi.comm, sim.mpi.rank
-        ckpt_dir = self._ckpt_dir(sim.itime)
-        if rank == 0:
-            ckpt_dir.mkdir(parents=True, exist_ok=True)
-        comm.Barrier()
-        with open(self._rank_shard_path(sim.itime, rank), "wb") as f:
-            dill.dump(sim, f, byref=True, recurse=True)
-        comm.Barrier()
-        if rank == 0 and self.keep is not None and self.keep > 0:
-            self._gc_old_checkpoints(self.keep)
-        comm.Barrier()
+        mpi = sim.mpi
+        if mpi.rank == 0:
+            self._ckpt_dir(sim.itime).mkdir(parents=True, exist_ok=True)
+        mpi.comm.Barrier()
+        shard = self._rank_shard_path(sim.itime, mpi.rank)
+        tmp = shard.with_suffix(".tmp")
+        with tmp.open("wb") as fh:          # written under another name first: a killed dump leaves no half shard
+            dill.dump(sim, fh, byref=True, recurse=True)
+        tmp.replace(shard)
+        mpi.comm.Barrier()
+        if mpi.rank == 0 and self.keep:
+            self._gc_old_checkpoints(int(self.keep))
+        mpi.comm.Barrier()
 
     __call__ = _call
 
     def _gc_old_checkpoints(self, keep: int) -> None:
-        subdirs = sorted((d for d in self.out_dir.iterdir() if d.is_dir() and d.name.startswith("ckpt_")),
-                         key=lambda p: p.name)
-        for d in subdirs[: max(len(subdirs) - keep, 0)]:
+        """all but the ``keep`` newest ``ckpt_*`` directories go (`restart.py:109-127`; names sort by itime)"""
+        import shutil
+        have = sorted(d for d in self.out_dir.glob("ckpt_*") if d.is_dir())
+        for stale in have[:-keep] if keep > 0 else []:
             try:
-                for path in sorted(d.rglob("*"), key=lambda p: len(p.parts), reverse=True):
-                    if path.is_file():
-                        path.unlink(missing_ok=True)
-                    elif path.is_dir():
-                        path.rmdir()
-                d.rmdir()
-            except OSError as e:                       # the reference logs and carries on (`restart.py:126-127`)
-                print(f"RestartDump: failed to remove old checkpoint {d}: {e}")
+                shutil.rmtree(stale)
+            except OSError as err:             # the reference logs and carries on
+                print(f"RestartDump: could not remove {stale}: {err}")
 
     # ---- loader (`restart.py:130-160`) ------------------------------------------------------------------------
     @staticmethod
@@ -99,15 +93,14 @@ class RestartDump:
         rank 0 of 1 without one); the loaded simulation's communicator is re-bound to its groups.  ``device``:
         device to restore onto (default: the one the checkpoint was written from)."""
         import torch.distributed as dist
-        ckpt_dir = Path(ckpt_dir)
         if comm is not None:
             rank = comm.rank
         else:
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         _device.RESTORE_DEVICE = device
         try:
-            with open(ckpt_dir / f"rank_{rank:06d}.pkl", "rb") as f:
-                sim = dill.load(f)
+            with (Path(ckpt_dir) / ("rank_%06d.pkl" % rank)).open("rb") as fh:
+                sim = dill.load(fh)
         finally:
             _device.RESTORE_DEVICE = None
         if comm is not None:
@@ -115,7 +108,7 @@ class RestartDump:
         if device is not None:
             sim.device = device
         sim.update_lists()
-        sim.itime += 1                     # the dump ran before the loop's increment
-        sim.time = sim.itime * sim.dt      # keep time in sync with itime
+        sim.itime += 1                     # the dump ran before the loop's increment ...
+        sim.time = sim.itime * sim.dt      # ... and time follows itime (`restart.py:153-156`)
         sim.mpi.comm.Barrier()
         return sim
