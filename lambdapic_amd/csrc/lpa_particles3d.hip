@@ -790,7 +790,15 @@ __global__ void __launch_bounds__(K13_THREADS) k_push_deposit_tiled_3d(
         if (wb >= *n_blocks) return;  // block-uniform
         tile = blk_tile[wb]; blk_b = blk_begin[wb]; blk_e = blk_end[wb];
     } else {
+#ifdef LPA_XCD_TILES_3D   // experiment: every XCD (workgroups are dealt round-robin over 8) walks a contiguous run of tiles.
+                          // C5 leg (profiles/r03_ab_xcd3.txt): HBM fetch -3 % only, K1 1.85 -> 3.5 ms (the vacuum tiles of
+                          // the slab all fall to two XCDs): off
+        const int chunk = (ntiles + 7) >> 3;
+        tile = (wb & 7) * chunk + (wb >> 3);
+        if (wb >= 8 * chunk || tile >= ntiles) return;
+#else
         if (wb >= ntiles) return;
+#endif
         bool any = false;                  // an empty tile (vacuum) costs nothing: no staging, no flush
         for (int s = 0; s < m.ns; s++) any = any || m.s[s].tile_off[tile] < m.s[s].tile_off[tile + 1];
         if (!any) return;                  // block-uniform
@@ -936,7 +944,7 @@ extern "C" int lpa_push_deposit_tiled_3d(const lpa_grid *g, const lpa_particles 
 static int launch_tiled_3d(const lpa_grid *g, const MultiArgs &m, const lpa_tiling *t0, bool blocks, bool defer,
                            bool rho, int part, int edge_cols, void *stream) {
     const int ntiles = t0->tiles_x * t0->tiles_y * t0->tiles_z;
-    const unsigned grid = blocks ? (unsigned)t0->max_blocks : (unsigned)ntiles;
+    const unsigned grid = blocks ? (unsigned)t0->max_blocks : (unsigned)(8 * ((ntiles + 7) / 8));
 #define LPA_LAUNCH_TILED3(D, R)                                                                                     \
     hipLaunchKernelGGL((k_push_deposit_tiled_3d<D, R>), dim3(grid), dim3(K13_THREADS), 0, (hipStream_t)stream,       \
                        make_gridv(g, 3), m, blocks ? t0->blk_tile : nullptr, blocks ? t0->blk_begin : nullptr,       \
