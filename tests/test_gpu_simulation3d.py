@@ -171,3 +171,40 @@ def test_moving_window_3d_matches_long_static_box():
         if scale > 0:
             assert np.abs(fw - fs).max() <= 1e-8 * scale, a
     assert w.engine.diagnostics()["nalive"][0] > 500
+
+
+def test_one_call_per_step_and_one_launch_for_all_species_equal_the_staged_loop():
+    """3-D: ``lpa_step`` (two calls per step around the laser) with both species in ONE K1-3D launch
+    (``lpa_push_deposit_tiled_multi_3d``) against (a) ``lpa_step`` with one launch per species and (b) the stage loop walked
+    facade by facade: same fields to summation order, same particles per id"""
+    def run(fused_step, fuse_species):
+        sim = _sim(npatch_x=2, npatch_y=1, npatch_z=2)
+        sim.initialize()
+        sim.engine.fused_step, sim.engine.fuse_species = fused_step, fuse_species
+        calls = {"n": 0}
+        inner = sim.engine.step_stages
+
+        def counted(dt, first, last):
+            calls["n"] += 1
+            return inner(dt, first, last)
+
+        sim.engine.step_stages = counted
+        sim.run(40, callbacks=[GaussianLaser3D(a0=3.0, l0=LAM, w0=1.0e-6, ctau=0.8e-6, x0=1.6e-6)])
+        return sim, calls["n"]
+
+    a, na = run(True, True)
+    b, nb = run(True, False)
+    c, nc = run(False, False)
+    assert na == nb == 80 and nc == 0
+    for other in (b, c):
+        for name in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
+            va, vo = a.engine.view(name), other.engine.view(name)
+            assert (va - vo).abs().max().item() <= 1e-9 * max(vo.abs().max().item(), 1e-300), name
+        assert a.engine.rho_steps == other.engine.rho_steps
+        for i in range(2):
+            da, do = a.engine.download_species(i), other.engine.download_species(i)
+            oa, oo = np.argsort(da["_id"].view(np.uint64)), np.argsort(do["_id"].view(np.uint64))
+            assert np.array_equal(da["_id"].view(np.uint64)[oa], do["_id"].view(np.uint64)[oo])
+            for k in ("x", "y", "z", "ux", "uy", "uz"):
+                assert np.abs(da[k][oa] - do[k][oo]).max() <= 1e-9 * max(np.abs(do[k]).max(), 1e-300), k
+    assert a.engine.view("ey").abs().max().item() > 0 and a.engine.rho_steps["continuity"] > 20
