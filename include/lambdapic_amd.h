@@ -125,6 +125,11 @@ typedef struct {
  * the live count is NOT the slot count (lpa_sort_live_count returns the slots). */
 #define LPA_ORDER_PADDED 2
 #define LPA_PAD_MIN_CELLS 192
+/* LPA_ORDER_COLUMN: stripes over ONE column of a tile at a time -- the 16 z-cells of an (x, y) column of a 3-D tile, the
+ * 32 y-cells of a row of a 2-D tile: the r-th particle of each of its cells for r = 0, 1, ..., then the next column.  A
+ * 16-lane group then stays inside one column even where the stripes are partial (few particles per cell), so its LDS
+ * gather reads fall on consecutive banks or on the same address. */
+#define LPA_ORDER_COLUMN 3
 
 const char *lpa_last_error(void);
 int lpa_version(void);

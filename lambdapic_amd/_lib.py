@@ -18,6 +18,7 @@ LPA_TILE_Y = 32
 LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1
 LPA_ORDER_PADDED = 2
+LPA_ORDER_COLUMN = 3
 LPA_TILE_MARGIN = 2
 LPA_TILE3_X, LPA_TILE3_Y, LPA_TILE3_Z, LPA_TILE3_MARGIN = 4, 4, 16, 1
 LPA_MIG_NATTR = 9

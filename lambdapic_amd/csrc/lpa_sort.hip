@@ -345,29 +345,52 @@ __device__ __forceinline__ int stripe_slot(const unsigned long long *__restrict_
     return a0 + below;
 }
 
+// `striped`: 0 = CELL_MAJOR, 1 = STRIPED / PADDED (stripe tables), 2 + log2(L) = COLUMN with columns of L cells:
+// stripes over the L cells of ONE column (the run of cells along the fastest axis) at a time, rank after rank, the
+// columns one after the other.  slot = start of the column (cell-major scan) + what the column's ranks below r hold
+// + the cells before c that reach rank r -- from the column's L counters (one or two cache lines, shared by all its
+// particles).
+__device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
+                                          const int32_t *__restrict__ cell_base,
+                                          const int32_t *__restrict__ tile_off,
+                                          const int32_t *__restrict__ cell_off,
+                                          const unsigned long long *__restrict__ masks,
+                                          const int32_t *__restrict__ apre,
+                                          const int32_t *__restrict__ cell_cnt = nullptr) {
+    if (r & RANK_LOCAL) r = (r & ~RANK_LOCAL) + (uint32_t)cell_base[ck];
+    if (!striped) return (long)cell_off[ck] + r;
+    if (striped >= 2) {
+        const int L = 1 << (striped - 2);
+        const uint32_t c0 = ck & ~(uint32_t)(L - 1);
+        const int32_t *cnt = cell_cnt + c0;
+        long o = cell_off[c0];
+        const int cc = (int)(ck - c0);
+        for (int q = 0; q < L; q++) {
+            const int n = cnt[q];
+            o += min(n, (int)r) + (q < cc && n > (int)r ? 1 : 0);
+        }
+        return o;
+    }
+    long t = ck >> 8;
+    int c = ck & 255;
+    if (r < RMAX) return (long)tile_off[t] + stripe_slot(masks + (t * RMAX + r) * 4, apre + t * (RMAX + 1), r, c);
+    return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
+}
+
 __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_t *__restrict__ key,
                                                  const uint32_t *__restrict__ rank,
                                                  const int32_t *__restrict__ tile_off,
                                                  const int32_t *__restrict__ cell_off,
                                                  const unsigned long long *__restrict__ masks,
                                                  const int32_t *__restrict__ apre, int striped,
-                                                 const SortHdr *hdr) {
+                                                 const SortHdr *hdr, const int32_t *__restrict__ cell_cnt) {
     long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
     if (hdr->overflow) return;                         // the destination cannot hold the order: see SortHdr
     if (hdr->prev_valid && ip < hdr->prev_n) return;   // moved by k_scatter_tiled
     uint32_t ck = key[ip];
     if (ck == KEY_DEAD) return;
-    uint32_t r = rank[ip];
-    long o;
-    if (!striped) {
-        o = (long)cell_off[ck] + r;
-    } else {
-        long t = ck >> 8;
-        int c = ck & 255;
-        if (r < RMAX) o = (long)tile_off[t] + stripe_slot(masks + (t * RMAX + r) * 4, apre + t * (RMAX + 1), r, c);
-        else o = (long)tile_off[t] + cell_off[ck] + (r - RMAX);
-    }
+    const long o = dest_slot(ck, rank[ip], striped, nullptr, tile_off, cell_off, masks, apre, cell_cnt);
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
     d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
@@ -404,20 +427,6 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
     }
 }
 
-__device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
-                                          const int32_t *__restrict__ cell_base,
-                                          const int32_t *__restrict__ tile_off,
-                                          const int32_t *__restrict__ cell_off,
-                                          const unsigned long long *__restrict__ masks,
-                                          const int32_t *__restrict__ apre) {
-    if (r & RANK_LOCAL) r = (r & ~RANK_LOCAL) + (uint32_t)cell_base[ck];
-    if (!striped) return (long)cell_off[ck] + r;
-    long t = ck >> 8;
-    int c = ck & 255;
-    if (r < RMAX) return (long)tile_off[t] + stripe_slot(masks + (t * RMAX + r) * 4, apre + t * (RMAX + 1), r, c);
-    return (long)tile_off[t] + cell_off[ck] + (r - RMAX);
-}
-
 #ifndef LPA_ST_NBUF
 #define LPA_ST_NBUF 2
 #endif
@@ -436,7 +445,8 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     AttrList al, const SortHdr *hdr, const int32_t *__restrict__ tile_off_prev,
     const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ cell_base,
     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ cell_off,
-    const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped) {
+    const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped,
+    const int32_t *__restrict__ cell_cnt) {
     __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
     if (!hdr->prev_valid || hdr->overflow) return;
@@ -451,7 +461,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
             dest[j] = -1;
             if (ip < se) {
                 uint32_t ck = key[ip];
-                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre);
+                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre, cell_cnt);
             }
         }
         // (a tile with more than ST_BITS particles is covered in several passes)
@@ -519,7 +529,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                 "%s: bad grid", name);
     LPA_REQUIRE(lpa_part_ok(src, dim) && lpa_part_ok(dst, dim) && workspace && out,
                 "%s: bad particle stores / workspace", name);
-    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED,
+    LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED ||
+                    order == LPA_ORDER_COLUMN,
                 "%s: bad order", name);
     LPA_REQUIRE(src->n < (1ll << 31) - 1, "%s: more than 2^31 particles in one store", name);
     LPA_REQUIRE(dst->n >= src->n, "%s: dst capacity (dst->n) smaller than src->n", name);
@@ -598,14 +609,16 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         add((const double *)sv.id, (double *)dv.id);       // 8-byte payload, moved as is
         if (sv.eb[0] && dv.eb[0])
             for (int c = 0; c < 6; c++) add(sv.eb[c], dv.eb[c]);
-        const int striped = (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
+        // columns: the 16 z-cells of an (x, y) column of a 3-D tile, the 32 y-cells of a row of a 2-D tile
+        const int striped = order == LPA_ORDER_COLUMN ? 2 + (dim == 3 ? 4 : 5)
+                                                      : (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
         hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
-                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped);
+                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
         unsigned nb = (unsigned)((src->n + 255) / 256);
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
-                           w.cell_off, w.masks, w.apre, striped, w.hdr);
+                           w.cell_off, w.masks, w.apre, striped, w.hdr, w.cell_cnt);
         LPA_CHECK_LAUNCH("k_scatter");
     }
     out->tiles_x = tiles_x;

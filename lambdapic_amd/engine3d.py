@@ -116,6 +116,7 @@ class DevicePML3D:
 
 class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     dim = 3
+    DEFAULT_ORDER = _lib.LPA_ORDER_STRIPED   # the in-tile order new engines sort to (LPA_ORDER_*)
 
     def __init__(self, nx, ny, nz, dx, dy, dz, n_guard=3, device="cuda:0", tiled=None, sort_interval=10,
                  block_particles=4096, comm=None, migrate_capacity=32768, boundary_conditions=None,
@@ -192,7 +193,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self._axes = {}
         # LPA_ORDER_STRIPED, or LPA_ORDER_PADDED: the leading ranks of every tile as full stripes with holes (the store
         # needs a few per cent more slots) -- every 16-lane group is then one z column of 16 different cells
-        self.order = _lib.LPA_ORDER_STRIPED
+        self.order = self.DEFAULT_ORDER
         # bench instrumentation: when a list, (start, end) HIP events are recorded around every launch of the
         # tiled push+deposit kernel on the stream it runs on
         self.kernel_events = None

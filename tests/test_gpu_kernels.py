@@ -283,12 +283,27 @@ def test_wave_reduce_scatter_selftest():
     np.testing.assert_allclose(d_out.cpu().numpy(), a.sum(axis=1), rtol=1e-13, atol=1e-13)
 
 
-@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR, 2])
+def _expected_tile_sequence(cnt, order):
+    """the cell sequence of one tile's particles for a striped order, from its 256 cell counts"""
+    if order == 3:     # LPA_ORDER_COLUMN: rank by rank inside each 32-cell row of the 2-D tile, row after row
+        exp = []
+        for c0 in range(0, 256, 32):
+            col = cnt[c0:c0 + 32]
+            exp += [c0 + np.nonzero(col > r)[0] for r in range(col.max())]
+        return np.concatenate(exp) if exp else np.zeros(0, int)
+    # for r < 128 the cells with count > r ascending, then the deep tails
+    exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), 128))]
+    exp += [np.repeat(c, cnt[c] - 128) for c in np.nonzero(cnt > 128)[0]]
+    return np.concatenate(exp)
+
+
+@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR, 2, 3])
 def test_cell_sort_properties(order):
     """reference tests/test_sort.py:38-117,201-251 restated for the device sort: per-cell counts
     equal a numpy histogram, tiles are contiguous and in order, inside a tile the particles are cell
-    by cell (CELL_MAJOR) or rank by rank with cells ascending inside a rank (STRIPED), the multiset
-    of live particles is preserved, dead / NaN particles are dropped, re-sorting keeps the keys."""
+    by cell (CELL_MAJOR), rank by rank with cells ascending inside a rank (STRIPED) or the same inside each
+    column of the tile (COLUMN), the multiset of live particles is preserved, dead / NaN particles are dropped,
+    re-sorting keeps the keys."""
     import torch
     from lambdapic_amd.engine import PicEngine2D
     rng = np.random.default_rng(9)
@@ -330,10 +345,7 @@ def test_cell_sort_properties(order):
         for t in np.unique(tile):
             kt = k_out[tile == t] & 255
             cnt = np.bincount(kt, minlength=256)
-            # expected sequence: for r < 128 the cells with count > r ascending, then the deep tails
-            exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), 128))]
-            exp += [np.repeat(c, cnt[c] - 128) for c in np.nonzero(cnt > 128)[0]]
-            assert np.array_equal(kt, np.concatenate(exp)), t
+            assert np.array_equal(kt, _expected_tile_sequence(cnt, order)), t
     order_in = np.argsort(p.id[live])
     order_out = np.argsort(out["_id"].view(np.uint64))
     assert np.array_equal(p.id[live][order_in], out["_id"].view(np.uint64)[order_out])
@@ -366,9 +378,7 @@ def test_cell_sort_properties(order):
         for t in np.unique(t3):
             kt = k3[t3 == t] & 255
             cnt = np.bincount(kt, minlength=256)
-            exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), 128))]
-            exp += [np.repeat(c, cnt[c] - 128) for c in np.nonzero(cnt > 128)[0]]
-            assert np.array_equal(kt, np.concatenate(exp)), t
+            assert np.array_equal(kt, _expected_tile_sequence(cnt, order)), t
     ib, ia = np.argsort(before["_id"].view(np.uint64)), np.argsort(out3["_id"].view(np.uint64))
     assert np.array_equal(before["_id"].view(np.uint64)[ib], out3["_id"].view(np.uint64)[ia])
     for a in ("x", "y", "ux", "w"):

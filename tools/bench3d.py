@@ -16,7 +16,7 @@ ap.add_argument("--nz", type=int, default=256); ap.add_argument("--ppc", type=in
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--global", dest="glob", action="store_true"); ap.add_argument("--sort-interval", type=int, default=10)
 ap.add_argument("--block-particles", type=int, default=4096)
-ap.add_argument("--order", default="striped", choices=["striped", "padded"])
+ap.add_argument("--order", default="striped", choices=["striped", "padded", "column"])
 ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (gamma beta)")
 ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
                 help="rho between two sorts: from the continuity equation (default) or deposited in every step")
@@ -34,6 +34,8 @@ eng.fuse_species = not a.no_fuse
 n = a.nx * a.ny * a.nz * a.ppc
 if a.order == "padded":
     eng.order = _lib.LPA_ORDER_PADDED
+if a.order == "column":
+    eng.order = _lib.LPA_ORDER_COLUMN
 cap = int(1.6 * n) + 65536 if a.order == "padded" else n
 dev = eng.device
 g = torch.Generator(device=dev).manual_seed(1)
@@ -51,7 +53,7 @@ data[7, :n] = constants.EPSILON_0 * constants.M_E * omega ** 2 / constants.E_CHA
 if a.species == 1:
     eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
 else:          # the same particles dealt to several species (cell by cell), each in its own store
-    assert a.order == "striped"
+    assert a.order != "padded"
     for k in range(a.species):
         part = data[:, k:n:a.species].contiguous()
         eng.add_species_device(-constants.E_CHARGE, constants.M_E, part, part.shape[1])
