@@ -201,7 +201,9 @@ class Patches:
         (`core/patch/patch.py:446-507`).  Single-rank: neighbor_ipatch == neighbor_index."""
         where = {(p.ipatch_x, p.ipatch_y): k for k, p in enumerate(self.patches)}
         for p in self.patches:
-            p.neighbor_index.fill(-1)
+            p.neighbor_index.fill(-1)        # a rebuild (patches relabelled by a moving window) starts clean
+            p.neighbor_ipatch.fill(-1)
+            p.neighbor_rank.fill(-1)
             for b, (di, dj) in OFFSET_2D.items():
                 ni, nj = p.ipatch_x + di, p.ipatch_y + dj
                 if ni < 0:

@@ -1,0 +1,177 @@
+"""f3 (moving window), the one known difference against the reference bounded by a test.
+
+The reference's ``MovingWindow`` (callback/utils.py:471-648) cannot run here (mpi4py, numba, h5py at import time): f3
+stays "parity unpinned".  What CAN be compared is the device slab against a host restatement of the reference's patch
+recycling, run on the oracle's patch kernels (oracle/driver.py, themselves pinned to the reference's traces g1-g7):
+
+    callback/utils.py:594-620  _shift_right: the patches with ipatch_x == 0 move to ipatch_x = npatch_x - 1 (x0, xaxis
+                               += Lx), all others ipatch_x -= 1
+    callback/utils.py:653-690  _update_patch_info_2d: neighbour tables rebuilt from (ipatch_x, ipatch_y)
+    callback/utils.py:748-800  _fill_particles_2d: the recycled patch's particle arrays are re-initialised and loaded from
+                               the species' density
+    callback/utils.py:576-585  ALL field arrays of the recycled patch are zeroed -- guards included
+
+The last line is where the slab differs by construction: a recycled patch starts its first E half step with ZERO low
+guards (they are refreshed by the guard sync that follows that half step), the slab has no seam and its first new column
+differentiates against its true left neighbour.  The difference is dt/2 c^2 B_edge / dx in the first new column, B_edge
+= the field in the last column of the old window:
+
+* test A: nothing has reached the window's leading edge (a pulse and a cold plasma slab well inside it): B_edge = 0 and
+  the slab equals the patch recycling to round-off -- fields, currents, charge density and every particle by id;
+* test B: a warm plasma fills the window, so B_edge is its thermal noise: the slab and the patch recycling differ, the
+  test bounds the field difference by that noise (measured: max |dB| = 0.3 x its rms = 2e-4 of the pulse amplitude)
+  and the particle differences that follow from it (0.01 cells, 8e-4 in u after 150 steps and 7 shifts).
+
+The injected columns come from the product's own seeded loader on both sides (the reference draws them from a per-rank
+numpy generator: identical physics, different noise)."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C = 299792458.0
+BC = {"xmin": "pml", "xmax": "pml", "ymin": "periodic", "ymax": "periodic"}
+FIELDS = ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho")
+
+
+def _recycle_left_column(P, sim, species, id_next):
+    """callback/utils.py:594-620,653-690,748-800,576-585 on the host mirrors (see the module docstring)"""
+    import torch  # noqa: F401
+    from lambdapic_amd.simulation import load_block_device
+    npx, Lx = sim.npatch_x, sim.npatch_x * sim.nx_per_patch * sim.dx
+    new = []
+    for p in P:
+        if p.ipatch_x == 0:
+            p.ipatch_x = npx - 1
+            p.x0 += Lx
+            p.xaxis = p.xaxis + Lx
+            p.fields.x0 = p.x0
+            p.fields.xaxis = p.fields.xaxis + Lx
+            new.append(p)
+        else:
+            p.ipatch_x -= 1
+    P.init_rect_neighbor_index_2d(npx, sim.npatch_y, boundary_conditions=BC)
+    P.xmin_global += sim.nx_per_patch * sim.dx
+    P.xmax_global += sim.nx_per_patch * sim.dx
+    for p in new:
+        for s in species:
+            q = p.particles[s.ispec]
+            b = load_block_device(s, (p.x0, p.y0), (p.nx, p.ny), (sim.dx, sim.dy), sim._seed(s, p.x0, p.y0),
+                                  sim.device, id_prefix=id_next[s.ispec])
+            q.initialize(0 if b is None else b["x"].numel())
+            if b is not None:
+                id_next[s.ispec] += b["x"].numel()
+                for a in ("x", "y", "ux", "uy", "uz", "inv_gamma", "w"):
+                    getattr(q, a)[:] = b[a].cpu().numpy()
+                q.id[:] = b["id"].cpu().numpy().astype(q.id.dtype)
+        for a in FIELDS:
+            getattr(p.fields, a).fill(0.0)
+
+
+def _pair(thermal, nsteps=150):
+    import torch
+    from lambdapic_amd import constants
+    from lambdapic_amd.simulation import MovingWindow, Simulation, Species
+    from oracle import driver
+    lam = 0.8e-6
+    dx = dy = lam / 16
+    nx, ny, npx = 96, 32, 6
+    sim = Simulation(nx, ny, dx, dy, npatch_x=npx, npatch_y=1, boundary_conditions=BC, cpml_thickness=4,
+                     random_seed=5, sort_interval=4)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
+    if thermal:
+        dens, sigma = (lambda x, y: np.full(np.shape(x), 0.05 * nc)), 0.02
+    else:   # a cold slab the pulse runs through (its later columns are injected), vacuum ahead of it
+        dens, sigma = (lambda x, y: np.where((x > 40 * dx) & (x < 150 * dx), 0.05 * nc, 0.0)), 0.0
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=sigma))
+    sim.initialize()
+    # a compact plane-wave packet travelling in +x (Ez, By = -Ez / c), uniform in y
+    eng, ng = sim.engine, sim.n_guard
+    xs = torch.arange(nx, dtype=torch.float64, device=eng.device)
+    env = torch.where((xs - 24).abs() < 16, torch.cos(np.pi * (xs - 24) / 32) ** 2, torch.zeros_like(xs))
+    E0 = 0.3 * constants.M_E * C * (2 * np.pi * C / lam) / constants.E_CHARGE
+    ez = (E0 * env * torch.sin(2 * np.pi * xs / 16))[:, None].expand(nx, ny)
+    eng.grid.view("ez")[ng:ng + nx, ng:ng + ny] = ez
+    eng.grid.view("by")[ng:ng + nx, ng:ng + ny] = -ez / C
+    eng.sync_guard_fields(("ex", "ey", "ez", "bx", "by", "bz"))
+    win = MovingWindow(velocity=C, start_time=0.0)
+    sim.download()
+    P = copy.deepcopy(sim.patches._m)             # the oracle's patches start as the device state's mirrors
+    id_next = dict(sim._id_next)
+    species = list(sim.species)
+    ks = driver.oracle_kernels()
+    qm = [(s.q, s.m) for s in species]
+    patch_Lx = sim.nx_per_patch * dx
+    acc = patch_Lx                                # callback/utils.py:531-538: the counters start at one patch width
+    shifts, edge = 0, []
+    for it in range(nsteps):
+        # the device slab, through the product's callback and stage loop
+        sim.run(1, callbacks=[win])
+        # the patch recycling, stage "start" of the same step (callback/utils.py:540-585), then the stage loop
+        acc += C * sim.dt
+        if acc >= patch_Lx:
+            acc -= patch_Lx
+            last = [p for p in P if p.ipatch_x == npx - 1][0]
+            # B at the seam at the moment of the shift: what the recycled patch's first E half step does not see
+            # (wrapped guard layout, core/fields.py:24-27: the interior is [0, n))
+            edge.append(np.stack([getattr(last.fields, a)[last.nx - 1, :last.ny] for a in ("by", "bz")]))
+            _recycle_left_column(P, sim, species, id_next)
+            shifts += 1
+        driver.step(P, ks, sim.dt, qm, do_sort=(it % 4 == 0))
+    assert shifts == sim.window_shifts and shifts >= 5
+    sim.download()
+    by_x = sorted(P, key=lambda p: p.ipatch_x)
+    return sim, by_x, np.stack(edge), E0
+
+
+def _stack(patches, a):
+    return np.concatenate([getattr(p.fields, a)[:p.nx, :p.ny] for p in patches], axis=0)
+
+
+def test_window_recycling_matches_patch_restatement_when_the_edge_is_quiet():
+    sim, ref, edge, E0 = _pair(thermal=False)
+    assert np.abs(edge).max() <= 1e-12 * E0 / C                 # nothing has reached the leading edge
+    dev = sorted(sim.patches._m, key=lambda p: p.x0)
+    assert [p.x0 for p in dev] == pytest.approx([p.x0 for p in ref], rel=1e-13)
+    margin = 4        # columns next to the open trailing edge (no neighbour, stale guard) are not compared
+    for a in FIELDS:
+        d, r = _stack(dev, a)[margin:], _stack(ref, a)[margin:]
+        scale = np.abs(r).max()
+        if a in ("ez", "by", "jz", "rho"):
+            assert scale > 0, a
+        assert np.abs(d - r).max() <= 1e-9 * max(scale, 1e-300), a
+    cat = lambda ps, a: np.concatenate([getattr(p.particles[0], a)[~p.particles[0].is_dead] for p in ps])
+    idd, idr = cat(dev, "id"), cat(ref, "id")
+    od, orr = np.argsort(idd), np.argsort(idr)
+    assert idd.size > 1000 and np.array_equal(idd[od], idr[orr])
+    for a, s in (("x", sim.dx), ("y", sim.dy), ("ux", 1.0), ("uy", 1.0), ("uz", 1.0)):
+        np.testing.assert_allclose(cat(dev, a)[od], cat(ref, a)[orr], rtol=0, atol=1e-9 * s, err_msg=a)
+
+
+def test_window_seam_difference_is_bounded_by_the_edge_field():
+    sim, ref, edge, E0 = _pair(thermal=True)
+    noise = np.sqrt(np.mean(edge[1:] ** 2))       # rms B in the last column when the window shifts: thermal noise
+    assert 0 < noise < 1e-2 * E0 / C
+    dev = sorted(sim.patches._m, key=lambda p: p.x0)
+    margin = 4
+    worst = {}
+    for a, unit in (("ez", C), ("ey", C), ("ex", C), ("bx", 1.0), ("by", 1.0), ("bz", 1.0)):
+        d, r = _stack(dev, a)[margin:], _stack(ref, a)[margin:]
+        worst[a] = np.abs(d - r).max() / unit      # in units of B
+    w = max(worst.values())
+    assert w > 0                                   # the two DO differ here: that is the documented deviation
+    assert w <= 1.0 * noise, (worst, noise)        # measured: 0.3 x the rms edge field
+    assert w <= 1e-3 * E0 / C, (worst, E0 / C)     # and far below the pulse
+    # the particles: the same set but for the few that a field difference of that size moves across the open trailing
+    # edge one step earlier or later; everybody else sits where the patch recycling puts them
+    cat = lambda ps, a: np.concatenate([getattr(p.particles[0], a)[~p.particles[0].is_dead] for p in ps])
+    idd, idr = cat(dev, "id"), cat(ref, "id")
+    common, kd, kr = np.intersect1d(idd, idr, return_indices=True)
+    assert common.size >= 0.999 * max(idd.size, idr.size) and common.size > 10000
+    # measured after 150 steps / 7 shifts: 0.0095 cells, 8.4e-4 in u (thermal spread 0.02, pulse a0 = 0.3)
+    for a, unit, bound in (("x", sim.dx, 0.03), ("y", sim.dy, 0.03), ("ux", 1.0, 3e-3), ("uy", 1.0, 3e-3),
+                           ("uz", 1.0, 3e-3)):
+        worst_p = np.abs(cat(dev, a)[kd] - cat(ref, a)[kr]).max() / unit
+        assert worst_p <= bound, (a, worst_p)
