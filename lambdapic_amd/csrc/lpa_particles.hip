@@ -16,6 +16,9 @@
 //
 // Restates unified_boris_pusher_cpu_2d (core/pusher/unified/unified_pusher_2d.c:157-365).
 #include "lpa_common.hpp"
+#ifndef LPA_NT_PARTICLES_2D
+#define LPA_NT_PARTICLES_2D 0
+#endif
 
 struct PushK {
     double dt, q, m;
@@ -405,13 +408,21 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     // below 2^29 particles): one VALU instruction per access instead of a 64-bit address each
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
     auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
+    // the particle attributes stream through once per step: non-temporal (see lpa_particles3d.hip)
+    // LPA_NT_PARTICLES_2D: bit 0 = loads, bit 1 = stores
+    auto ldp = [](const double *base, uint32_t off) {
+        const double *q = (const double *)((const char *)base + off);
+        return (LPA_NT_PARTICLES_2D & 1) ? __builtin_nontemporal_load(q) : *q; };
+    auto stp = [](double *base, uint32_t off, double v) {
+        double *q = (double *)((char *)base + off);
+        if (LPA_NT_PARTICLES_2D & 2) __builtin_nontemporal_store(v, q); else *q = v; };
     double nx_ = 0.0, ny_ = 0.0, nux = 0.0, nuy = 0.0, nuz = 0.0, nig = 1.0, nw = 0.0;
     {
         const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
         if (ip0 < end) {
             const uint32_t o = (uint32_t)ip0 * 8u;
-            nx_ = ld(p.x, o); ny_ = ld(p.y, o); nux = ld(p.ux, o); nuy = ld(p.uy, o); nuz = ld(p.uz, o);
-            nig = ld(p.ig, o); nw = ld(p.w, o);
+            nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
+            nig = ldp(p.ig, o); nw = ldp(p.w, o);
         }
     }
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
@@ -426,8 +437,8 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {
                 const uint32_t o = (uint32_t)ipn * 8u;
-                nx_ = ld(p.x, o); ny_ = ld(p.y, o); nux = ld(p.ux, o); nuy = ld(p.uy, o); nuz = ld(p.uz, o);
-                nig = ld(p.ig, o); nw = ld(p.w, o);
+                nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
+                nig = ldp(p.ig, o); nw = ldp(p.w, o);
             }
         }
         valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
@@ -555,8 +566,8 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                    k.dep.c_rho * w);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)ip * 8u;
-            st(p.x, o, xs); st(p.y, o, ys);
-            st(p.ux, o, ux); st(p.uy, o, uy); st(p.uz, o, uz); st(p.ig, o, ig);
+            stp(p.x, o, xs); stp(p.y, o, ys);
+            stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); stp(p.ig, o, ig);
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
