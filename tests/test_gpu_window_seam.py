@@ -22,6 +22,8 @@ differentiates against its true left neighbour.  The difference is dt/2 c^2 B_ed
   test bounds the field difference by that noise (measured: max |dB| = 0.3 x its rms = 2e-4 of the pulse amplitude)
   and the particle differences that follow from it (0.01 cells, 8e-4 in u after 150 steps and 7 shifts).
 
+* test A in 3-D: `Simulation3D` against the same restatement on 3-D patches.
+
 The injected columns come from the product's own seeded loader on both sides (the reference draws them from a per-rank
 numpy generator: identical physics, different noise)."""
 import copy
@@ -175,3 +177,142 @@ def test_window_seam_difference_is_bounded_by_the_edge_field():
                            ("uz", 1.0, 3e-3)):
         worst_p = np.abs(cat(dev, a)[kd] - cat(ref, a)[kr]).max() / unit
         assert worst_p <= bound, (a, worst_p)
+
+
+# ---- 3-D: the slab of Simulation3D against the same restatement on 3-D patches (relabelling: callback/utils.py:705-730) ----
+BC3 = {"xmin": "pml", "xmax": "pml", "ymin": "periodic", "ymax": "periodic", "zmin": "periodic", "zmax": "periodic"}
+
+
+def _oracle_step_3d(P, dt, qm):
+    """the no-callback stage order (simulation/simulation.py:946-1118) on 3-D patches with the oracle's kernels"""
+    import oracle
+    from oracle import sync
+    fl, pl, n = [p.fields for p in P], list(P), P.npatches
+    f0 = fl[0]
+    dims = (f0.nx, f0.ny, f0.nz, f0.n_guard)
+    E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
+    for f in fl:
+        oracle.update_efield_3d(f, 0.5 * dt)
+    sync.sync_guard_fields_3d(fl, pl, E, n, *dims)
+    for f in fl:
+        oracle.update_bfield_3d(f, 0.5 * dt)
+    sync.sync_guard_fields_3d(fl, pl, B, n, *dims)
+    oracle.reset_current(fl, n)
+    for ispec, (q, m) in enumerate(qm):
+        oracle.unified_boris_pusher_cpu_3d([p.particles[ispec] for p in P], fl, n, dt, q, m)
+    sync.sync_currents_3d(fl, pl, n, *dims)
+    for ispec in range(len(qm)):
+        sync.sync_particles_3d(P, ispec, (f0.dx, f0.dy, f0.dz))
+    for f in fl:
+        oracle.update_bfield_3d(f, 0.5 * dt)
+    sync.sync_guard_fields_3d(fl, pl, B, n, *dims)
+    for f in fl:
+        oracle.update_efield_3d(f, 0.5 * dt)
+    sync.sync_guard_fields_3d(fl, pl, E, n, *dims)
+
+
+def _recycle_left_column_3d(P, sim, species, id_next):
+    from lambdapic_amd.engine3d import ATTRS3
+    from lambdapic_amd.patch import init_rect_neighbor_index_3d
+    from lambdapic_amd.simulation import load_block_device
+    npx = sim.npatch[0]
+    npp, d = sim.n_per_patch, (sim.dx, sim.dy, sim.dz)
+    Lx = npx * npp[0] * sim.dx
+    new = []
+    for p in P:
+        if p.ipatch_x == 0:
+            p.ipatch_x = npx - 1
+            p.x0 += Lx
+            p.fields.x0 = p.x0
+            p.fields.xaxis = p.fields.xaxis + Lx
+            new.append(p)
+        else:
+            p.ipatch_x -= 1
+    init_rect_neighbor_index_3d(P.patches, sim.npatch, BC3)
+    P.xmin_global += npp[0] * sim.dx
+    P.xmax_global += npp[0] * sim.dx
+    for p in new:
+        for s in species:
+            q = p.particles[s.ispec]
+            org = (p.x0, p.y0, p.z0)
+            b = load_block_device(s, org, npp, d, sim._seed(s, org), sim.device)
+            k = 0 if b is None else b["x"].numel()
+            q.initialize(k)
+            if k:
+                for a in ATTRS3:
+                    getattr(q, a)[:] = b[a].cpu().numpy()
+                q.id[:] = np.arange(id_next[s.ispec], id_next[s.ispec] + k, dtype=np.uint64)   # rank 0: no high bits
+                id_next[s.ispec] += k
+        for a in FIELDS:
+            getattr(p.fields, a).fill(0.0)
+
+
+def test_window_recycling_3d_matches_patch_restatement_when_the_edge_is_quiet():
+    import torch
+    from lambdapic_amd import constants
+    from lambdapic_amd.engine3d import ATTRS3
+    from lambdapic_amd.patch import make_patches_3d
+    from lambdapic_amd.simulation import MovingWindow, Species
+    from lambdapic_amd.simulation3d import Simulation3D
+    lam = 0.8e-6
+    dx, dy, dz = lam / 16, lam / 8, lam / 8
+    n, npx = (48, 16, 16), 6
+    sim = Simulation3D(*n, dx, dy, dz, npatch_x=npx, boundary_conditions=BC3, cpml_thickness=4, random_seed=7,
+                       sort_interval=4)
+    nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
+    dens = lambda x, y, z: np.where((x > 20 * dx) & (x < 90 * dx), 0.05 * nc, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=2, momentum_sigma=0.0))
+    sim.initialize()
+    eng, ng = sim.engine, sim.n_guard
+    xs = torch.arange(n[0], dtype=torch.float64, device=eng.device)
+    env = torch.where((xs - 12).abs() < 8, torch.cos(np.pi * (xs - 12) / 16) ** 2, torch.zeros_like(xs))
+    E0 = 0.3 * constants.M_E * C * (2 * np.pi * C / lam) / constants.E_CHARGE
+    ez = (E0 * env * torch.sin(2 * np.pi * xs / 16))[:, None, None].expand(*n)
+    inner = tuple(slice(ng, ng + m) for m in n)
+    eng.view("ez")[inner] = ez
+    eng.view("by")[inner] = -ez / C
+    eng.sync_guard_fields(3)
+    win = MovingWindow(velocity=C, start_time=0.0)
+    sim.download()
+    P = make_patches_3d(n, (dx, dy, dz), sim.npatch, ng, BC3, nspecies=1)
+    for pm, po in zip(sim.patches, P):                # the oracle's patches start as the device state's mirrors
+        assert (pm.ipatch_x, pm.x0) == (po.ipatch_x, po.x0)
+        for a in FIELDS:
+            getattr(po.fields, a)[...] = getattr(pm.fields, a)
+        qm_, qo = pm.particles[0], po.particles[0]
+        qo.initialize(qm_.npart)
+        for a in ATTRS3 + ("_id",):
+            getattr(qo, a)[:] = getattr(qm_, a)
+    id_next = dict(eng._id_next)
+    species, qm = list(sim.species), [(s.q, s.m) for s in sim.species]
+    patch_Lx = sim.n_per_patch[0] * dx
+    acc, shifts = patch_Lx, 0
+    for it in range(70):
+        sim.run(1, callbacks=[win])
+        acc += C * sim.dt
+        if acc >= patch_Lx:
+            acc -= patch_Lx
+            last = [p for p in P if p.ipatch_x == npx - 1][0]
+            assert max(np.abs(getattr(last.fields, a)[last.nx - 1]).max() for a in ("by", "bz")) <= 1e-12 * E0 / C
+            _recycle_left_column_3d(P, sim, species, id_next)
+            shifts += 1
+        _oracle_step_3d(P, sim.dt, qm)
+    assert shifts == sim.window_shifts and shifts >= 4
+    sim.download()
+    dev = sorted(sim.patches, key=lambda p: p.x0)
+    ref = sorted(P, key=lambda p: p.ipatch_x)
+    assert [p.x0 for p in dev] == pytest.approx([p.x0 for p in ref], rel=1e-13)
+    stack = lambda ps, a: np.concatenate([getattr(p.fields, a)[:p.nx, :p.ny, :p.nz] for p in ps], axis=0)
+    margin = 4
+    for a in FIELDS:
+        d, r = stack(dev, a)[margin:], stack(ref, a)[margin:]
+        scale = np.abs(r).max()
+        if a in ("ez", "by", "jz", "rho"):
+            assert scale > 0, a
+        assert np.abs(d - r).max() <= 1e-9 * max(scale, 1e-300), a
+    cat = lambda ps, a: np.concatenate([getattr(p.particles[0], a)[~p.particles[0].is_dead] for p in ps])
+    idd, idr = cat(dev, "id"), cat(ref, "id")
+    od, orr = np.argsort(idd), np.argsort(idr)
+    assert idd.size > 5000 and np.array_equal(idd[od], idr[orr])
+    for a, s in (("x", dx), ("y", dy), ("z", dz), ("ux", 1.0), ("uy", 1.0), ("uz", 1.0)):
+        np.testing.assert_allclose(cat(dev, a)[od], cat(ref, a)[orr], rtol=0, atol=1e-9 * s, err_msg=a)
