@@ -137,7 +137,9 @@ def test_mirror_round_trip_is_lossless():
     sim.download()
     sim.upload()
     after = sim.engine.diagnostics()
-    assert before["field_energy"] == after["field_energy"] and before["nalive"] == after["nalive"]
+    # (the energy diagnostic sums with atomics: the last bit depends on their order)
+    assert before["field_energy"] == pytest.approx(after["field_energy"], rel=1e-14)
+    assert before["nalive"] == after["nalive"]
     assert before["kinetic"][0] == pytest.approx(after["kinetic"][0], rel=1e-14)
     assert (sim.engine.grid.view("ex") - ex0).abs().max().item() == 0.0
     sim.run(3)                                    # and the run continues from the uploaded state
