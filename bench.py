@@ -658,6 +658,9 @@ def main():
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
+    ap.add_argument("--inv-gamma", default="recomputed", choices=["recomputed", "streamed"],
+                    help="1 / gamma of a particle: recomputed from its momenta by the fused kernels (default; two of the "
+                         "thirteen attribute streams go) or loaded and stored like the reference's kernel")
     ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
                     help="rho between two sorts: advanced with the discrete continuity equation (default; the fused "
                          "kernel skips its rho atomics, a real deposit re-anchors rho on every sort step) or deposited "
@@ -720,6 +723,7 @@ def main():
     eng.defer_crossers = not args.no_defer
     eng.reseat = args.reseat
     eng.rho_continuity = args.rho == "continuity"
+    eng.lazy_inv_gamma = args.inv_gamma == "recomputed"
     for _ in range(args.warmup):
         eng.step(dt)
     # timed region: EXACTLY --steps steps between barrier + synchronize on both sides
@@ -764,6 +768,8 @@ def main():
                    # rho between two sorts (lambdapic_amd/rho.py): "continuity" = advanced from the folded currents,
                    # re-anchored by a real deposit on every sort step; "deposited" = the reference's kernel
                    "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
+                   "inv_gamma": "recomputed from the momenta in the fused kernels (LPA_PUSH_NO_IG)" if eng._noig()
+                   else "streamed",
                    "dead_particles": "x = NaN (the resident store has no is_dead array; the 105 B of SURVEY 8(d) "
                                      "count one byte for it)"},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,

@@ -293,6 +293,14 @@ typedef struct {
  * lpa_reset_current) whenever particles appear or vanish outside the kernel, and the kernel reports the particles it
  * absorbs at open faces itself (`absorbed`), whose charge lpa_rho_absorbed takes out of rho before the next update. */
 #define LPA_PUSH_NO_RHO 1
+/* LPA_PUSH_NO_IG (2-D resident stores): inv_gamma is a function of the momenta, 1 / sqrt(1 + u^2) -- the value the
+ * Boris rotation of the reference leaves in the array (unified_pusher_2d.c:50) and reads back for the next half push
+ * (:59-60).  With this flag the fused kernels recompute it from (ux, uy, uz) where the reference loads it and do not
+ * write it back: two of the thirteen attribute streams of a particle-update (16 of 105 bytes) go.  The array is then
+ * STALE until lpa_refresh_inv_gamma rebuilds it (same function, same bits as the fused kernel would have stored);
+ * whoever reads inv_gamma -- mirrors, diagnostics, the split kernels, a checkpoint -- refreshes first.  Tiled kernel:
+ * STRIPED stores with the second-pass scratch arrays and without E / B write-back; global / list kernels: always. */
+#define LPA_PUSH_NO_IG 2
 
 int lpa_push_deposit_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp,
                         int64_t first, int64_t count, void *stream);
@@ -563,6 +571,9 @@ int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage, void *stre
  *      particles: out[0] += sum w (1/inv_gamma - 1) m c^2, out[1] += number alive */
 int lpa_diag_fields(const lpa_grid *g, double eps0, double mu0, double *out, void *stream);
 int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stream);
+/* inv_gamma[i] = 1 / sqrt(1 + ux[i]^2 + uy[i]^2 + uz[i]^2) for the slots [first, first + count): what the fused kernels
+ * would have stored had they not been run with LPA_PUSH_NO_IG (dead slots: whatever their momenta give) */
+int lpa_refresh_inv_gamma(const lpa_particles *p, int64_t first, int64_t count, void *stream);
 
 /* ---- self test of the wave-level reduce-scatter used by the tiled deposit: in[64][64] doubles
  *      (value index, lane) -> out[lane] = sum over lanes of in[lane][.]; one wave. */

@@ -26,6 +26,7 @@ LPA_HALO_PACK_GUARD_SRC, LPA_HALO_UNPACK_GUARD, LPA_HALO_PACK_CURRENT, LPA_HALO_
 LPA_PART_ALL, LPA_PART_EDGE, LPA_PART_INTERIOR = 0, 1, 2
 LPA_ABSORB_X = 16
 LPA_PUSH_NO_RHO = 1
+LPA_PUSH_NO_IG = 2
 
 
 class LpaError(RuntimeError):
@@ -171,6 +172,7 @@ SIGNATURES = {
     "lpa_step": (_i, [C.POINTER(lpa_step_desc), _i, _i, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),
+    "lpa_refresh_inv_gamma": (_i, [_P, _i64, _i64, _vp]),
     "lpa_selftest_wave_reduce": (_i, [_vp, _vp, _vp]),
     "lpa_selftest_wave_shift": (_i, [_vp, _vp, _vp]),
 }

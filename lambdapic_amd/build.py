@@ -27,11 +27,11 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_variant(name: str, defines) -> Path:
-    """diagnostic build with extra -D flags into lambdapic_amd/csrc/build/<name>.so (not the product)"""
+def build_variant(name: str, defines, extra_flags=()) -> Path:
+    """diagnostic build with extra -D flags (and compiler flags) into lambdapic_amd/csrc/build/<name>.so (not the product)"""
     out = CSRC / "build" / f"liblambdapic_amd_{name}.so"
     out.parent.mkdir(exist_ok=True)
-    cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], "-shared", *[str(CSRC / s) for s in SOURCES],
+    cmd = [_hipcc(), *FLAGS, *extra_flags, *[f"-D{d}" for d in defines], "-shared", *[str(CSRC / s) for s in SOURCES],
            "-o", str(out)]
     subprocess.run(cmd, check=True)
     return out

@@ -117,6 +117,7 @@ def _species_arrays(sim, species):
         d = sp["data"][:, : sp["n"]]
         return d[3], d[4], d[5], d[6], ~torch.isnan(d[0])
     sp = eng.species[species.ispec]
+    sp.refresh_inv_gamma()
     a = sp.cset.arr
     n = sp.n
     return a("ux")[:n], a("uy")[:n], a("uz")[:n], a("inv_gamma")[:n], ~torch.isnan(a("x")[:n])

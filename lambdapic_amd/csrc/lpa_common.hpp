@@ -124,6 +124,12 @@ __device__ __forceinline__ double rcp_nr(double a) {
 }
 
 // relativistic Boris rotation, core/pusher/unified/unified_pusher_2d.c:15-51
+// 1 / gamma of a momentum (unified_pusher_2d.c:50).  ONE function for the value the Boris rotation leaves behind and
+// for its recomputation from the stored momenta (LPA_PUSH_NO_IG): the same bits by construction.
+__device__ __forceinline__ double inv_gamma_of(double ux, double uy, double uz) {
+    return rsqrt_nr(fma(uz, uz, fma(uy, uy, fma(ux, ux, 1.0))));
+}
+
 __device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double &ig, double Ex,
                                       double Ey, double Ez, double Bx, double By, double Bz,
                                       double efactor, double bfactor) {
@@ -141,7 +147,7 @@ __device__ __forceinline__ void boris(double &ux, double &uy, double &uz, double
     ux = px + efactor * Ex;
     uy = py + efactor * Ey;
     uz = pz + efactor * Ez;
-    ig = rsqrt_nr(1 + ux * ux + uy * uy + uz * uz);
+    ig = inv_gamma_of(ux, uy, uz);
 }
 
 // One axis of the Esirkepov deposit on a 4-cell window (current/current_deposit.h:7-35,206-249).

@@ -155,7 +155,9 @@ __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, doub
 __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p, const PushK &k, long ip) {
     double x = p.x[ip], y = p.y[ip];
     if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return;
-    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], ig = p.ig[ip], w = p.w[ip];
+    double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], w = p.w[ip];
+    const bool noig = k.flags & LPA_PUSH_NO_IG;      // the store's inv_gamma is neither read nor written
+    double ig = noig ? inv_gamma_of(ux, uy, uz) : p.ig[ip];
     x += k.cdt_half * ig * ux;
     y += k.cdt_half * ig * uy;
     double eb[6];
@@ -173,7 +175,8 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
         report_absorbed_2d(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
                            (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy), k.dep.c_rho * w);
     p.x[ip] = x; p.y[ip] = y;
-    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
+    p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
+    if (!noig) p.ig[ip] = ig;
 }
 
 __global__ void __launch_bounds__(256) k_push_deposit_global_2d(GridV g, PartV p, PushK k, long first,
@@ -314,7 +317,7 @@ struct Coop {
 // Template parameters of the product build: WRITE_EB (store the gathered E / B per particle), DEFER (second pass for
 // the cell-crossers), RHO (deposit rho; false = LPA_PUSH_NO_RHO).  WAVE_REDUCE / RELOC_MODE / COOP select the variant
 // deposit paths and are false / 0 unless LPA_K1_VARIANTS (their code is fenced by `#if LPA_K1_VARIANTS`).
-template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE, bool COOP, bool RHO>
+template <bool WRITE_EB, bool WAVE_REDUCE, bool DEFER, int RELOC_MODE, bool COOP, bool RHO, bool NOIG = false>
 __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_push_deposit_tiled_2d(GridV g, PartV p, PushK k,
                                                               const int32_t *__restrict__ blk_tile,
                                                               const int32_t *__restrict__ blk_begin,
@@ -327,6 +330,13 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     constexpr bool RELOC = RELOC_MODE != 0, RL_INIT = RELOC_MODE == 2;
     static_assert(!RELOC || (DEFER && !WAVE_REDUCE && !WRITE_EB), "RELOC rides on the parked-crosser pass");
     static_assert(!COOP || (DEFER && !WAVE_REDUCE), "COOP parks what it cannot deposit");
+    // NOIG (lpa_push_params.flags & LPA_PUSH_NO_IG): inv_gamma is a function of the momenta, so the resident store need
+    // not stream it -- 1 / gamma is recomputed from (ux, uy, uz) with the very function the Boris rotation ends with
+    // (inv_gamma_of: ~10 VALU instructions) instead of being loaded, and is not written back: 16 of the 105 bytes per
+    // particle-update.  K1 2-D moves its bytes at 72 % of what a plain streaming kernel with the same accesses reaches
+    // (tools/ubench/stream_soa.hip: 6.07 TB/s) and every attribute stream it drops is worth 0.06-0.09 ms (DESIGN.md
+    // section 5, round 3).  The array goes stale; lpa_refresh_inv_gamma rebuilds it for whoever reads it.
+    static_assert(!NOIG || (DEFER && !WRITE_EB && !WAVE_REDUCE && !RELOC_MODE && !COOP), "NOIG: product path only");
     static_assert(LPA_K1_VARIANTS || (!WAVE_REDUCE && !RELOC && !COOP), "variant paths need -DLPA_K1_VARIANTS=1");
     static_assert(RHO || (!WAVE_REDUCE && !COOP), "the variant deposits always carry rho");
     constexpr int NJ = RHO ? 4 : 3;      // jx jy jz (rho)
@@ -422,7 +432,8 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         if (ip0 < end) {
             const uint32_t o = (uint32_t)ip0 * 8u;
             nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
-            nig = ldp(p.ig, o); nw = ldp(p.w, o);
+            if (!NOIG) nig = ldp(p.ig, o);
+            nw = ldp(p.w, o);
         }
     }
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
@@ -438,9 +449,11 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (ipn < end) {
                 const uint32_t o = (uint32_t)ipn * 8u;
                 nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
-                nig = ldp(p.ig, o); nw = ldp(p.w, o);
+                if (!NOIG) nig = ldp(p.ig, o);
+                nw = ldp(p.w, o);
             }
         }
+        if (NOIG) ig = inv_gamma_of(ux, uy, uz);
         valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
         // first half push and the nearest node (ix1, iy1) of the mid-step position.  The LDS path is
         // valid iff that node lies within the tile + margin: the gather then reads nodes ix1-2..ix1+1
@@ -567,7 +580,8 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)ip * 8u;
             stp(p.x, o, xs); stp(p.y, o, ys);
-            stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); stp(p.ig, o, ig);
+            stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz);
+            if (!NOIG) stp(p.ig, o, ig);
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -984,10 +998,14 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     Reloc rl{t->slot_class, t->aux_slot, t->aux_info, (unsigned long long *)t->scratch[7], t->reloc_stats,
              t->class_init};
     Coop co{t->tile_off, t->pad_ranks};
-#define LPA_LAUNCH_TILED(E, W, D, R, CO, RH)                                                                  \
-    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R, CO, RH>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
+#define LPA_LAUNCH_TILED(E, W, D, R, CO, RH, ...)                                                             \
+    hipLaunchKernelGGL((k_push_deposit_tiled_2d<E, W, D, R, CO, RH, ##__VA_ARGS__>), dim3(t->max_blocks), dim3(K1_THREADS), 0, \
                        (hipStream_t)stream, gv, pv, k, t->blk_tile, t->blk_begin, t->blk_end, t->n_blocks,   \
                        t->tiles_y, overflow, overflow_count, part, t->tiles_x, edge_cols, sc, rl, co)
+    const bool noig = pp->flags & LPA_PUSH_NO_IG;
+    LPA_REQUIRE(!noig || (defer && !eb && t->order == LPA_ORDER_STRIPED && !t->slot_class),
+                "lpa_push_deposit_tiled_2d: LPA_PUSH_NO_IG needs a STRIPED store without E / B write-back and slot "
+                "classes, and the scratch arrays of the second pass");
 #if LPA_K1_VARIANTS
     // CELL_MAJOR stores use the wave reduce-scatter deposit, PADDED stores the cooperative one; with slot classes the
     // striped path re-seats its movers.  The variant deposits always carry rho.
@@ -1011,7 +1029,9 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
     LPA_REQUIRE(!t->slot_class, "lpa_push_deposit_tiled_2d: the in-kernel re-seating (slot classes) is compiled only "
                                 "into the variants library (-DLPA_K1_VARIANTS=1)");
 #endif
-    if (eb && defer && rho) LPA_LAUNCH_TILED(true, false, true, 0, false, true);
+    if (noig && rho) LPA_LAUNCH_TILED(false, false, true, 0, false, true, true);
+    else if (noig) LPA_LAUNCH_TILED(false, false, true, 0, false, false, true);
+    else if (eb && defer && rho) LPA_LAUNCH_TILED(true, false, true, 0, false, true);
     else if (eb && defer) LPA_LAUNCH_TILED(true, false, true, 0, false, false);
     else if (eb && rho) LPA_LAUNCH_TILED(true, false, false, 0, false, true);
     else if (eb) LPA_LAUNCH_TILED(true, false, false, 0, false, false);
@@ -1140,6 +1160,25 @@ __global__ void __launch_bounds__(256) k_diag_particles(PartV p, double mc2, dou
     }
     block_atomic_sum(e * mc2, out + 0);
     block_atomic_sum(n, out + 1);
+}
+
+__global__ void __launch_bounds__(256) k_refresh_inv_gamma(PartV p, long first, long count) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x * blockDim.x) {
+        const long ip = first + t;
+        p.ig[ip] = inv_gamma_of(p.ux[ip], p.uy[ip], p.uz[ip]);
+    }
+}
+
+extern "C" int lpa_refresh_inv_gamma(const lpa_particles *p, int64_t first, int64_t count, void *stream) {
+    LPA_REQUIRE(p && first >= 0 && count >= 0 && first + count <= p->n &&
+                    (count == 0 || (p->ux && p->uy && p->uz && p->inv_gamma)),
+                "lpa_refresh_inv_gamma: bad args");
+    if (count == 0) return LPA_OK;
+    const long nb = (count + 255) / 256;
+    hipLaunchKernelGGL(k_refresh_inv_gamma, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       make_partv(p), (long)first, (long)count);
+    LPA_CHECK_LAUNCH("lpa_refresh_inv_gamma");
+    return LPA_OK;
 }
 
 extern "C" int lpa_diag_particles(const lpa_particles *p, double m, double *out, void *stream) {

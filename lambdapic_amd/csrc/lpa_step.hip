@@ -24,7 +24,7 @@ static int step_fields(const lpa_step_desc *d, bool efield, void *st) {
 static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
     lpa_push_params pp = sp->pp;
     pp.dt = d->dt;
-    pp.flags = d->continuity ? LPA_PUSH_NO_RHO : 0;
+    pp.flags = (sp->pp.flags & ~LPA_PUSH_NO_RHO) | (d->continuity ? LPA_PUSH_NO_RHO : 0);   // (LPA_PUSH_NO_IG: per species)
     pp.absorbed = d->absorbed; pp.absorbed_count = d->absorbed_count; pp.absorbed_capacity = d->absorbed_capacity;
     return pp;
 }

@@ -15,6 +15,8 @@ HBM layout
 from __future__ import annotations
 
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -164,6 +166,19 @@ class DeviceParticles:
         self.n_sorted = 0     # [0, n_sorted) is tile ordered
         self.tiling = None
         self.steps_since_sort = 0
+        # the fused kernels of the resident engine do not stream inv_gamma (LPA_PUSH_NO_IG): the array is rebuilt from
+        # the momenta for whoever reads it (refresh_inv_gamma)
+        self.ig_stale = False
+
+    def refresh_inv_gamma(self):
+        """inv_gamma[0:n) = 1 / sqrt(1 + u^2) if a fused push left it stale (same function, same bits as the kernel
+        would have stored); call before reading ``cset.arr('inv_gamma')`` directly"""
+        if getattr(self, "ig_stale", False) and self.n > 0:
+            pc = self.cset.cstruct(self.n, eb=False)
+            _lib.check(_lib.lib().lpa_refresh_inv_gamma(C.byref(pc), 0, self.n,
+                                                      torch.cuda.current_stream(self.device).cuda_stream),
+                       "lpa_refresh_inv_gamma")
+        self.ig_stale = False
 
     @property
     def cset(self) -> ParticleSet:
@@ -206,10 +221,12 @@ class DeviceParticles:
             s.arr(a)[:n].copy_(torch.from_numpy(np.concatenate(cols[a])))
         s.id[:n].copy_(torch.from_numpy(np.concatenate(ids)))
         self.n, self.n_sorted, self.tiling = n, 0, None
+        self.ig_stale = False
 
     def __getstate__(self):
         """slots [0, n) of the current set as host arrays (dead slots included: x = NaN marks them); the tile
         order is not kept -- the first push after a load re-sorts, like the first push of a run"""
+        self.refresh_inv_gamma()
         st = {k: v for k, v in self.__dict__.items() if k not in ("sets", "tiling", "device")}
         s = self.cset
         st.update(device=str(self.device), names=list(s.names), data_host=to_host(s.data[:, : self.n]),
@@ -230,6 +247,7 @@ class DeviceParticles:
 
     def download(self):
         """dict of host arrays of the LIVE particles (order = device order)"""
+        self.refresh_inv_gamma()
         s = self.cset
         x = s.arr("x")[: self.n]
         live = ~torch.isnan(x)

@@ -182,6 +182,10 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # (profiles/r02_pmc_reseat.txt) and still leaves K1 at 1.95-1.99 ms against 1.91-1.94 ms without it -- the
         # class test costs 6 % more VALU instructions and the extra parked particles a longer second pass
         self.reseat = False
+        # inv_gamma is a function of the momenta: the fused kernels recompute it instead of streaming it (two of the
+        # thirteen attribute streams of a particle-update; LPA_PUSH_NO_IG) and the array is rebuilt on demand
+        # (DeviceParticles.refresh_inv_gamma: download, diagnostics, the split kernels, a checkpoint)
+        self.lazy_inv_gamma = True
         self.reseat_stats = False  # diagnostics: count parked particles / movers / unmatched movers (ws["reloc_stats"])
         self.fused_cpml = True
         self._axes = {}
@@ -499,7 +503,15 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         pp.lo[1], pp.hi[1] = self.y0 - self.dy / 2, self.y0 + self.Ly - self.dy / 2
         pp.lo[2], pp.hi[2] = 0.0, 0.0
         self._push_flags(pp, dt, self.absorb)
+        if self._noig():
+            pp.flags |= _lib.LPA_PUSH_NO_IG
+            sp.ig_stale = True
         return pp
+
+    def _noig(self):
+        """may the fused kernels leave inv_gamma alone?  (what the tiled kernel's LPA_PUSH_NO_IG instantiation needs)"""
+        return (self.lazy_inv_gamma and not self.write_part_eb and self.order == _lib.LPA_ORDER_STRIPED
+                and not self.reseat and self.defer_crossers)
 
     def push_deposit(self, ispec, dt, tiled=True, part=_lib.LPA_PART_ALL, edge_cols=0):
         """``part``: LPA_PART_EDGE pushes the edge tile columns, the overflow list and the loose
@@ -607,6 +619,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def push_position(self, ispec, dt):
         sp = self.species[ispec]
+        sp.refresh_inv_gamma()
         pc = sp.cset.cstruct(sp.n)
         check(self.L.lpa_push_position_2d(C.byref(pc), dt, self.stream), "lpa_push_position_2d")
 
@@ -624,6 +637,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if self._no_rho:
             raise _lib.LpaError("the standalone deposit carries rho: set rho_continuity_blocked (or rho_continuity = "
                                 "False) before reset_current() when the split pusher path is used")
+        sp.refresh_inv_gamma()
         pc = sp.cset.cstruct(sp.n)
         check(self.L.lpa_deposit_2d(self._g(), C.byref(pc), dt, sp.q, self.stream), "lpa_deposit_2d")
         pp = self._push_params(sp, dt)
@@ -936,6 +950,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                    jx=f[3], jy=f[4], jz=f[5], kinetic=[], nalive=[])
         for sp in self.species:
             d = torch.zeros(2, dtype=torch.float64, device=self.device)
+            sp.refresh_inv_gamma()
             pc = sp.cset.cstruct(sp.n)
             check(self.L.lpa_diag_particles(C.byref(pc), sp.m, d.data_ptr(), st), "diag particles")
             d = d.cpu().numpy()

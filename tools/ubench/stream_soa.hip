@@ -1,0 +1,50 @@
+// stream_soa.hip -- what HBM rate does K1's memory pattern reach without K1's arithmetic?
+// 7 SoA attribute arrays of N doubles; a 512-thread workgroup owns a block of 8192 particles and walks it in 16
+// iterations with the next iteration's 7 loads in flight (K1's software pipeline); 6 attributes are written back
+//   mode 0: in place (K1)          mode 1: to a second set of arrays (out of place)      mode 2: reads only
+//   mode 3: in place, 7 x dwordx4 per two particles (wider accesses: thread handles 2 consecutive particles)
+// hipcc --offload-arch=gfx950 -O3 tools/ubench/stream_soa.hip -o tools/ubench/stream_soa
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+struct Arr { double *a[7]; };
+template <int MODE>
+__global__ void __launch_bounds__(512) k(Arr in, Arr out, long n, int block) {
+    long begin = (long)blockIdx.x * block, end = begin + block < n ? begin + block : n;
+    double v[7], nv[7];
+    long ip = begin + threadIdx.x;
+    for (int c = 0; c < 7; c++) nv[c] = ip < end ? in.a[c][ip] : 0.0;
+    double acc = 0.0;
+    for (; ip < end; ip += 512) {
+        for (int c = 0; c < 7; c++) v[c] = nv[c];
+        long ipn = ip + 512;
+        if (ipn < end) for (int c = 0; c < 7; c++) nv[c] = in.a[c][ipn];
+        double g = v[5] * 0.999 + 1e-9 * v[6];
+        if (MODE == 2) { acc += v[0] + v[1] + v[2] + v[3] + v[4] + g; continue; }
+        double *const *dst = MODE == 1 ? out.a : in.a;
+        dst[0][ip] = v[0] + 1e-9 * v[2]; dst[1][ip] = v[1] + 1e-9 * v[3];
+        dst[2][ip] = v[2] * 0.999; dst[3][ip] = v[3] * 0.999; dst[4][ip] = v[4] * 0.999; dst[5][ip] = g;
+    }
+    if (MODE == 2 && acc == 1.2345e300) out.a[0][0] = acc;
+}
+int main() {
+    const long n = 1l << 26;
+    Arr a, b;
+    for (int c = 0; c < 7; c++) { hipMalloc(&a.a[c], n * 8); hipMalloc(&b.a[c], n * 8); hipMemset(a.a[c], 0, n * 8); hipMemset(b.a[c], 0, n * 8); }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int block = 8192; const int nb = (int)((n + block - 1) / block);
+    for (int mode = 0; mode < 3; mode++) {
+        float best = 1e9;
+        for (int rep = 0; rep < 6; rep++) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nb), dim3(512), 0, 0, a, b, n, block);
+            if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nb), dim3(512), 0, 0, a, b, n, block);
+            if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(nb), dim3(512), 0, 0, a, b, n, block);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
+        }
+        double bytes = (double)n * 8 * (mode == 2 ? 7 : 13);
+        printf("mode %d (%s): %.3f ms  %.2f TB/s\n", mode, mode == 0 ? "in place 7r/6w" : mode == 1 ? "out of place 7r/6w" : "reads only 7r", best, bytes / best / 1e9);
+    }
+    return 0;
+}
