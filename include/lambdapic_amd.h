@@ -373,7 +373,8 @@ int lpa_wrap_positions_3d(const lpa_particles *p, const lpa_push_params *pp, voi
  *      binned by LPA_TILE_X x LPA_TILE_Y cell tiles into `dst` (same capacity), dead / NaN
  *      particles are dropped (they sort behind every live particle in the reference and are
  *      recycled by sync_particles); the order inside a tile is `order` (LPA_ORDER_*).  The number
- *      of live particles is written to the workspace header (lpa_sort_live_count). */
+ *      of live particles is written to the workspace header (lpa_sort_live_count).  `inv_gamma` may be NULL in
+ *      BOTH stores (see LPA_PUSH_NO_IG): it is then not moved. */
 int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,

@@ -651,8 +651,10 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 if (DEFER && (cross || (RELOC && mover))) {
                     const int slot = atomicAdd(&s_ncross, 1);
                     const uint32_t o = (uint32_t)(begin + slot) * 8u;
+#ifndef LPA_ABLATE_NO_PARK   // diagnostic build (wrong physics, with LPA_ABLATE_NO_PASS2): what the seven parking stores cost
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
                     st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
+#endif
                     if (RELOC) {
                         rl.aux_slot[begin + slot] = (uint32_t)ip;
                         rl.aux_info[begin + slot] = (ccls << 8) | (cnow << 16) | (cross ? RL_DEP : 0u) | (mover ? RL_MOV : 0u);

@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
     d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
-    d.ig[o] = s.ig[ip]; d.w[o] = s.w[ip];
+    if (s.ig && d.ig) d.ig[o] = s.ig[ip];
+    d.w[o] = s.w[ip];
     if (s.id && d.id) d.id[o] = s.id[ip];
     if (s.eb[0] && d.eb[0]) {
 #pragma unroll
@@ -527,7 +528,11 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                       int32_t block_particles, int32_t order, lpa_tiling *out, void *stream) {
     LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && (dim == 2 || (g->nz > 1 && g->dz > 0)),
                 "%s: bad grid", name);
-    LPA_REQUIRE(lpa_part_ok(src, dim) && lpa_part_ok(dst, dim) && workspace && out,
+    // inv_gamma may be left out of BOTH stores: a store whose fused kernels run with LPA_PUSH_NO_IG holds a stale array
+    // that nobody wants moved (the destination's is rebuilt by lpa_refresh_inv_gamma before anything reads it)
+    lpa_particles s_chk = *src, d_chk = *dst;
+    if (!src->inv_gamma && !dst->inv_gamma) s_chk.inv_gamma = s_chk.ux, d_chk.inv_gamma = d_chk.ux;
+    LPA_REQUIRE(lpa_part_ok(&s_chk, dim) && lpa_part_ok(&d_chk, dim) && workspace && out,
                 "%s: bad particle stores / workspace", name);
     LPA_REQUIRE(order == LPA_ORDER_CELL_MAJOR || order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED ||
                     order == LPA_ORDER_COLUMN,

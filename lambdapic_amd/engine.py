@@ -415,6 +415,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         ws = self._ws_checked(sp)
         src, dst = sp.cset, sp.other()
         ps, pd = src.cstruct(sp.n), dst.cstruct(dst.capacity)
+        if self._noig():          # nobody reads the store's inv_gamma before a refresh: the sort need not move it
+            ps.inv_gamma = pd.inv_gamma = None
+            sp.ig_stale = True
         # small stores: smaller work blocks, or a 2 M-particle species is 256 workgroups on 256 CUs (config C3: K1
         # 0.19 -> 0.15 ms per step with 4096, tools/exp_c3_blocks.py)
         bp = self.block_particles if sp.n >= (1 << 23) else min(self.block_particles, 4096)
