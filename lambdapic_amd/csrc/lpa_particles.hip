@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                     const uint32_t o = (uint32_t)(begin + slot) * 8u;
 #ifndef LPA_ABLATE_NO_PARK   // diagnostic build (wrong physics, with LPA_ABLATE_NO_PASS2): what the seven parking stores cost
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
-                    st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
+                    st(sc.a[4], o, uz); if (!NOIG) st(sc.a[5], o, ig); st(sc.a[6], o, w);
 #endif
                     if (RELOC) {
                         rl.aux_slot[begin + slot] = (uint32_t)ip;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (!(info & RL_DEP) && !(first && (info & RL_MOV))) continue;
             const uint32_t o = (uint32_t)(begin + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
-                         uz = ld(sc.a[4], o), ig = ld(sc.a[5], o), w = ld(sc.a[6], o);
+                         uz = ld(sc.a[4], o), ig = NOIG ? inv_gamma_of(ux, uy, uz) : ld(sc.a[5], o), w = ld(sc.a[6], o);
 #if LPA_K1_VARIANTS
 #ifdef LPA_RL_NO_PHASES   // diagnostic build: movers are parked but stay where they are
             if (false) {
