@@ -454,6 +454,9 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             }
         }
         if (NOIG) ig = inv_gamma_of(ux, uy, uz);
+#ifdef LPA_ABLATE_PSTORE_SAME
+        const double x0_loaded = x, y0_loaded = y, u0_loaded[3] = {ux, uy, uz};
+#endif
         valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
         // first half push and the nearest node (ix1, iy1) of the mid-step position.  The LDS path is
         // valid iff that node lies within the tile + margin: the gather then reads nodes ix1-2..ix1+1
@@ -579,9 +582,23 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                    k.dep.c_rho * w);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)ip * 8u;
+            // diagnostic builds (wrong physics; profiles/r03_k1_streams.txt): what the attribute stores cost
+#if defined(LPA_ABLATE_NO_PSTORE)          // none at all
+            if (xs == 1.2345e300) { stp(p.x, o, xs); stp(p.y, o, ys); stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); }
+#elif defined(LPA_ABLATE_PSTORE_OOP)       // to the scratch arrays (out of place; LPA_ABLATE_PSTORE_OOP = 2: w with them)
+            stp(sc.a[0], o, xs); stp(sc.a[1], o, ys); stp(sc.a[2], o, ux); stp(sc.a[3], o, uy); stp(sc.a[4], o, uz);
+            if (!NOIG) stp(sc.a[5], o, ig);
+            if (LPA_ABLATE_PSTORE_OOP == 2) stp(sc.a[6], o, w);
+#elif defined(LPA_ABLATE_PSTORE_SAME)      // in place, values that do not move the particle (no drift between sorts)
+            stp(p.x, o, x0_loaded + 1e-300 * xs); stp(p.y, o, y0_loaded + 1e-300 * ys);
+            stp(p.ux, o, u0_loaded[0] + 1e-300 * ux); stp(p.uy, o, u0_loaded[1] + 1e-300 * uy);
+            stp(p.uz, o, u0_loaded[2] + 1e-300 * uz);
+            if (!NOIG) stp(p.ig, o, ig);
+#else
             stp(p.x, o, xs); stp(p.y, o, ys);
             stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz);
             if (!NOIG) stp(p.ig, o, ig);
+#endif
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
