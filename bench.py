@@ -768,8 +768,10 @@ def main():
                    # rho between two sorts (lambdapic_amd/rho.py): "continuity" = advanced from the folded currents,
                    # re-anchored by a real deposit on every sort step; "deposited" = the reference's kernel
                    "rho": eng.rho_mode(), "rho_steps": dict(eng.rho_steps),
-                   "inv_gamma": "recomputed from the momenta in the fused kernels (LPA_PUSH_NO_IG)" if eng._noig()
-                   else "streamed",
+                   # algorithmic bytes stay SURVEY 8(d)'s 105 B per particle-update (the reference's data contract); with
+                   # LPA_PUSH_NO_IG the kernel itself streams 89 of them (inv_gamma neither loaded nor stored)
+                   "inv_gamma": "recomputed from the momenta in the fused kernels (LPA_PUSH_NO_IG): 89 of the 105 "
+                                "algorithmic bytes are streamed" if eng._noig() else "streamed",
                    "dead_particles": "x = NaN (the resident store has no is_dead array; the 105 B of SURVEY 8(d) "
                                      "count one byte for it)"},
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
