@@ -171,6 +171,13 @@ int lpa_cpml_psi_2d(const lpa_grid *g, int efield, int axis, int start, int stop
  *      rows iy in [iy_start, iy_end) are driven. */
 int lpa_laser_inject_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start,
                         int iy_end, const double *ey_source, const double *ez_source, void *stream);
+/* the same with the sources factorised: the profiles of callback/laser.py:351-386,504-555 are amp(y) T(t) times
+ * sin / cos of theta(t) + phi(y) (plane phase fronts at normal incidence, Gaussian / Laguerre-Gaussian beams), i.e.
+ *      ey_source = k4[0] pc + k4[1] ps,   ez_source = k4[2] pc + k4[3] ps,   pc = amp cos(phi), ps = amp sin(phi)
+ * with pc, ps [ny] fixed for the run and four numbers per step (lambdapic_amd/laser.py: Laser2D.separable): the
+ * kernel evaluates the sources itself and the '_laser' stage is one launch. */
+int lpa_laser_inject_sep_2d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start, int iy_end,
+                            const double *pc, const double *ps, const double *k4, void *stream);
 /* fused form: the kappa-scaled update and the psi recursions of all the layers a cell lies in, in one launch
  * per field update (same operations, same order; the psi recursion of E reads only B and vice versa).
  * One descriptor per axis: kappa [n]; the low / high layer's cell range ([x0, x1) empty = none), bcoeff /
@@ -200,6 +207,10 @@ int lpa_cpml_psi_3d(const lpa_grid *g, int efield, int axis, int start, int stop
 int lpa_laser_inject_3d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start, int iy_end,
                         int iz_start, int iz_end, const double *ey_source, const double *ez_source,
                         void *stream);
+/* factorised sources (see lpa_laser_inject_sep_2d); pc, ps [ny][nz] */
+int lpa_laser_inject_sep_3d(const lpa_grid *g, int laserpos, double dt, double eps0, int iy_start, int iy_end,
+                            int iz_start, int iz_end, const double *pc, const double *ps, const double *k4,
+                            void *stream);
 
 /* ---- zero jx jy jz rho including guards (replaces reset_current_cpu_2d/3d,
  *      core/current/cpu2d.c:19-72, cpu3d.c:185-240) */

@@ -108,6 +108,7 @@ SIGNATURES = {
     "lpa_fdtd_b_cpml_2d": (_i, [_G, _d, _vp, _vp, _vp]),
     "lpa_cpml_psi_2d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "lpa_laser_inject_2d": (_i, [_G, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
+    "lpa_laser_inject_sep_2d": (_i, [_G, _i, _d, _d, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "lpa_fdtd_e_cpml_fused_2d": (_i, [_G, _d, _d, C.POINTER(lpa_cpml_axis), C.POINTER(lpa_cpml_axis), _vp]),
     "lpa_fdtd_b_cpml_fused_2d": (_i, [_G, _d, C.POINTER(lpa_cpml_axis), C.POINTER(lpa_cpml_axis), _vp]),
     "lpa_fdtd_e_cpml_fused_3d": (_i, [_G, _d, _d] + [C.POINTER(lpa_cpml_axis)] * 3 + [_vp]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "lpa_fdtd_b_cpml_3d": (_i, [_G, _d, _vp, _vp, _vp, _vp]),
     "lpa_cpml_psi_3d": (_i, [_G, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "lpa_laser_inject_3d": (_i, [_G, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "lpa_laser_inject_sep_3d": (_i, [_G, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "lpa_reset_current": (_i, [_G, _vp]),
     "lpa_reset_j": (_i, [_G, _vp]),
     "lpa_rho_continuity": (_i, [_G, _d, _i, _i, _vp, _vp]),

@@ -331,6 +331,18 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                                          self.stream), "lpa_laser_inject_2d")
         self._keep = (ey, ez)   # keep the buffers alive until the stream has consumed them
 
+    def laser_inject_sep(self, pc, ps, k4, dt):
+        """factorised sources (device tensors ``pc``, ``ps`` [ny], four floats ``k4``): ey = k4[0] pc + k4[1] ps,
+        ez = k4[2] pc + k4[3] ps, evaluated inside the injection kernel (lpa_laser_inject_sep_2d)"""
+        if self.pml is None or "xmin" not in self.pml.sides:
+            return
+        t = self.cpml_thickness
+        iy0 = t if self.bc["ymin"] == "pml" else 0
+        iy1 = self.ny - t if self.bc["ymax"] == "pml" else self.ny
+        kk = (C.c_double * 4)(*[float(v) for v in k4])
+        check(self.L.lpa_laser_inject_sep_2d(self._g(), t + 2, dt, self.eps0, iy0, iy1, pc.data_ptr(), ps.data_ptr(), kk,
+                                             self.stream), "lpa_laser_inject_sep_2d")
+
     # ---- guard cells (Patches.sync_guard_fields + MPIManager.sync_guard_fields_start/_wait) --------
     def _halo_bufs(self):
         if self._halo is None:

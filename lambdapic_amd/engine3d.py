@@ -590,6 +590,17 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                                          ez.data_ptr(), self.stream), "lpa_laser_inject_3d")
         self._keep = (ey, ez)
 
+    def laser_inject_sep(self, pc, ps, k4, dt):
+        """factorised sources (device tensors ``pc``, ``ps`` [ny][nz], four floats ``k4``), see PicEngine2D"""
+        if self.pml is None or "xmin" not in self.pml.sides:
+            return
+        t = self.cpml_thickness
+        iy0, iy1 = (t, self.n[1] - t) if self.bc["ymin"] == "pml" else (0, self.n[1])
+        iz0, iz1 = (t, self.n[2] - t) if self.bc["zmin"] == "pml" else (0, self.n[2])
+        kk = (C.c_double * 4)(*[float(v) for v in k4])
+        check(self.L.lpa_laser_inject_sep_3d(self._g(), t + 2, dt, self.eps0, iy0, iy1, iz0, iz1, pc.data_ptr(),
+                                             ps.data_ptr(), kk, self.stream), "lpa_laser_inject_sep_3d")
+
     # ---- moving window (MovingWindow callback, callback/utils.py:471-648; 3-D patch relabelling :705-730) ----
     def remove_x_pml(self):
         """the reference drops the x layers when the window starts moving (callback/utils.py:547-553)"""

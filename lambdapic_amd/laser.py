@@ -32,6 +32,93 @@ def _polyval(coeffs, x):
     return acc
 
 
+# ---- factorised sources: one launch per '_laser' stage ---------------------------------------------------------------
+# Evaluated as torch expressions a profile is ~17 launches of 4 us per step -- 0.14 ms, a third of a C3 step.  The
+# profiles of the reference are amp(y[, z]) T(t) times sin / cos of theta(t) + phi(y[, z]) whenever the temporal envelope is
+# the same on the whole boundary (Gaussian / Laguerre-Gaussian beams; the plane-front pulse at normal incidence), so
+#     ey = k0 pc + k1 ps,  ez = k2 pc + k3 ps,   pc = amp cos(phi), ps = amp sin(phi)  (fixed arrays),
+# with four numbers per step; lpa_laser_inject_sep_2d/3d evaluates that inside the injection kernel.  pc, ps are not
+# re-derived here: they are solved from the class' own source_fields (the formulas pinned by tests/test_laser_profiles.py)
+# at the envelope's peak with (pol_angle, ellipticity) = (0, 1), where ey = amp sin(phase) / sqrt 2 and
+# ez = amp cos(phase) / sqrt 2; the factorisation is then checked against source_fields at another time and the laser
+# falls back to the general path if it does not reproduce it (oblique incidence: the envelope varies along y).
+class _SimAt:
+    """what source_fields reads of a simulation, at another time"""
+
+    def __init__(self, sim, time):
+        self.time, self.cpml_thickness, self.dx = time, sim.cpml_thickness, sim.dx
+
+
+def _sep_coefficients(T, theta, pol_angle, ellipticity):
+    """k0 .. k3 of the factorised sources (the algebra of _polarise on sin / cos of theta + phi)"""
+    norm = float(np.sqrt(1 + ellipticity ** 2))
+    major, minor = 1.0 / norm, ellipticity / norm
+    cp, sp = float(np.cos(pol_angle)), float(np.sin(pol_angle))
+    a, b, c, d = major * cp, minor * sp, major * sp, minor * cp
+    st, ct = float(np.sin(theta)), float(np.cos(theta))
+    return (T * (a * st - b * ct), T * (a * ct + b * st), T * (c * st + d * ct), T * (c * ct - d * st))
+
+
+def _factorise(laser, sim, coords):
+    """(pc, ps) device tensors of ``laser`` on the boundary ``coords``, or None when its sources do not factorise"""
+    import copy
+    tf = getattr(laser, "_time_factors", None)
+    if tf is None or not getattr(laser, "factorise", True):
+        return None
+    t_pk = laser._t_peak()
+    T, theta = tf(sim, t_pk)
+    if not T > 0.5:
+        return None
+    probe = copy.copy(laser)
+    probe.pol_angle, probe.ellipticity = 0.0, 1.0
+    e_s, e_c = probe.source_fields(_SimAt(sim, t_pk), *coords)
+    if e_s is None:
+        return None
+    a_s, a_c = e_s * float(np.sqrt(2.0) / T), e_c * float(np.sqrt(2.0) / T)      # amp sin / cos (theta + phi)
+    st, ct = float(np.sin(theta)), float(np.cos(theta))
+    pc, ps = (a_c * ct + a_s * st).contiguous(), (a_s * ct - a_c * st).contiguous()
+    # does it reproduce the profile at another moment of the pulse?
+    t2 = t_pk * 0.83 + 0.37 * 2 * np.pi / laser.omega0
+    ey, ez = laser.source_fields(_SimAt(sim, t2), *coords)
+    if ey is None:
+        return None
+    k = _sep_coefficients(*tf(sim, t2), laser.pol_angle, laser.ellipticity)
+    scale = float(max(ey.abs().max(), ez.abs().max(), pc.abs().max()))
+    err = float(max((k[0] * pc + k[1] * ps - ey).abs().max(), (k[2] * pc + k[3] * ps - ez).abs().max()))
+    return (pc, ps) if err <= 1e-10 * scale else None
+
+
+def _inject(laser, sim, coords, key):
+    """one '_laser' stage: the factorised form when the profile allows it, else the general one"""
+    eng = sim.engine
+    if getattr(laser, "_sep_key", None) != key:
+        laser._sep, laser._sep_key = _factorise(laser, sim, coords), key
+    if laser._sep is not None:
+        k = _sep_coefficients(*laser._time_factors(sim, sim.time), laser.pol_angle, laser.ellipticity)
+        eng.laser_inject_sep(laser._sep[0], laser._sep[1], k, sim.dt)
+        return
+    ey, ez = laser.source_fields(sim, *coords)
+    if ey is not None:
+        eng.laser_inject(ey, ez, sim.dt)
+
+
+def _simple_time_factors(self, sim, time):
+    """SimpleLaser (callback/laser.py:351-386) at normal incidence: sin^2 envelope, plane phase"""
+    if self.angle_y != 0:
+        return 0.0, 0.0
+    ct = C * time
+    return (float(np.sin(ct / (2 * self.ctau) * np.pi) ** 2) if ct < 2 * self.ctau else 0.0), self.omega0 * time + self.cep
+
+
+def _gaussian_time_factors(self, sim, time):
+    """GaussianLaser (callback/laser.py:504-555): Gaussian envelope; the phase carries the propagation to the injection
+    plane and the Gouy shift"""
+    x_rel = sim.cpml_thickness * sim.dx
+    psi = self.beam_params(x_rel)[2]
+    return (float(np.exp(-(C * time - self.x0) ** 2 / self.ctau ** 2)),
+            self.omega0 * time + self.cep - self.k0 * x_rel - (2 * self.p + abs(self.l) + 1) * psi)
+
+
 class _LaserBase:
     """shared state of the 2-D and 3-D callbacks"""
     stage = "_laser"
@@ -78,9 +165,13 @@ class Laser2D:
         if eng.bc["xmin"] != "pml" or (eng.comm.rank == 0 and (eng.pml is None or "xmin" not in eng.pml.sides)):
             self.disabled = True
             return
-        ey, ez = self.source_fields(sim, self.boundary_y_device(sim))
-        if ey is not None:
-            eng.laser_inject(ey, ez, sim.dt)
+        y = self.boundary_y_device(sim)
+        if y is None:                        # a sum of lasers: each evaluates on its own coordinates
+            ey, ez = self.source_fields(sim, None)
+            if ey is not None:
+                eng.laser_inject(ey, ez, sim.dt)
+            return
+        _inject(self, sim, (y,), (id(eng), sim.Ly, sim.cpml_thickness, sim.dx, self.pol_angle, self.ellipticity))
 
     def boundary_y_device(self, sim):
         key = (id(sim.engine), sim.Ly)
@@ -260,9 +351,7 @@ class Laser3D(_LaserBase):
         if getattr(self, "_yz_key", None) != key:      # boundary coordinates live on the device
             self._yz = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(eng.device) for a in self.boundary_yz(sim))
             self._yz_key = key
-        ey, ez = self.source_fields(sim, *self._yz)
-        if ey is not None:
-            eng.laser_inject(ey, ez, sim.dt)
+        _inject(self, sim, self._yz, key + (sim.cpml_thickness, sim.dx, self.pol_angle, self.ellipticity))
 
 
 class SimpleLaser3D(Laser3D):
@@ -322,3 +411,13 @@ class GaussianLaser3D(Laser3D):
         phase = (float(self.omega0 * time + self.cep - self.k0 * x_rel - (2 * self.p + abs(self.l) + 1) * psi)
                  - float(self.k0 / (2 * R)) * r ** 2 - phase_lg)
         return _polarise(amp, phase, self.pol_angle, self.ellipticity)
+
+
+# the time factors / envelope peaks of the factorised form (see _factorise)
+for _cls in (SimpleLaser2D, SimpleLaser3D):
+    _cls._time_factors = _simple_time_factors
+    _cls._t_peak = lambda self: self.ctau / C
+for _cls in (GaussianLaser2D, GaussianLaser3D):
+    _cls._time_factors = _gaussian_time_factors
+    _cls._t_peak = lambda self: self.x0 / C
+del _cls

@@ -196,3 +196,44 @@ def test_gaussian_laser_and_sum_inject_on_device():
     # vacuum Maxwell is linear: the sum of the runs is the run of the sum
     assert (ey12 - ey1 - ey2).abs().max().item() < 1e-12 * E0
     assert (ez12 - ez1 - ez2).abs().max().item() < 1e-12 * E0
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_factorised_laser_sources_match_the_general_path(dim):
+    """The '_laser' stage as ONE launch (lpa_laser_inject_sep_2d/3d: the profile factorised into two fixed arrays and four
+    numbers per step, lambdapic_amd/laser.py `_factorise`) against the general path that evaluates the reference's
+    source-field formulas as device expressions every step (callback/laser.py:351-386,504-555 -> lpa_laser_inject_2d/3d):
+    the fields agree to 1e-12 of the pulse after it has entered the box; an obliquely incident plane-front pulse does not
+    factorise and silently takes the general path."""
+    from lambdapic_amd import laser as LZ
+    lam = 0.8e-6
+
+    def run(make, factorise):
+        if dim == 2:
+            sim = Simulation(96, 128, lam / 16, lam / 16, boundary_conditions=PML, cpml_thickness=6)
+        else:
+            from lambdapic_amd.simulation3d import Simulation3D
+            sim = Simulation3D(48, 32, 32, lam / 16, lam / 8, lam / 8, cpml_thickness=4)
+        las = make()
+        las.factorise = factorise
+        sim.run(int(5e-6 / C / sim.dt), callbacks=[las])
+        eng = sim.engine
+        view = (lambda a: eng.grid.view(a)) if dim == 2 else eng.view
+        return las, {a: view(a).clone() for a in ("ey", "ez", "by", "bz")}
+
+    G2, G3, S2, S3 = LZ.GaussianLaser2D, LZ.GaussianLaser3D, LZ.SimpleLaser2D, LZ.SimpleLaser3D
+    makers = [lambda: (G2 if dim == 2 else G3)(a0=2.0, l0=lam, w0=1.5e-6, ctau=1.5e-6, pol_angle=0.4, ellipticity=0.3,
+                                                cep=0.7, focus_position=3e-6),
+              lambda: (G2 if dim == 2 else G3)(a0=1.0, l0=lam, w0=2.0e-6, ctau=1.5e-6, l=1, p=1),
+              lambda: (S2 if dim == 2 else S3)(a0=0.5, w0=1.5e-6, ctau=1.5e-6, pol_angle=np.pi / 3, l0=lam)]
+    for make in makers:
+        la, fa = run(make, True)
+        lb, fb = run(make, False)
+        assert la._sep is not None and lb._sep is None
+        peak = max(float(fb[a].abs().max()) for a in ("ey", "ez"))
+        assert peak > 0.2 * la.E0
+        for a, unit in (("ey", 1.0), ("ez", 1.0), ("by", C), ("bz", C)):
+            assert float((fa[a] - fb[a]).abs().max()) * unit <= 1e-12 * peak, a
+    if dim == 2:
+        lo, _ = run(lambda: S2(a0=0.5, w0=1.5e-6, ctau=1.5e-6, angle_y=0.3, l0=lam), True)
+        assert lo._sep is None
