@@ -72,7 +72,12 @@ typedef struct {
     const int32_t *blk_end;    /* [max_blocks] one past the last particle                        */
     const int32_t *n_blocks;   /* [1] number of valid work blocks                                */
     int32_t tiles_z;           /* 3-D tilings (lpa_sort_tiles_3d): tiles along z; 0 for 2-D      */
-    int32_t reserved_;
+    int32_t prefix_hint;       /* IN, lpa_sort_tiles_*: the caller knows that the first prefix_hint slots of `src` are
+                                  what the previous sort through this workspace produced (its live count, read back
+                                  with lpa_sort_live_count; dead slots among them are fine) -- the per-particle kernels
+                                  of the re-sort then start behind them instead of launching a thread per slot that
+                                  returns at once.  0 = unknown.  A hint the workspace header does not confirm makes
+                                  the sort refuse (lpa_sort_overflow bit 2).  Reset to 0 on return.               */
     double *scratch[8];        /* optional (set by the caller, all or none): device arrays of at least n_sorted
                                   doubles each, e.g. the idle half of the ping-pong sort stores -- seven for a
                                   2-D tiling, eight for a 3-D one.  The tiled push kernels park the particles that

@@ -51,7 +51,7 @@ class lpa_tiling(C.Structure):
                 ("max_blocks", C.c_int32), ("order", C.c_int32),
                 ("tile_off", C.c_void_p), ("blk_tile", C.c_void_p), ("blk_begin", C.c_void_p),
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
-                ("tiles_z", C.c_int32), ("reserved_", C.c_int32), ("scratch", C.c_void_p * 8),
+                ("tiles_z", C.c_int32), ("prefix_hint", C.c_int32), ("scratch", C.c_void_p * 8),
                 ("pad_ranks", C.c_void_p), ("slot_class", C.c_void_p), ("aux_slot", C.c_void_p), ("aux_info", C.c_void_p),
                 ("reloc_stats", C.c_void_p), ("class_init", C.c_int32), ("reserved2_", C.c_int32)]
 
@@ -240,7 +240,10 @@ def sort_result(L, wsbuf):
     if ovf:
         raise LpaError("tile sort refused (nothing was moved): " +
                        ("the sorted order needs more slots than the destination holds -- a padded order stores up to "
-                        "4/3 n + 64 slots per tile" if ovf & 1 else "work-block table too small"))
+                        "4/3 n + 64 slots per tile" if ovf & 1 else
+                        "work-block table too small" if ovf & 2 else
+                        "lpa_tiling.prefix_hint is not confirmed by the workspace header (the source is not the previous "
+                        "sort's result)"))
     return hdr[(L.lpa_sort_live_count(ptr) - ptr) // 4]
 
 

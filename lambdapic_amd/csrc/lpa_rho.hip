@@ -51,9 +51,11 @@ __device__ __forceinline__ bool rho_axis(int c, int n, int ng, int N, int mode, 
 __global__ void __launch_bounds__(256) k_rho_continuity(GridV g, double dtdx, double dtdy, double dtdz, int mx, int my,
                                                         int mz, const double *__restrict__ left) {
     const bool d3 = g.NZ > 1;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;  // fastest axis
-    if (f >= (d3 ? g.NZ : g.NY)) return;
-    const int cx = d3 ? blockIdx.z : blockIdx.y, cy = d3 ? (int)blockIdx.y : f, cz = d3 ? f : 0;
+    // one x plane per blockIdx.y, its (y, z) nodes flattened over blockIdx.x (a 262-node z row per block would leave
+    // the second of its two 256-thread blocks with six lanes)
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= g.NY * g.NZ) return;
+    const int cx = blockIdx.y, cy = f / g.NZ, cz = f - cy * g.NZ;
     int px, py, pz = 0;
     if (!rho_axis(cx, g.nx, g.ng, g.NX, mx, px) || !rho_axis(cy, g.ny, g.ng, g.NY, my, py)) return;
     if (d3 && !rho_axis(cz, g.nz, g.ng, g.NZ, mz, pz)) return;
@@ -75,7 +77,7 @@ extern "C" int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axe
     GridV v = make_gridv(g, dim);
     const int mx = split_x ? ((split_x & 1 ? RHO_NB_LO : 0) | (split_x & 2 ? RHO_NB_HI : 0)) : (periodic_axes & 1),
               my = (periodic_axes >> 1) & 1, mz = (periodic_axes >> 2) & 1;
-    dim3 grid = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
+    dim3 grid((v.NY * v.NZ + 255) / 256, v.NX);
     hipLaunchKernelGGL(k_rho_continuity, grid, dim3(256), 0, (hipStream_t)stream, v, dt / g->dx, dt / g->dy,
                        dim == 3 ? dt / g->dz : 0.0, mx, my, mz, jx_left_plane);
     LPA_CHECK_LAUNCH("lpa_rho_continuity");

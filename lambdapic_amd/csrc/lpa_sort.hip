@@ -38,11 +38,12 @@ struct SortHdr {      // first 64 bytes of the workspace
     int32_t magic, prev_ntiles, prev_n, prev_valid;
     // set by k_tile_scan, read by the scatter kernels (which then move nothing) and by the caller after the sort:
     // bit 0 = the slots of the sorted order (live + the holes and 64-slot rounding of LPA_ORDER_PADDED) exceed the
-    // destination's capacity; bit 1 = more work blocks than the table holds
+    // destination's capacity; bit 1 = more work blocks than the table holds; bit 2 = the caller's prefix_hint exceeds
+    // the tile-ordered prefix this header vouches for
     int32_t overflow;
     int32_t pad[9];
 };
-constexpr int32_t SORT_OVF_SLOTS = 1, SORT_OVF_BLOCKS = 2;
+constexpr int32_t SORT_OVF_SLOTS = 1, SORT_OVF_BLOCKS = 2, SORT_BAD_HINT = 4;
 constexpr int32_t SORT_MAGIC = 0x4c504131;
 
 struct SortWs {
@@ -156,9 +157,10 @@ __device__ __forceinline__ uint32_t cell_key(const PartV &p, long ip, const KeyG
 
 // any particle order: key + rank by atomics on the global cell counters
 __global__ void __launch_bounds__(256) k_cell_count(PartV p, KeyGeom k, const SortHdr *hdr, int32_t *cell_cnt,
-                                                    uint32_t *key, uint32_t *rank) {
-    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (hdr->prev_valid && (long)(blockIdx.x + 1) * blockDim.x <= hdr->prev_n) return;  // block-uniform
+                                                    uint32_t *key, uint32_t *rank, long first_block) {
+    const long blk = first_block + blockIdx.x;     // (blocks below the caller's prefix_hint are not launched)
+    long ip = blk * blockDim.x + threadIdx.x;
+    if (hdr->prev_valid && (blk + 1) * blockDim.x <= hdr->prev_n) return;  // block-uniform
     bool mine = ip < p.n && !(hdr->prev_valid && ip < hdr->prev_n);   // the rest: k_cell_count_tiled
     uint32_t ck = mine ? cell_key(p, ip, k) : KEY_DEAD;
     uint32_t r = cell_rank(ck != KEY_DEAD, ck, cell_cnt);
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
         hdr->n_blocks = min(s_blk[1023], max_blocks);
         // a PADDED order stores up to 4/3 n + 63 slots per tile: it may not fit a destination sized for the live
         // count; nothing is scattered then (every slot beyond the capacity would be an out-of-bounds store)
-        hdr->overflow = ((long)s_part[1023] > dst_capacity ? SORT_OVF_SLOTS : 0) |
+        hdr->overflow = (hdr->overflow & SORT_BAD_HINT) | ((long)s_part[1023] > dst_capacity ? SORT_OVF_SLOTS : 0) |
                         (s_blk[1023] > max_blocks ? SORT_OVF_BLOCKS : 0);
     }
 }
@@ -383,8 +385,9 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
                                                  const int32_t *__restrict__ cell_off,
                                                  const unsigned long long *__restrict__ masks,
                                                  const int32_t *__restrict__ apre, int striped,
-                                                 const SortHdr *hdr, const int32_t *__restrict__ cell_cnt) {
-    long ip = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                 const SortHdr *hdr, const int32_t *__restrict__ cell_cnt,
+                                                 long first_block) {
+    long ip = (first_block + blockIdx.x) * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
     if (hdr->overflow) return;                         // the destination cannot hold the order: see SortHdr
     if (hdr->prev_valid && ip < hdr->prev_n) return;   // moved by k_scatter_tiled
@@ -417,12 +420,15 @@ struct AttrList {
 };
 
 __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile_off_prev, int ntiles,
-                            long src_n) {
+                            long src_n, long prefix_hint) {
     for (int t = threadIdx.x; t <= ntiles; t += blockDim.x) tile_off_prev[t] = tile_off[t];
     if (threadIdx.x == 0) {
         bool ok = hdr->magic == SORT_MAGIC && hdr->prev_ntiles == ntiles && hdr->n_live <= src_n;
         hdr->prev_valid = ok ? 1 : 0;
         hdr->prev_n = ok ? hdr->n_live : 0;
+        // the per-particle kernels were launched from slot prefix_hint on: everything below must be covered by the
+        // tile-ordered prefix, or those particles would be lost -- refuse instead (k_tile_scan keeps the bit)
+        hdr->overflow = prefix_hint > (ok ? (long)hdr->n_live : 0l) ? SORT_BAD_HINT : 0;
         hdr->magic = SORT_MAGIC;
         hdr->prev_ntiles = ntiles;
     }
@@ -562,8 +568,11 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         return LPA_ERR_HIP;
     }
     PartV sv = make_partv(src), dv = make_partv(dst);
+    const long hint = out->prefix_hint;
+    LPA_REQUIRE(hint >= 0 && hint <= src->n, "%s: prefix_hint outside the source", name);
+    const long first_block = hint / 256;       // per-particle kernels start here (see lpa_tiling.prefix_hint)
     hipLaunchKernelGGL(k_save_prev, dim3(1), dim3(1024), 0, st, w.hdr, w.tile_off, w.tile_off_prev, w.ntiles,
-                       (long)src->n);
+                       (long)src->n, hint);
     LPA_CHECK_LAUNCH("k_save_prev");
     if (src->n > 0) {
         KeyGeom kg;
@@ -575,9 +584,12 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         hipLaunchKernelGGL(k_cell_count_tiled, dim3(w.ntiles), dim3(512), 0, st, sv, kg, w.hdr, w.tile_off_prev,
                            w.cell_cnt, w.cell_base, w.key, w.rank);
         LPA_CHECK_LAUNCH("k_cell_count_tiled");
-        unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, sv, kg, w.hdr, w.cell_cnt, w.key, w.rank);
-        LPA_CHECK_LAUNCH("k_cell_count");
+        const long nb = (src->n + 255) / 256 - first_block;
+        if (nb > 0) {
+            hipLaunchKernelGGL(k_cell_count, dim3((unsigned)nb), dim3(256), 0, st, sv, kg, w.hdr, w.cell_cnt, w.key, w.rank,
+                               first_block);
+            LPA_CHECK_LAUNCH("k_cell_count");
+        }
     }
     const bool padded = order == LPA_ORDER_PADDED;
     if (padded) {
@@ -621,15 +633,17 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
                            w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
-        unsigned nb = (unsigned)((src->n + 255) / 256);
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
-                           w.cell_off, w.masks, w.apre, striped, w.hdr, w.cell_cnt);
-        LPA_CHECK_LAUNCH("k_scatter");
+        const long nb = (src->n + 255) / 256 - first_block;
+        if (nb > 0) {
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
+                               w.cell_off, w.masks, w.apre, striped, w.hdr, w.cell_cnt, first_block);
+            LPA_CHECK_LAUNCH("k_scatter");
+        }
     }
     out->tiles_x = tiles_x;
     out->tiles_y = tiles_y;
     out->tiles_z = tiles_z;
-    out->reserved_ = 0;
+    out->prefix_hint = 0;
     for (int c = 0; c < 8; c++) out->scratch[c] = nullptr;   // the caller may attach the idle store
     out->n_sorted = src->n;  // upper bound known on the host; the exact count is hdr->n_live
     out->max_blocks = w.max_blocks;

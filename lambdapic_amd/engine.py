@@ -433,6 +433,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # small stores: smaller work blocks, or a 2 M-particle species is 256 workgroups on 256 CUs (config C3: K1
         # 0.19 -> 0.15 ms per step with 4096, tools/exp_c3_blocks.py)
         bp = self.block_particles if sp.n >= (1 << 23) else min(self.block_particles, 4096)
+        # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
+        ws["tiling"].prefix_hint = int(sp.n_sorted) if sp.tiling is not None else 0
         check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), bp, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")

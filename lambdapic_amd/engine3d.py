@@ -359,6 +359,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         ws = self._ws(sp)
         cap = sp["data"].shape[1]
         src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
+        # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
+        ws["tiling"].prefix_hint = int(sp["n_sorted"]) if sp["tiling"] is not None else 0
         check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), self.block_particles, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")

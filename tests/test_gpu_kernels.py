@@ -602,3 +602,32 @@ def test_padded_sort_refuses_a_store_that_is_too_small():
     roomy.species[0].upload([p])
     roomy.sort(0)
     assert roomy.species[0].n_sorted >= n and roomy.diagnostics()["nalive"][0] == n
+
+
+def test_sort_refuses_a_prefix_hint_its_workspace_does_not_confirm():
+    """lpa_tiling.prefix_hint lets a re-sort skip the per-particle launches over the tile-ordered prefix; a hint the
+    workspace header does not vouch for (here: the header is wiped, as if the store had been replaced behind the
+    engine's back) would leave those particles unsorted -- the device refuses the whole sort instead"""
+    import torch
+    from lambdapic_amd import _lib
+    from lambdapic_amd.engine import PicEngine2D
+    rng = np.random.default_rng(2)
+    nx, ny, dx, dy, n = 16, 64, 4e-8, 4e-8, 20_000
+    p = ParticlesBase(0, 0)
+    p.initialize(n)
+    p.x[:] = rng.uniform(-0.5, nx - 0.5, n) * dx
+    p.y[:] = rng.uniform(-0.5, ny - 0.5, n) * dy
+    p.w[:] = 1.0
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", block_particles=1024)
+    eng.add_species(QE, ME, capacity=n + 64)
+    eng.species[0].upload([p])
+    eng.sort(0)
+    eng.sort(0)                                    # a confirmed hint: fine
+    assert eng.species[0].n_sorted == n
+    ws = eng._sort_ws(eng.species[0])
+    ws["sort"][:64].zero_()                        # the header forgets the previous sort ...
+    with pytest.raises(_lib.LpaError, match="prefix_hint"):
+        eng.sort(0)                                # ... the engine still hints n_sorted
+    eng.species[0].tiling = None                   # what an upload does: no hint, a first sort
+    eng.sort(0)
+    assert eng.species[0].n_sorted == n
