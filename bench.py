@@ -777,7 +777,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_push_deposit_tiled_2d", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
-                     "traffic_source": traffic_source},
+                     "traffic_source": traffic_source,
+                     # context, not the roofline: what a plain streaming kernel with K1's own access pattern reaches
+                     # (tools/ubench/stream_soa.hip, recorded in profiles/r03_k1_streams.txt; boxes: 5.1-6.1 TB/s)
+                     "counted_traffic_over_plain_stream_6070GBps":
+                         (traffic / (k_ms * 1e-3) / 1e9 / 6070.0) if (traffic and ev) else None},
     }
     if comm.size > 1 and not args.no_extra:
         # the configs BASELINE.json defines on several GPUs are FIXED-size problems: C2's 1024^2 box (north_star quotes
