@@ -392,6 +392,9 @@ int lpa_wrap_positions_3d(const lpa_particles *p, const lpa_push_params *pp, voi
  *      of live particles is written to the workspace header (lpa_sort_live_count).  `inv_gamma` may be NULL in
  *      BOTH stores (see LPA_PUSH_NO_IG): it is then not moved. */
 int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
+/* ranks per cell the striped orders of a workspace of this capacity keep in stripes (twice the mean occupancy at full
+ * capacity, a power of two in [32, 1024]); a cell's deeper particles follow cell by cell behind the stripes of its tile */
+int32_t lpa_sort_stripe_ranks(const lpa_grid *g, int64_t capacity);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
                       int32_t order, lpa_tiling *out, void *stream);

@@ -148,6 +148,7 @@ SIGNATURES = {
     "lpa_interpolate_3d": (_i, [_G, _P, _vp]),
     "lpa_deposit_3d": (_i, [_G, _P, _d, _d, _vp]),
     "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),
+    "lpa_sort_stripe_ranks": (C.c_int32, [_G, _i64]),
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),

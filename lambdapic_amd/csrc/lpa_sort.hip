@@ -27,7 +27,18 @@
 
 constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;
 constexpr int TCELLS = TX * TY;  // 256
-constexpr int RMAX = 128;        // ranks that are striped; deeper particles follow cell by cell
+// ranks that are striped (one 256-bit cell mask per tile and rank); deeper particles follow cell by cell, where all the
+// lanes of a wave sit in ONE cell and every LDS atomic of the tiled kernels is a 64-way conflict (K1 2-D at 256 particles
+// per cell with 128 striped ranks: 3.5 ms instead of 1.6).  Sized per workspace from the mean occupancy the store can
+// hold: twice the particles per cell at full capacity, as a power of two in [32, 1024] -- C2 (64 per cell): 256 ranks,
+// 34 MB of masks; a 3-D slab at 8 per cell: 32 ranks instead of 128.
+static int stripe_ranks(const lpa_grid *g, int64_t cap, int ntiles) {
+    (void)g;
+    const int64_t per_cell = (cap + (int64_t)ntiles * 256 - 1) / ((int64_t)ntiles * 256);
+    int r = 32;
+    while (r < 2 * per_cell && r < 1024) r *= 2;
+    return r;
+}
 static_assert(TCELLS == 256, "one workgroup thread per tile cell");
 
 struct SortHdr {      // first 64 bytes of the workspace
@@ -52,7 +63,7 @@ struct SortWs {
     int32_t *pad_ranks;
     unsigned long long *masks;
     uint32_t *key, *rank;
-    int ntiles, max_blocks;
+    int rmax, ntiles, max_blocks;
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -69,6 +80,7 @@ static int tile_count(const lpa_grid *g) {
 
 static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
     int nt = tile_count(g);
+    const int RMAX = stripe_ranks(g, cap, nt);
     // + 8: the tiled kernels launch max_blocks workgroups and deal work blocks to them in XCD order
     int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1 + 8;
     size_t off = 0;
@@ -89,7 +101,7 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     p = take(sizeof(int32_t) * (size_t)nt * (RMAX + 1)); if (w) w->apre = (int32_t *)p;
     p = take(sizeof(uint32_t) * cap); if (w) w->key = (uint32_t *)p;
     p = take(sizeof(uint32_t) * cap); if (w) w->rank = (uint32_t *)p;
-    if (w) { w->ntiles = nt; w->max_blocks = (int)maxb; }
+    if (w) { w->ntiles = nt; w->max_blocks = (int)maxb; w->rmax = RMAX; }
     return (int64_t)off;
 }
 
@@ -97,6 +109,11 @@ extern "C" int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity)
     if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;  // nz > 1 selects the 3-D tiles
     // sized for the smallest block size accepted by lpa_sort_tiles_2d
     return ws_layout(g, capacity, 1024, nullptr, nullptr);
+}
+
+extern "C" int32_t lpa_sort_stripe_ranks(const lpa_grid *g, int64_t capacity) {
+    if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;
+    return stripe_ranks(g, capacity, tile_count(g));
 }
 
 extern "C" const int32_t *lpa_sort_live_count(void *workspace) {
@@ -301,7 +318,7 @@ __global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ c
 __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict__ cell_cnt,
                                                       unsigned long long *masks, int32_t *apre,
                                                       int32_t *cell_off, int pad_min, int32_t *tile_cnt_out,
-                                                      int32_t *pad_ranks) {
+                                                      int32_t *pad_ranks, const int RMAX) {
     __shared__ unsigned long long s_mask[4];
     const int c = threadIdx.x, lane = c & 63, wv = c >> 6;
     const long t = blockIdx.x;
@@ -357,7 +374,7 @@ __device__ __forceinline__ long dest_slot(uint32_t ck, uint32_t r, int striped,
                                           const int32_t *__restrict__ tile_off,
                                           const int32_t *__restrict__ cell_off,
                                           const unsigned long long *__restrict__ masks,
-                                          const int32_t *__restrict__ apre,
+                                          const int32_t *__restrict__ apre, const int RMAX,
                                           const int32_t *__restrict__ cell_cnt = nullptr) {
     if (r & RANK_LOCAL) r = (r & ~RANK_LOCAL) + (uint32_t)cell_base[ck];
     if (!striped) return (long)cell_off[ck] + r;
@@ -386,14 +403,14 @@ __global__ void __launch_bounds__(256) k_scatter(PartV s, PartV d, const uint32_
                                                  const unsigned long long *__restrict__ masks,
                                                  const int32_t *__restrict__ apre, int striped,
                                                  const SortHdr *hdr, const int32_t *__restrict__ cell_cnt,
-                                                 long first_block) {
+                                                 long first_block, int rmax) {
     long ip = (first_block + blockIdx.x) * blockDim.x + threadIdx.x;
     if (ip >= s.n) return;
     if (hdr->overflow) return;                         // the destination cannot hold the order: see SortHdr
     if (hdr->prev_valid && ip < hdr->prev_n) return;   // moved by k_scatter_tiled
     uint32_t ck = key[ip];
     if (ck == KEY_DEAD) return;
-    const long o = dest_slot(ck, rank[ip], striped, nullptr, tile_off, cell_off, masks, apre, cell_cnt);
+    const long o = dest_slot(ck, rank[ip], striped, nullptr, tile_off, cell_off, masks, apre, rmax, cell_cnt);
     d.x[o] = s.x[ip]; d.y[o] = s.y[ip];
     if (s.z && d.z) d.z[o] = s.z[ip];
     d.ux[o] = s.ux[ip]; d.uy[o] = s.uy[ip]; d.uz[o] = s.uz[ip];
@@ -453,7 +470,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ cell_base,
     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ cell_off,
     const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped,
-    const int32_t *__restrict__ cell_cnt) {
+    const int32_t *__restrict__ cell_cnt, int rmax) {
     __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
     if (!hdr->prev_valid || hdr->overflow) return;
@@ -468,7 +485,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
             dest[j] = -1;
             if (ip < se) {
                 uint32_t ck = key[ip];
-                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre, cell_cnt);
+                if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre, rmax, cell_cnt);
             }
         }
         // (a tile with more than ST_BITS particles is covered in several passes)
@@ -596,7 +613,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         // the padded tile totals come out of the stripe tables: tables first, then the scan; the destination's
         // positions start as NaN, so every slot the scatter does not fill is a hole
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre, w.cell_off,
-                           LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks);
+                           LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks, w.rmax);
         LPA_CHECK_LAUNCH("k_stripe_table (padded)");
         if (hipMemsetAsync(dv.x, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
             hipMemsetAsync(dv.y, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
@@ -613,7 +630,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     LPA_CHECK_LAUNCH("k_tile_scan");
     if (order == LPA_ORDER_STRIPED)
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre,
-                           w.cell_off, 0, (int32_t *)nullptr, w.pad_ranks);
+                           w.cell_off, 0, (int32_t *)nullptr, w.pad_ranks, w.rmax);
     else if (!padded)
         hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
     LPA_CHECK_LAUNCH("k_cell_scan / k_stripe_table");
@@ -631,12 +648,12 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
                                                       : (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
         hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
-                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt);
+                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt, w.rmax);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
         const long nb = (src->n + 255) / 256 - first_block;
         if (nb > 0) {
             hipLaunchKernelGGL(k_scatter, dim3((unsigned)nb), dim3(256), 0, st, sv, dv, w.key, w.rank, w.tile_off,
-                               w.cell_off, w.masks, w.apre, striped, w.hdr, w.cell_cnt, first_block);
+                               w.cell_off, w.masks, w.apre, striped, w.hdr, w.cell_cnt, first_block, w.rmax);
             LPA_CHECK_LAUNCH("k_scatter");
         }
     }

@@ -283,17 +283,18 @@ def test_wave_reduce_scatter_selftest():
     np.testing.assert_allclose(d_out.cpu().numpy(), a.sum(axis=1), rtol=1e-13, atol=1e-13)
 
 
-def _expected_tile_sequence(cnt, order):
-    """the cell sequence of one tile's particles for a striped order, from its 256 cell counts"""
+def _expected_tile_sequence(cnt, order, rmax=128):
+    """the cell sequence of one tile's particles for a striped order, from its 256 cell counts (``rmax``: the ranks the
+    workspace keeps in stripes, lpa_sort_stripe_ranks)"""
     if order == 3:     # LPA_ORDER_COLUMN: rank by rank inside each 32-cell row of the 2-D tile, row after row
         exp = []
         for c0 in range(0, 256, 32):
             col = cnt[c0:c0 + 32]
             exp += [c0 + np.nonzero(col > r)[0] for r in range(col.max())]
         return np.concatenate(exp) if exp else np.zeros(0, int)
-    # for r < 128 the cells with count > r ascending, then the deep tails
-    exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), 128))]
-    exp += [np.repeat(c, cnt[c] - 128) for c in np.nonzero(cnt > 128)[0]]
+    # for r < rmax the cells with count > r ascending, then the deep tails
+    exp = [np.nonzero(cnt > r)[0] for r in range(min(cnt.max(), rmax))]
+    exp += [np.repeat(c, cnt[c] - rmax) for c in np.nonzero(cnt > rmax)[0]]
     return np.concatenate(exp)
 
 
@@ -326,6 +327,8 @@ def test_cell_sort_properties(order):
     eng.species[0].upload([p])
     assert eng.species[0].n == live.sum()
     eng.sort(0)
+    rmax = int(eng.L.lpa_sort_stripe_ranks(eng._g(), eng.species[0].capacity))
+    assert 32 <= rmax < 2000 // 3           # the deep cells below (667 particles each) do leave the stripes
     out = eng.species[0].download()
     assert out["x"].size == live.sum()
     tiles_y = (ny + 31) // 32
@@ -345,7 +348,7 @@ def test_cell_sort_properties(order):
         for t in np.unique(tile):
             kt = k_out[tile == t] & 255
             cnt = np.bincount(kt, minlength=256)
-            assert np.array_equal(kt, _expected_tile_sequence(cnt, order)), t
+            assert np.array_equal(kt, _expected_tile_sequence(cnt, order, rmax)), t
     order_in = np.argsort(p.id[live])
     order_out = np.argsort(out["_id"].view(np.uint64))
     assert np.array_equal(p.id[live][order_in], out["_id"].view(np.uint64)[order_out])
@@ -378,7 +381,7 @@ def test_cell_sort_properties(order):
         for t in np.unique(t3):
             kt = k3[t3 == t] & 255
             cnt = np.bincount(kt, minlength=256)
-            assert np.array_equal(kt, _expected_tile_sequence(cnt, order)), t
+            assert np.array_equal(kt, _expected_tile_sequence(cnt, order, rmax)), t
     ib, ia = np.argsort(before["_id"].view(np.uint64)), np.argsort(out3["_id"].view(np.uint64))
     assert np.array_equal(before["_id"].view(np.uint64)[ib], out3["_id"].view(np.uint64)[ia])
     for a in ("x", "y", "ux", "w"):
