@@ -46,7 +46,7 @@ def build_engine(args, comm, device, nx=None):
     q, m = -constants.E_CHARGE, constants.M_E
     omega = 2 * np.pi * C_LIGHT / LAMBDA0
     n_c = constants.EPSILON_0 * m * omega ** 2 / q ** 2     # tests/test_numerical_heating.py:16,86
-    u_th = 0.0442                                           # 1 keV electrons
+    u_th = getattr(args, "uth", 0.0442)                     # 1 keV electrons (C2); --uth: off-benchmark sweeps
     n = nx * ny * ppc
     from lambdapic_amd import _lib
     padded = getattr(args, "order", "striped") == "padded"
@@ -658,6 +658,8 @@ def main():
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
+    ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (C2: 0.0442 = 1 keV); "
+                                                              "other values: off-benchmark sweeps (tools/sweep_uth2d.sh)")
     ap.add_argument("--inv-gamma", default="recomputed", choices=["recomputed", "streamed"],
                     help="1 / gamma of a particle: recomputed from its momenta by the fused kernels (default; two of the "
                          "thirteen attribute streams go) or loaded and stored like the reference's kernel")

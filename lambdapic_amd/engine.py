@@ -186,6 +186,16 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # thirteen attribute streams of a particle-update; LPA_PUSH_NO_IG) and the array is rebuilt on demand
         # (DeviceParticles.refresh_inv_gamma: download, diagnostics, the split kernels, a checkpoint)
         self.lazy_inv_gamma = True
+        # The tiled kernels hand the particles that have left their tile's staged region since the sort to the overflow
+        # list: pushed one by one on global memory at ~30 x the cost of a tiled particle, their number growing two- to
+        # three-fold per step once it starts.  ``sort_interval`` (tuned for a 1 keV plasma) is therefore only the LONGEST
+        # interval: every sort looks at the overflow count of the push before it (already on the host with the sort's
+        # own read-back: no extra sync, nothing per step) and shortens the species' interval when more than
+        # ``overflow_sort_fraction`` of it was on the list, lengthens it again when (almost) nobody was.  A hot plasma
+        # (u_th >= 0.2) runs at 2.8-4 ms per step instead of 7.5-26 (profiles/r03_sweep_hot2d.txt).  Single slab only: on a
+        # slab chain every rank must sort -- and re-anchor rho -- in the same steps.  0 = fixed interval
+        self.overflow_sort_fraction = 0.003
+        self.min_sort_interval = 2
         self.reseat_stats = False  # diagnostics: count parked particles / movers / unmatched movers (ws["reloc_stats"])
         self.fused_cpml = True
         self._axes = {}
@@ -203,7 +213,42 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         return self.order == _lib.LPA_ORDER_STRIPED and not self.reseat
 
     def _rho_sort_due(self):
-        return any(sp.tiling is None or sp.steps_since_sort >= self.sort_interval for sp in self.species if sp.n)
+        return any(self.sort_due(sp) for sp in self.species if sp.n)
+
+    def sort_due(self, sp):
+        """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
+        a species whose last intervals ended with a long overflow list (``_adapt_sort_interval``)"""
+        return sp.tiling is None or sp.steps_since_sort >= min(self.sort_interval, getattr(sp, "sort_interval_now", 1 << 30))
+
+    def _first_sort_interval(self, sp, cset, comps, d, margin):
+        """a store is sorted for the first time: start its interval where 2.5-sigma particles would outrun the tile margin
+        (one reduction over the momenta; a 1 keV plasma gets the full ``sort_interval``), the controller takes it from
+        there"""
+        dt = getattr(self, "_dt_hint", None)
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or sp.n == 0:
+            return
+        u = [cset.arr(a)[: sp.n] for a in ("ux", "uy", "uz")]
+        live = ~torch.isnan(cset.arr("x")[: sp.n])
+        v2 = [torch.where(live, c * c / (1 + u[0] ** 2 + u[1] ** 2 + u[2] ** 2), torch.zeros_like(c)) for c in u[: len(comps)]]
+        nl = max(int(live.sum().item()), 1)
+        cells = max(float(torch.sqrt(w.sum() / nl).item()) * constants.C_LIGHT * dt / dd for w, dd in zip(v2, d))
+        est = int(margin / max(2.5 * cells, 1e-12))
+        sp.sort_interval_now = max(self.min_sort_interval, min(self.sort_interval, est))
+
+    def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
+        """called by sort() with the overflow count of the last push of the interval that just ended"""
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 \
+                or sp.steps_since_sort > self.sort_interval:          # (forced sorts of stale stores tell nothing)
+            return
+        now = min(getattr(sp, "sort_interval_now", self.sort_interval), self.sort_interval)
+        f = overflow / n_sorted_before
+        if f > self.overflow_sort_fraction:
+            # (measured on a u_th = 0.2 plasma: 0.27 % on the list after 9 steps, 8.5 % after 20: ~1.4-fold per step that far out)
+            cut = 1 + int(np.log(f / self.overflow_sort_fraction) / np.log(1.4))
+            now = max(self.min_sort_interval, min(now, sp.steps_since_sort) - cut)
+        elif f < 0.1 * self.overflow_sort_fraction:
+            now = min(self.sort_interval, now + 1)
+        sp.sort_interval_now = now
 
     def _rho_particle_slots(self):
         return sum(sp.capacity for sp in self.species)
@@ -441,6 +486,10 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         n_live = _lib.sort_result(self.L, ws["sort"])    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]
+        if sp.tiling is not None:
+            self._adapt_sort_interval(sp, cnts[0], sp.n_sorted)      # cnts[0]: the overflow list of the last push
+        else:
+            self._first_sort_interval(sp, src, ("ux", "uy"), (self.dx, self.dy), _lib.LPA_TILE_MARGIN)
         if arrivals > ws["area"]:
             raise _lib.LpaError(f"arrival area overflow: {arrivals} > {ws['area']} (raise migrate_capacity)")
         if surplus > 0:
@@ -885,8 +934,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         return self.grid.c
 
     def sort_due_species(self):
-        return [i for i, sp in enumerate(self.species)
-                if sp.tiling is None or sp.steps_since_sort >= self.sort_interval]
+        return [i for i, sp in enumerate(self.species) if self.sort_due(sp)]
 
     def _species_entries(self, dt):
         for sp in self.species:
@@ -908,6 +956,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
     def step(self, dt, tiled=True):
+        self._dt_hint = dt
         if tiled and self.can_fuse():
             self.step_fused(dt)
             return
@@ -918,7 +967,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self.sync_guard_fields(B)
         if tiled:
             for i, sp in enumerate(self.species):
-                if sp.tiling is None or sp.steps_since_sort >= self.sort_interval:
+                if self.sort_due(sp):
                     self.sort(i)
         self.reset_current()
         if tiled and self.overlap and self.push_deposit_overlapped(dt):

@@ -187,6 +187,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
+        self.overflow_sort_fraction = 0.003    # shorten a species' sort interval when its intervals end with more than
+        self.min_sort_interval = 2             # this fraction on the overflow list (PicEngine2D; single slab only)
         self.defer_crossers = True   # cell-crossers deposit in a dense second pass of the tiled kernel
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
@@ -203,7 +205,42 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         return self.tiled
 
     def _rho_sort_due(self):
-        return any(sp["tiling"] is None or sp["since"] >= self.sort_interval for sp in self.species)
+        return any(self.sort_due(sp) for sp in self.species)
+
+    def sort_due(self, sp):
+        """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
+        a species whose last intervals ended with a long overflow list (see PicEngine2D.overflow_sort_fraction)"""
+        return sp["tiling"] is None or sp["since"] >= min(self.sort_interval, sp.get("sort_interval_now", 1 << 30))
+
+    def _first_sort_interval(self, sp):
+        """see PicEngine2D._first_sort_interval (3-D tiles keep a margin of ONE cell)"""
+        dt = getattr(self, "_dt_hint", None)
+        n = sp["n"]
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or n == 0:
+            return
+        dta = sp["data"]
+        u = [dta[k, :n] for k in (3, 4, 5)]
+        live = ~torch.isnan(dta[0, :n])
+        g2 = 1 + u[0] ** 2 + u[1] ** 2 + u[2] ** 2
+        nl = max(int(live.sum().item()), 1)
+        cells = max(float(torch.sqrt(torch.where(live, c * c / g2, torch.zeros_like(c)).sum() / nl).item())
+                    * constants.C_LIGHT * dt / dd for c, dd in zip(u, self.d))
+        est = int(_lib.LPA_TILE3_MARGIN / max(2.5 * cells, 1e-12))
+        sp["sort_interval_now"] = max(self.min_sort_interval, min(self.sort_interval, est))
+
+    def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
+        """called by sort() with the overflow count of the last push of the interval that just ended"""
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 or sp["since"] > self.sort_interval:
+            return
+        now = min(sp.get("sort_interval_now", self.sort_interval), self.sort_interval)
+        f = overflow / n_sorted_before
+        if f > self.overflow_sort_fraction:
+            cut = 1 + int(np.log(f / self.overflow_sort_fraction) / np.log(1.4))
+            now = max(self.min_sort_interval, min(now, sp["since"]) - cut)
+        elif f < 0.1 * self.overflow_sort_fraction:
+            now = min(self.sort_interval, now + 1)
+        sp["sort_interval_now"] = now
+
 
     def _rho_particle_slots(self):
         return sum(int(sp["data"].shape[1]) for sp in self.species)
@@ -367,6 +404,10 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         n_live = _lib.sort_result(self.L, ws["sort"])
         area = self.arrival_area()
         cnts = ws["counters"].tolist()
+        if sp["tiling"] is not None:
+            self._adapt_sort_interval(sp, cnts[0], sp["n_sorted"])   # cnts[0]: the overflow list of the last push
+        else:
+            self._first_sort_interval(sp)
         if cnts[1] > area:
             raise _lib.LpaError("arrival area overflow (raise migrate_capacity)")
         if cnts[3] > 0:
@@ -728,13 +769,13 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         deposit into the x guard planes), LPA_PART_INTERIOR = the remaining tiles (+ their overflow)"""
         L, st, g, sp = self.L, self.stream, self._g(), self.species[i]
         pp = self._push_params(sp, dt)
-        if self._no_rho and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
+        if self._no_rho and self.sort_due(sp):
             raise _lib.LpaError("a store needs sorting inside a continuity step: call reset_current() first")
         self._push_flags(pp, dt, self.absorb)
         if not self.tiled:
             check(L.lpa_push_deposit_3d(g, C.byref(sp["c"]), C.byref(pp), 0, sp["n"], st), "lpa_push_deposit_3d")
             return
-        if part != _lib.LPA_PART_INTERIOR and (sp["tiling"] is None or sp["since"] >= self.sort_interval):
+        if part != _lib.LPA_PART_INTERIOR and self.sort_due(sp):
             self.sort(i)
         ws = sp["ws"]
         # the edge part may run on a second stream beside the interior part: own overflow list + counter
@@ -782,7 +823,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             self._side = torch.cuda.Stream(device=self.device, priority=-1)
         for i in range(len(self.species)):      # a sort that is due runs here, before the two parts split
             sp = self.species[i]
-            if sp["tiling"] is None or sp["since"] >= self.sort_interval:
+            if self.sort_due(sp):
                 self.sort(i)
         ready, done = torch.cuda.Event(), torch.cuda.Event()
         ready.record(main)
@@ -813,7 +854,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def sort_due_species(self):
         if not self.tiled:
             return []
-        return [i for i, sp in enumerate(self.species) if sp["tiling"] is None or sp["since"] >= self.sort_interval]
+        return [i for i, sp in enumerate(self.species) if self.sort_due(sp)]
 
     def _push_params(self, sp, dt):
         pp = _lib.lpa_push_params()
@@ -838,6 +879,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def step(self, dt, laser=None):
         """``laser``: optional callable ``laser(engine, dt)`` run at the reference's '_laser' stage
         (between the second B half step and its guard sync, simulation.py:1098-1112)"""
+        self._dt_hint = dt
         if self.can_fuse():
             self.step_fused(dt, laser)
             return

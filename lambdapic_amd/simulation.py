@@ -173,7 +173,7 @@ class ParticleSort2D(_Facade):
         if not self._enabled:
             return 0
         sp = self.sim.engine.species[self.ispec]
-        if force or sp.tiling is None or sp.steps_since_sort >= self.sim.engine.sort_interval:
+        if force or self.sim.engine.sort_due(sp):
             self.sim.engine.sort(self.ispec)
             self.nbuf_last = sp.n_sorted
         else:

@@ -64,7 +64,7 @@ class ParticleSort3D(_Facade):
     def __call__(self, force=False):
         eng = self.sim.engine
         sp = eng.species[self.ispec]
-        if self._enabled and eng.tiled and (force or sp["tiling"] is None or sp["since"] >= eng.sort_interval):
+        if self._enabled and eng.tiled and (force or eng.sort_due(sp)):
             eng.sort(self.ispec)
 
 

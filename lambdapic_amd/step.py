@@ -37,6 +37,7 @@ class FusedStepMixin:
         when LPA_STAGE_RESET is part of the range and closed when LPA_STAGE_FOLD is."""
         if not self.can_fuse():
             raise _lib.LpaError("lpa_step drives a single slab (and the fused CPML sweeps)")
+        self._dt_hint = dt        # (the first sort of a store sizes its sort interval from the particles' speed)
         d = _lib.lpa_step_desc()
         d.grid = self._grid_struct()
         d.dim, d.local_axes, d.dt, d.eps0 = self.dim, self.local_axes, dt, self.eps0

@@ -232,6 +232,7 @@ def test_rho_from_continuity_matches_deposited_rho(bc):
         eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", sort_interval=6, block_particles=1024,
                           boundary_conditions=bcs, cpml_thickness=4)
         eng.rho_continuity = cont
+        eng.overflow_sort_fraction = 0       # the fixed sort schedule (the step counts asserted below); these electrons are hot
         rng = np.random.default_rng(9)
         for k, (q, m, ppc, uth) in enumerate(((qe, me, 12, 0.4), (-qe, 1836 * me, 6, 0.002))):
             p = block(rng, ppc, uth)
@@ -321,3 +322,54 @@ def test_lazy_inv_gamma_matches_the_stored_one(bc):
             assert (va - vb).abs().max().item() <= 1e-12 * max(vb.abs().max().item(), 1e-300), (it, name)
     ka, kb = a.diagnostics(), b.diagnostics()
     assert ka["nalive"] == kb["nalive"] and ka["kinetic"][0] == pytest.approx(kb["kinetic"][0], rel=1e-14)
+
+
+# ---- the sort interval follows the overflow list ---------------------------------------------------------------------------
+def test_sort_interval_follows_the_overflow_list():
+    """``sort_interval`` is the LONGEST interval: the first sort of a store starts the species where 2.5-sigma particles
+    would outrun the tile margin, and every later sort shortens / lengthens it by what the push before it had to send to
+    the overflow list (PicEngine2D.overflow_sort_fraction; nothing is read between sorts).  A hot plasma ends up sorting
+    every few steps, a 1 keV one keeps the full interval -- and WHEN a store is sorted changes nothing physical: the hot
+    run equals the same run on the fixed interval to the order of the deposit's atomics."""
+    from lambdapic_amd.particles import ParticlesBase
+    nx = ny = 96
+    dx = dy = 4e-8
+    c = 299792458.0
+    dt = 0.95 / (c * np.sqrt(dx ** -2 + dy ** -2))
+
+    def run(uth, fraction, steps):
+        rng = np.random.default_rng(12)
+        ppc = 16
+        n = nx * ny * ppc
+        p = ParticlesBase(0, 0)
+        p.initialize(n)
+        cells = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij"), -1).reshape(-1, 2)
+        p.x[:], p.y[:] = ((np.repeat(cells, ppc, axis=0) + rng.uniform(-0.5, 0.5, (n, 2))) * dx).T
+        for a in ("ux", "uy", "uz"):
+            getattr(p, a)[:] = rng.normal(size=n) * uth
+        p.inv_gamma[:] = 1 / np.sqrt(1 + p.ux ** 2 + p.uy ** 2 + p.uz ** 2)
+        p.w[:] = 1e26 * dx * dy / ppc
+        eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", sort_interval=20, block_particles=1024)
+        eng.overflow_sort_fraction = fraction
+        eng.add_species(-oracle.E_CHARGE, oracle.M_E, capacity=2 * n)
+        eng.species[0].upload([p])
+        sorts = []
+        orig = eng.sort
+        eng.sort = lambda i: (sorts.append(eng.species[i].steps_since_sort), orig(i))[1]
+        for _ in range(steps):
+            eng.step(dt)
+        return eng, sorts
+
+    cold, s_cold = run(0.0442, 0.003, 45)
+    assert cold.species[0].sort_interval_now == 20 and s_cold[1:] == [20, 20]
+    hot, s_hot = run(0.6, 0.003, 45)
+    assert hot.species[0].sort_interval_now <= 6 and max(s_hot[1:]) <= 8 and len(s_hot) >= 8
+    ws = hot._sort_ws(hot.species[0])
+    assert int(ws["counters"][0].item()) <= 0.02 * hot.species[0].n_sorted       # the list stays short
+    fixed, s_fixed = run(0.6, 0.0, 45)
+    assert s_fixed[1:] == [20, 20]
+    for name in ("ex", "ey", "bz", "jx", "jy", "jz", "rho"):
+        a, b = hot.grid.view(name), fixed.grid.view(name)
+        assert (a - b).abs().max().item() <= 1e-10 * b.abs().max().item(), name
+    dh, df = hot.diagnostics(), fixed.diagnostics()
+    assert dh["nalive"] == df["nalive"] and dh["kinetic"][0] == pytest.approx(df["kinetic"][0], rel=1e-12)

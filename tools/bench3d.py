@@ -22,6 +22,7 @@ ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited
                 help="rho between two sorts: from the continuity equation (default) or deposited in every step")
 ap.add_argument("--no-fuse", action="store_true", help="per-species launches (lpa_push_deposit_tiled_3d) instead of the "
                                                        "one-launch form (lpa_push_deposit_tiled_multi_3d)")
+ap.add_argument("--fixed-sort", action="store_true", help="no early sorts on overflow growth (overflow_sort_fraction = 0)")
 ap.add_argument("--species", type=int, default=1, help="split the particles over this many species (same q / m)")
 a = ap.parse_args()
 lam = 0.8e-6
@@ -31,6 +32,8 @@ eng = PicEngine3D(a.nx, a.ny, a.nz, dx, dy, dz, 3, tiled=not a.glob, sort_interv
                   block_particles=a.block_particles)
 eng.rho_continuity = a.rho == "continuity"
 eng.fuse_species = not a.no_fuse
+if a.fixed_sort:
+    eng.overflow_sort_fraction = 0
 n = a.nx * a.ny * a.nz * a.ppc
 if a.order == "padded":
     eng.order = _lib.LPA_ORDER_PADDED
