@@ -151,17 +151,19 @@ class RhoContinuityMixin:
     def _finish_rho(self):
         """after the currents were folded: rho^{n+1} = rho^n - dt div J on a continuity step"""
         phase, self._phase = self._phase, "idle"
-        if phase != "continuity" or self._dt_step <= 0.0:     # (no push ran: J = 0, rho stays)
-            return
         left = None
-        if self.comm.size > 1:
-            # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step
+        if self.comm.size > 1 and self.rho_continuity and self._rho_available():
+            # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step.  Sent in
+            # EVERY step, whatever this rank's own phase (and whether it pushed anything): the ranks decide their real-
+            # deposit steps -- their sorts -- independently, and the neighbour may be in a continuity step
             send = self._rho_last_jx_plane().reshape(-1)
             if self._jx_plane is None:
                 self._jx_plane = torch.zeros_like(send)
                 self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
             self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
             left = self._jx_plane if self.comm.has_left else None
+        if phase != "continuity" or self._dt_step <= 0.0:     # (no push ran: J = 0, rho stays)
+            return
         split = ((1 if self.comm.has_left else 0) | (2 if self.comm.has_right else 0)) if self.comm.size > 1 else 0
         check(self.L.lpa_rho_continuity(self._g(), self._dt_step, self.local_axes, split,
                                         left.data_ptr() if left is not None else None, self.stream),

@@ -42,6 +42,7 @@ def _run(reuse, nsteps=18, cap=8192):
     eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", comm=_Mirror(nx * dx, cap), sort_interval=9,
                       block_particles=2048, migrate_capacity=cap)
     eng.reuse_slots = reuse
+    eng.overflow_sort_fraction = 0      # the fixed sort schedule: the test watches the arrival area fill up over an interval
     n = nx * ny * ppc
     q, m = -constants.E_CHARGE, constants.M_E
     eng.add_species(q, m, capacity=2 * n)
