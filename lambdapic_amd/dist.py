@@ -156,6 +156,15 @@ class SlabComm:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def any(self, flag: bool) -> bool:
+        """logical OR over the ranks (one small all-reduce; every rank must call it in the same step)"""
+        if self.size == 1:
+            return bool(flag)
+        on_host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64,
+                         device="cpu" if on_host else torch.cuda.current_device())
+        return float(self.allreduce_sum(t)[0]) > 0.0
+
     def reduce_diagnostics(self, d: dict) -> dict:
         """sum a diagnostics() dict (floats, ints and lists of them) over the ranks: one all-reduce"""
         if self.size == 1:

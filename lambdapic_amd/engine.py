@@ -192,9 +192,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # interval: every sort looks at the overflow count of the push before it (already on the host with the sort's
         # own read-back: no extra sync, nothing per step) and shortens the species' interval when more than
         # ``overflow_sort_fraction`` of it was on the list, lengthens it again when (almost) nobody was.  A hot plasma
-        # (u_th >= 0.2) runs at 2.8-4 ms per step instead of 7.5-26 (profiles/r03_sweep_hot2d.txt).  On a slab chain every
-        # rank follows its own particles (a sort is local; the one exchange that depended on the ranks' rho phases, the jx
-        # plane of the continuity update, is sent in every step: rho.py).  0 = fixed interval
+        # (u_th >= 0.2) runs at 2.8-4 ms per step instead of 7.5-26 (profiles/r03_sweep_hot2d.txt).  Single slab only: on a
+        # slab chain neighbouring slabs must sort -- and re-deposit rho -- in the same steps (sort_due: one clock for all
+        # ranks).  0 = fixed interval
         self.overflow_sort_fraction = 0.003
         self.min_sort_interval = 2
         self.reseat_stats = False  # diagnostics: count parked particles / movers / unmatched movers (ws["reloc_stats"])
@@ -214,11 +214,17 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         return self.order == _lib.LPA_ORDER_STRIPED and not self.reseat
 
     def _rho_sort_due(self):
-        return any(self.sort_due(sp) for sp in self.species if sp.n)
+        return any(self.sort_due(sp) for sp in self.species if sp.n or self.comm.size > 1)
 
     def sort_due(self, sp):
         """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
         a species whose last intervals ended with a long overflow list (``_adapt_sort_interval``)"""
+        if self.comm.size > 1:
+            # slab chain: ONE clock for all ranks and species (rho.py: neighbouring slabs must re-deposit rho in the same
+            # steps, and a sort step is such a step), whatever a rank's own stores look like -- a slab that was empty
+            # pushes its first arrivals with the global kernel until the common sort -- plus the forced re-sorts, which
+            # every rank is told at once (window shifts, uploads)
+            return self._chain_clock >= self.sort_interval or sp.steps_since_sort >= (1 << 29)
         return sp.tiling is None or sp.steps_since_sort >= min(self.sort_interval, getattr(sp, "sort_interval_now", 1 << 30))
 
     def _first_sort_interval(self, sp, cset, comps, d, margin):
@@ -226,7 +232,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         (one reduction over the momenta; a 1 keV plasma gets the full ``sort_interval``), the controller takes it from
         there"""
         dt = getattr(self, "_dt_hint", None)
-        if self.overflow_sort_fraction <= 0 or not dt or sp.n == 0:
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or sp.n == 0:
             return
         u = [cset.arr(a)[: sp.n] for a in ("ux", "uy", "uz")]
         live = ~torch.isnan(cset.arr("x")[: sp.n])
@@ -238,7 +244,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
         """called by sort() with the overflow count of the last push of the interval that just ended"""
-        if self.overflow_sort_fraction <= 0 or n_sorted_before <= 0 \
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 \
                 or sp.steps_since_sort > self.sort_interval:          # (forced sorts of stale stores tell nothing)
             return
         now = min(getattr(sp, "sort_interval_now", self.sort_interval), self.sort_interval)

@@ -188,7 +188,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
         self.overlap = True
         self.overflow_sort_fraction = 0.003    # shorten a species' sort interval when its intervals end with more than
-        self.min_sort_interval = 2             # this fraction on the overflow list (see PicEngine2D)
+        self.min_sort_interval = 2             # this fraction on the overflow list (see PicEngine2D; single slab only)
         self.defer_crossers = True   # cell-crossers deposit in a dense second pass of the tiled kernel
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.fused_cpml = True
@@ -205,18 +205,20 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         return self.tiled
 
     def _rho_sort_due(self):
-        return any(self.sort_due(sp) for sp in self.species)
+        return any(self.sort_due(sp) for sp in self.species)     # (an engine without species: nothing to re-deposit)
 
     def sort_due(self, sp):
         """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
         a species whose last intervals ended with a long overflow list (see PicEngine2D.overflow_sort_fraction)"""
+        if self.comm.size > 1:      # slab chain: one clock for all ranks and species (PicEngine2D.sort_due)
+            return self._chain_clock >= self.sort_interval or sp["since"] >= (1 << 29)
         return sp["tiling"] is None or sp["since"] >= min(self.sort_interval, sp.get("sort_interval_now", 1 << 30))
 
     def _first_sort_interval(self, sp):
         """see PicEngine2D._first_sort_interval (3-D tiles keep a margin of ONE cell)"""
         dt = getattr(self, "_dt_hint", None)
         n = sp["n"]
-        if self.overflow_sort_fraction <= 0 or not dt or n == 0:
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or n == 0:
             return
         dta = sp["data"]
         u = [dta[k, :n] for k in (3, 4, 5)]
@@ -230,7 +232,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
         """called by sort() with the overflow count of the last push of the interval that just ended"""
-        if self.overflow_sort_fraction <= 0 or n_sorted_before <= 0 or sp["since"] > self.sort_interval:
+        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 or sp["since"] > self.sort_interval:
             return
         now = min(sp.get("sort_interval_now", self.sort_interval), self.sort_interval)
         f = overflow / n_sorted_before

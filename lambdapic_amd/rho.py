@@ -34,6 +34,8 @@ from ._lib import check
 class RhoContinuityMixin:
     ABSORBED_MIN_CAPACITY = 1 << 16
 
+    _chain_clock = 1 << 30      # (due at the first step)
+
     def _rho_init(self):
         self.rho_continuity = True
         self.rho_continuity_blocked = False
@@ -76,7 +78,8 @@ class RhoContinuityMixin:
         want = max(self.ABSORBED_MIN_CAPACITY, self._rho_particle_slots() // 32)
         if self._absorbed is None:
             self._new_absorbed(want)
-        elif self._absorbed[2] < want and self._phase == "idle":     # (never swapped inside a step)
+        elif self._absorbed[2] < want and self._phase == "idle" and (self.comm.size == 1 or self._rho_sort_due()):
+            # (never swapped inside a step; on a slab chain only in the steps every rank re-deposits rho anyway)
             self._new_absorbed(max(want, 2 * self._absorbed[2]))
             self._anchor_pending = True      # the fresh list knows nothing of the last step's absorptions
         return self._absorbed
@@ -100,6 +103,15 @@ class RhoContinuityMixin:
                               f"fields) missed their removal since the last sort; this step re-deposits rho and the "
                               f"list grows to {4 * cap}", RuntimeWarning, stacklevel=3)
 
+    def _absorbing_chain(self):
+        """does ANY slab of the chain absorb particles?  (the same answer on every rank)"""
+        return any(v != "periodic" for v in self.bc.values())
+
+    def _tick_chain_clock(self):
+        """slab chains: ONE sort / real-deposit clock for all ranks and species (engines: ``sort_due``)"""
+        if self.comm.size > 1:
+            self._chain_clock = 1 if self._chain_clock >= self.sort_interval else self._chain_clock + 1
+
     def _rho_sorted(self):
         """called by sort(): a sort at the sorter stage (before reset_current) makes this step a real-deposit step"""
         if self._phase == "idle":
@@ -113,9 +125,13 @@ class RhoContinuityMixin:
             self._absorbed_bufs()            # allocated / grown between steps (growing it forces a real deposit)
         anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending \
             or self._rho_sort_due()
-        if not anchor and self._prev_phase == "anchor" and self.absorb:
-            # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval)
-            anchor = int(self._absorbed[1][0].item()) > self._absorbed[2]
+        if not anchor and self._prev_phase == "anchor" and (self.absorb if self.comm.size == 1 else self._absorbing_chain()):
+            # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval.)  On a
+            # slab chain neighbouring slabs must be in the SAME phase -- a slab that re-deposits rho puts its share of the
+            # face nodes into guard planes which the fold adds to a neighbour that carries that charge already -- so
+            # every phase decision there follows the common clock (sort_due), and this one is taken by all ranks together
+            over = self._absorbed is not None and int(self._absorbed[1][0].item()) > self._absorbed[2]
+            anchor = self.comm.any(over)
         self._anchor_pending = False
         self._phase = self._prev_phase = "anchor" if anchor else "continuity"
         self.rho_steps[self._phase] += 1
@@ -151,6 +167,7 @@ class RhoContinuityMixin:
     def _finish_rho(self):
         """after the currents were folded: rho^{n+1} = rho^n - dt div J on a continuity step"""
         phase, self._phase = self._phase, "idle"
+        self._tick_chain_clock()      # (the end of the step: every sort / phase decision of the step has seen the same clock)
         left = None
         if self.comm.size > 1 and self.rho_continuity and self._rho_available():
             # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step.  Sent in
@@ -162,9 +179,12 @@ class RhoContinuityMixin:
                 self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
             self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
             left = self._jx_plane if self.comm.has_left else None
-        if phase != "continuity" or self._dt_step <= 0.0:     # (no push ran: J = 0, rho stays)
+        # dt of the step: from this rank's pushes, or -- a rank that holds no particle (yet) still receives its
+        # neighbours' guard-plane currents through the fold and has to advance rho with them -- from the step driver
+        dt_step = self._dt_step if self._dt_step > 0.0 else (getattr(self, "_dt_hint", 0.0) if self.comm.size > 1 else 0.0)
+        if phase != "continuity" or not dt_step > 0.0:        # (single slab, no push ran: J = 0, rho stays)
             return
         split = ((1 if self.comm.has_left else 0) | (2 if self.comm.has_right else 0)) if self.comm.size > 1 else 0
-        check(self.L.lpa_rho_continuity(self._g(), self._dt_step, self.local_axes, split,
+        check(self.L.lpa_rho_continuity(self._g(), dt_step, self.local_axes, split,
                                         left.data_ptr() if left is not None else None, self.stream),
               "lpa_rho_continuity")

@@ -619,6 +619,7 @@ class Simulation:
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         for self.istep in range(self.itime, self.itime + nsteps):
+            self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
             self._run_stage(table, "start")
             if self._fused_step(table, unified):
                 self._run_stage(table, "maxwell_2")

@@ -334,6 +334,7 @@ class Simulation3D:
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         eng = self.engine
         for self.istep in range(self.itime, self.itime + nsteps):
+            self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
             self._run_stage(table, "start")
             if self._fused_step(table):
                 self._run_stage(table, "maxwell_2")

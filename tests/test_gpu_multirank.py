@@ -43,7 +43,7 @@ def _problem():
     return dx, dy, dt, x, y, u, ig, w
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, left_only=False):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -58,8 +58,10 @@ def _run(rank, world, port, q):
     eng.overlap = world == 2       # 2 ranks: J / rho guard exchange behind the interior tiles; 3 ranks: in line
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
     mine = (x >= lo) & (x < hi)
+    if left_only:                   # plasma in the left 40 % of the box only: the last rank starts without a particle
+        mine &= x < 0.4 * NXG * dx
     n = int(mine.sum())
-    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=3 * n)
+    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=3 * n + 20000)
     s = eng.species[0].cset
     for name, arr in (("x", x), ("y", y), ("ux", u[0]), ("uy", u[1]), ("uz", u[2]), ("inv_gamma", ig), ("w", w)):
         s.arr(name)[:n] = torch.from_numpy(arr[mine]).cuda()
@@ -87,11 +89,11 @@ def _run(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _launch(world):
+def _launch(world, left_only=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, left_only)) for r in range(world)]
     for p in procs:
         p.daemon = True
         p.start()
@@ -123,6 +125,22 @@ def _check_padded(fields, world):
 @pytest.fixture(scope="module")
 def single():
     return _launch(1)
+
+
+def test_a_rank_without_particles_keeps_pace():
+    """plasma in the left 40 % of the box: rank 1 of 2 starts EMPTY and fills by migration.  Every exchange of a step is
+    unconditional -- in particular the jx plane of the rho continuity update (rho.py), which a rank that pushed nothing
+    used to skip while its neighbour waited for it -- and each rank sorts, and re-anchors rho, when ITS particles ask
+    for it.  Against the same problem on one rank."""
+    t1, f1 = _launch(1, left_only=True)
+    t2, f2 = _launch(2, left_only=True)
+    assert np.array_equal(t2[:, 3], t1[:, 3]) and t1[0, 3] > 10000
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(t2[:, 1], t1[:, 1], rtol=1e-12)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-12)
+    for a in f1:
+        if not a.startswith("pad_"):
+            assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * np.abs(f1[a]).max(), a
 
 
 @pytest.mark.parametrize("world", [2, 3])
