@@ -352,7 +352,7 @@ def test_moving_window_chain_without_injection_matches_single_rank():
 
 
 # ---- 3-D slabs: two ranks against one on the same periodic box ----------------------------------------
-def _run_3d(rank, world, port, q):
+def _run_3d(rank, world, port, q, left_only=False):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -374,8 +374,10 @@ def _run_3d(rank, world, port, q):
                       migrate_capacity=2048)
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
     mine = (pos[0] >= lo) & (pos[0] < hi)
+    if left_only:                   # plasma in the left 40 % of the box: rank 1 of 2 starts without a particle
+        mine &= pos[0] < 0.4 * nxg * dx
     k = int(mine.sum())
-    cap = 3 * k + eng.arrival_area()
+    cap = 3 * k + eng.arrival_area() + 4096
     data = torch.full((len(ATTRS3), cap), float("nan"), dtype=torch.float64, device="cuda:0")
     data[:, :k] = torch.from_numpy(np.concatenate([pos[:, mine], u[:, mine], ig[None, mine], w[None, mine]])).cuda()
     # _id = the particle's index in the global arrays: the same particle has the same id whatever the decomposition
@@ -405,11 +407,11 @@ def _run_3d(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _launch_3d(world):
+def _launch_3d(world, left_only=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_3d, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_3d, args=(r, world, port, q, left_only)) for r in range(world)]
     for p in procs:
         p.daemon = True
         p.start()
@@ -425,6 +427,18 @@ def _launch_3d(world):
     trace = sum(r[1] for r in res)
     fields = {a: np.concatenate([r[2][a] for r in res], axis=0) for a in res[0][2]}
     return trace, fields
+
+
+def test_3d_rank_without_particles_keeps_pace():
+    """the 3-D twin of test_a_rank_without_particles_keeps_pace: one clock for the chain's sorts and real rho deposits"""
+    t1, f1 = _launch_3d(1, left_only=True)
+    t2, f2 = _launch_3d(2, left_only=True)
+    assert np.array_equal(t2[:, 3], t1[:, 3]) and t1[0, 3] > 2000
+    np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-12)
+    assert np.abs(t2[:, 1] - t1[:, 1]).max() <= 1e-12 * np.abs(t1[:, 1]).max()
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
+        assert np.abs(f2[a] - f1[a]).max() <= 1e-9 * np.abs(f1[a]).max(), a
 
 
 def test_3d_slabs_match_single_rank():
