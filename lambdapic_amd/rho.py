@@ -123,16 +123,26 @@ class RhoContinuityMixin:
         enabled = self.rho_continuity and self._rho_available()
         if enabled and self.absorb:
             self._absorbed_bufs()            # allocated / grown between steps (growing it forces a real deposit)
-        anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending \
-            or self._rho_sort_due()
-        if not anchor and self._prev_phase == "anchor" and (self.absorb if self.comm.size == 1 else self._absorbing_chain()):
-            # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval.)  On a
-            # slab chain neighbouring slabs must be in the SAME phase -- a slab that re-deposits rho puts its share of the
-            # face nodes into guard planes which the fold adds to a neighbour that carries that charge already -- so
-            # every phase decision there follows the common clock (sort_due), and this one is taken by all ranks together
-            over = self._absorbed is not None and int(self._absorbed[1][0].item()) > self._absorbed[2]
-            anchor = self.comm.any(over)
-        self._anchor_pending = False
+        if self.comm.size == 1:
+            anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending \
+                or self._rho_sort_due()
+            if not anchor and self._prev_phase == "anchor" and self.absorb:
+                # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval)
+                anchor = int(self._absorbed[1][0].item()) > self._absorbed[2]
+            self._anchor_pending = False
+        else:
+            # Slab chain: neighbouring slabs must be in the SAME phase -- a slab that re-deposits rho puts its share of
+            # the face nodes into guard planes which the fold adds to a neighbour that carries that charge already.  So
+            # the decision uses only what every rank knows (the chain's clock: sort_due; forced re-sorts; the
+            # configuration), and what one rank alone knows -- its absorbed-particle list overflowed, its list was
+            # swapped -- is put to the vote in the one step per interval in which all ranks ask (the step after a real
+            # deposit); until then a local wish waits.
+            anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._rho_sort_due()
+            if not anchor and self._prev_phase == "anchor" and self._absorbing_chain():
+                over = self._absorbed is not None and int(self._absorbed[1][0].item()) > self._absorbed[2]
+                anchor = self.comm.any(over or self._anchor_pending)
+            if anchor:
+                self._anchor_pending = False
         self._phase = self._prev_phase = "anchor" if anchor else "continuity"
         self.rho_steps[self._phase] += 1
         self._dt_step = 0.0          # set by the pushes of this step
