@@ -67,6 +67,8 @@ def _run(rank, world, port, q, left_only=False):
         s.arr(name)[:n] = torch.from_numpy(arr[mine]).cuda()
     s.id[:n] = torch.from_numpy(np.nonzero(mine)[0]).cuda()
     eng.species[0].n = n
+    if left_only:                   # ... and a second species that has no particle anywhere
+        eng.add_species(1.602176634e-19, 1836 * 9.1093837139e-31, capacity=20000)
     trace = []
     for _ in range(NSTEPS):
         eng.step(dt)
@@ -127,13 +129,15 @@ def single():
     return _launch(1)
 
 
-def test_a_rank_without_particles_keeps_pace():
-    """plasma in the left 40 % of the box: rank 1 of 2 starts EMPTY and fills by migration.  Every exchange of a step is
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_without_particles_keeps_pace(world):
+    """plasma in the left 40 % of the box: the last rank of 2 / 3 starts EMPTY and fills by migration (a second species is
+    empty on every rank).  Every exchange of a step is
     unconditional -- in particular the jx plane of the rho continuity update (rho.py), which a rank that pushed nothing
     used to skip while its neighbour waited for it -- and each rank sorts, and re-anchors rho, when ITS particles ask
     for it.  Against the same problem on one rank."""
     t1, f1 = _launch(1, left_only=True)
-    t2, f2 = _launch(2, left_only=True)
+    t2, f2 = _launch(world, left_only=True)
     assert np.array_equal(t2[:, 3], t1[:, 3]) and t1[0, 3] > 10000
     np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-10)
     np.testing.assert_allclose(t2[:, 1], t1[:, 1], rtol=1e-12)
@@ -324,13 +328,16 @@ def _launch_window(world, inject=True):
     return trace, fields
 
 
-def test_moving_window_chain_matches_single_rank():
+@pytest.mark.parametrize("world", [2, 4])
+def test_moving_window_chain_matches_single_rank(world):
+    """(4 ranks: the two left slabs hold no particle until the window has moved the plasma into them)"""
     t1, f1 = _launch_window(1)
-    t2, f2 = _launch_window(2)
+    t2, f2 = _launch_window(world)
     assert f1["_x0"][0, 0] >= 4 * 32 and np.array_equal(f1["_x0"][0], f2["_x0"][0])   # both shifted alike
     assert t1[-1, 3] > 1000                                        # plasma was injected and kept
     assert np.array_equal(t2[:, 3], t1[:, 3])
     np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(t2[:, 1], t1[:, 1], rtol=1e-9, atol=1e-12 * np.abs(t1[:, 1]).max())
     np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
         scale = np.abs(f1[a]).max()
