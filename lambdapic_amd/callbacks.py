@@ -1,4 +1,4 @@
-"""Device-native diagnostics callbacks (mirrors of the reference's, without the HDF5 / plotting parts).
+"""Device-native diagnostics callbacks (mirrors of the reference's; the HDF5 writers are in hdf5.py, no plotting).
 
 ``get_fields`` -- `callback/utils.py:26-237`: whole-box field arrays (a z-plane in 3-D) on rank 0.
 ``SetMomentum`` / ``SetTemperature`` / ``SetMomentumAndTemperature`` -- `callback/utils.py:842-1049` on the device.
@@ -17,57 +17,50 @@ import torch
 import torch.distributed as dist
 
 from . import constants
+from .hdf5 import SaveSpeciesDensityToHDF5
+from .slices import normalize_slice
 
 
-class ExtractSpeciesDensity:
-    stage = "current_deposition"
-    device_native = True
+class ExtractSpeciesDensity(SaveSpeciesDensityToHDF5):
+    """the density writer's computation (hdf5.py) with the result kept instead of written, as in the reference, where
+    this class derives from ``SaveSpeciesDensityToHDF5`` too (`callback/utils.py:240-293`).  ``slice``: an ``np.s_``
+    selection of the box (`callback/hdf5.py:14-99`)."""
 
     def __init__(self, sim, species, interval=100, slice=None):
-        if slice is not None:
-            raise NotImplementedError("slices of the density are not supported")
-        self.species, self.interval = species, interval
-        self.prev_rho = None
-        self._dev = None
+        self.stage, self.interval = self.DEFAULT_STAGE, interval
+        self.species, self.prev_rho = species, None
+        self.slice = slice
+        dims = (sim.nx, sim.ny) + ((sim.nz,) if getattr(sim, "dimension", 2) == 3 else ())
+        self._normalized_slice = normalize_slice(len(dims), slice, dims)       # (ValueError now, not at the first call)
+        self._dev = self._out_idx = self._shape = None
 
-    @property
-    def ispec_target(self):
-        return self.species.ispec
-
-    @staticmethod
-    def _rho(sim):
-        eng = sim.engine
-        g = eng.ng
-        if getattr(sim, "dimension", 2) == 3:
-            return eng.view("rho")[g:-g, g:-g, g:-g]
-        return eng.grid.view("rho")[g:-g, g:-g]
-
-    def __call__(self, sim):
-        t = self.ispec_target
-        if t > 0 and sim.ispec == t - 1:
-            sim.sync_currents()
-            self.prev_rho = self._rho(sim).clone()
-        elif sim.ispec == t:
-            sim.sync_currents()
-            rho = self._rho(sim)
-            d = rho.clone() if t == 0 else rho - self.prev_rho
-            self._dev = d / self.species.q
-            self.prev_rho = None
+    def _deliver(self, sim, density, out_idx, shape, norm):
+        self._dev, self._out_idx, self._shape = density, out_idx, shape
 
     @property
     def density_device(self) -> torch.Tensor:
+        """this rank's share of the selection (``None`` when the slab holds nothing of it)"""
         return self._dev
 
     @property
     def density(self) -> np.ndarray:
-        """this rank's slab (zeros before the first trigger)"""
+        """this rank's share (zeros before the first trigger)"""
         return self._dev.cpu().numpy() if self._dev is not None else np.zeros(0)
 
     def gather(self, sim):
-        """the whole box on rank 0 (None elsewhere): slabs concatenated along x"""
-        if self._dev is None:
+        """the whole selection on rank 0 (None elsewhere)"""
+        if self._shape is None:
             raise RuntimeError("ExtractSpeciesDensity.gather() before the callback was triggered")
-        return _gather_slabs(sim, self._dev)
+        if self._normalized_slice is None:
+            return _gather_slabs(sim, self._dev)
+        parts = sim.mpi.comm.gather((self._out_idx, self.density))
+        if parts is None:
+            return None
+        out = np.zeros(self._shape)
+        for idx, block in parts:
+            if idx is not None:
+                out[idx] = block
+        return out
 
 
 def _gather_slabs(sim, mine: torch.Tensor):
