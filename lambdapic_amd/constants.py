@@ -8,9 +8,10 @@ otherwise CODATA 2022 as shipped by scipy >= 1.15 -- the values the golden vecto
 """
 C_LIGHT = 299792458.0
 try:  # pragma: no cover - depends on the host
-    from scipy.constants import e as E_CHARGE, epsilon_0 as EPSILON_0, m_e as M_E, mu_0 as MU_0
+    from scipy.constants import e as E_CHARGE, epsilon_0 as EPSILON_0, m_e as M_E, m_p as M_P, mu_0 as MU_0
 except Exception:  # scipy absent
     EPSILON_0 = 8.8541878188e-12
     MU_0 = 1.25663706127e-06
     M_E = 9.1093837139e-31
     E_CHARGE = 1.602176634e-19
+    M_P = 1.67262192595e-27

@@ -909,10 +909,14 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         sp.steps_since_sort = 1 << 30
 
     def append_particles_device(self, ispec, dev):
-        """``dev``: dict of device tensors (x y ux uy uz inv_gamma w id) -> loose particles + forced re-sort"""
+        """``dev``: dict of device tensors (x y ux uy uz inv_gamma w id) -> loose particles + forced re-sort.
+        On a slab chain appends are collective in effect: the forced re-sort re-anchors rho, and neighbouring slabs must
+        do that in the same step (rho.py) -- every rank calls in the same step, with no particles if it has none."""
         sp = self.species[ispec]
         k = int(dev["x"].numel())
         if k == 0:
+            if self.comm.size > 1:
+                sp.steps_since_sort = 1 << 30
             return
         rows = torch.zeros((len(sp.cset.names), k), dtype=torch.float64, device=self.device)
         for i, a in enumerate(sp.cset.names):
@@ -926,6 +930,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         sp = self.species[ispec]
         k = int(host["x"].size)
         if k == 0:
+            if self.comm.size > 1:          # (see append_particles_device)
+                sp.steps_since_sort = 1 << 30
             return
         st = sp.cset
         rows = torch.zeros((len(st.names), k), dtype=torch.float64)

@@ -735,10 +735,13 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def append_device(self, i, rows, ids=None):
         """append particles (device tensor [NROWS3][k]: ATTRS3 order + id row; or [8][k] with ``ids`` int64[k],
         fresh ids when omitted) behind the stored ones as loose particles and force a re-sort; grows the store
-        when needed"""
+        when needed.  On a slab chain every rank calls in the same step (with no columns if it has none): the forced
+        re-sort re-anchors rho, which neighbouring slabs must do together (rho.py)"""
         sp = self.species[i]
         k = int(rows.shape[1])
         if k == 0:
+            if self.comm.size > 1:
+                sp["since"] = 1 << 30
             return
         if rows.shape[0] == ID_ROW:
             full = torch.empty((NROWS3, k), dtype=torch.float64, device=self.device)

@@ -329,6 +329,8 @@ class _File:
         elif mode in ("a", "r+"):
             self.id = L.H5Fopen(name, 1, 0) if os.path.exists(name) else L.H5Fcreate(name, 2, 0, 0)
         elif mode == "r":
+            if not os.path.exists(name):
+                raise FileNotFoundError(f"no such file: {name.decode()!r}")
             self.id = L.H5Fopen(name, 0, 0)
         else:
             raise ValueError(f"mode {mode!r}")

@@ -3,6 +3,7 @@
 ``SaveFieldsToHDF5``          `:282-399`  ``<prefix>/<itime:06d>.h5``, one dataset per field component
 ``SaveSpeciesDensityToHDF5``  `:402-614`  ``<prefix>/<species>_<itime:06d>.h5``, dataset ``density``
 ``SaveParticlesToHDF5``       `:616-700`  ``<prefix>/<species>_particles_<itime:06d>.h5``, one dataset per attribute + ``id``
+``LoadParticles``             `callback/utils.py:1051-1178`  the reverse: a particle file into the resident stores
 
 Same constructor arguments, file names, dataset names / shapes / types, chunking (one patch) and attributes.  What is
 different is where the data comes from: the reference walks its host patches; here every rank selects its share of the
@@ -235,3 +236,64 @@ class SaveParticlesToHDF5(_Writer):
                     f[a][start: start + len(v)] = v
 
         _in_turn(sim, self.prefix / f"{self.species.name}_particles_{sim.itime:06d}.h5", create, add)
+
+
+class LoadParticles(_Writer):
+    """stage ``init``, by default at the first step only: read ``/x /y (/z) /w`` and whatever else of the store's
+    attributes the file holds (``_id`` and ``inv_gamma`` are never taken from a file; other datasets are ignored) in
+    batches, keep what lies in this rank's slab -- [first node - d/2, last node + d/2) per axis, the patches' own
+    bounds in the reference (`callback/utils.py:1122-1129`) -- and append it to the resident store as loose particles
+    with fresh ids; the next step's sort files them.  ``inv_gamma`` is set to 1 / sqrt(1 + u^2) (the reference line
+    `:1146` stores sqrt(1 + u^2) there, which its first half position push would take for 1 / gamma; the resident 2-D
+    engine recomputes it from the momenta anyway)."""
+    DEFAULT_STAGE = "init"
+    REQUIRED = {2: ("x", "y", "w"), 3: ("x", "y", "z", "w")}
+
+    def __init__(self, species, file, interval=None):
+        h5lite.require()
+        self.stage, self.species, self.file = self.DEFAULT_STAGE, species, file
+        self._batch_size = 1 << 20
+        self.interval = (lambda sim: sim.itime == 0) if interval is None else interval
+
+    def _filter_attributes(self, sim):
+        with h5lite.File(self.file, "r") as f:
+            in_file = set(f.keys())
+        for a in self.REQUIRED[sim.dimension]:
+            if a not in in_file:
+                raise ValueError(f"Attribute '{a}' not found in {self.file}")
+        return (in_file & set(store_attributes(sim, self.species))) - {"_id", "inv_gamma"}
+
+    def _call(self, sim):
+        names = sorted(self._filter_attributes(sim))
+        eng, dim = sim.engine, sim.dimension
+        d = (sim.dx, sim.dy) + ((sim.dz,) if dim == 3 else ())
+        n_loc = (sim.nx // sim.comm.size, sim.ny) + ((sim.nz,) if dim == 3 else ())
+        origin = (eng.x0, getattr(eng, "y0", 0.0), getattr(eng, "z0", 0.0))[:dim]
+        with h5lite.File(self.file, "r") as f:
+            total = f["x"].shape[0]
+            for lo in range(0, total, self._batch_size):
+                hi = min(lo + self._batch_size, total)
+                data = {a: np.asarray(f[a][lo:hi], dtype=np.float64) for a in names}
+                keep = np.ones(hi - lo, dtype=bool)
+                for a, o, n, dd in zip("xyz", origin, n_loc, d):
+                    keep &= (data[a] >= o - dd / 2) & (data[a] < o + (n - 0.5) * dd)
+                k = int(keep.sum())
+                if k == 0:
+                    continue
+                dev = {a: torch.from_numpy(np.ascontiguousarray(v[keep])).to(eng.device) for a, v in data.items()}
+                for a in ("ux", "uy", "uz"):
+                    dev.setdefault(a, torch.zeros(k, dtype=torch.float64, device=eng.device))
+                dev["inv_gamma"] = torch.rsqrt(1.0 + dev["ux"] ** 2 + dev["uy"] ** 2 + dev["uz"] ** 2)
+                if dim == 3:
+                    from .engine3d import ATTRS3
+                    eng.append_device(self.species.ispec, torch.stack([dev[a] for a in ATTRS3]))
+                else:
+                    i = self.species.ispec
+                    dev["id"] = torch.arange(k, dtype=torch.int64, device=eng.device) + sim._next_ids(i)
+                    sim._id_next[i] += k
+                    eng.append_particles_device(i, dev)
+        if sim.comm.size > 1 and total:     # appends are collective on a chain (engine.append_particles_device)
+            if dim == 3:
+                eng.append_device(self.species.ispec, torch.empty((9, 0), dtype=torch.float64, device=eng.device))
+            else:
+                eng.append_particles_device(self.species.ispec, {"x": torch.empty(0, device=eng.device)})

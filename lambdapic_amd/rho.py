@@ -181,8 +181,8 @@ class RhoContinuityMixin:
         left = None
         if self.comm.size > 1 and self.rho_continuity and self._rho_available():
             # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step.  Sent in
-            # EVERY step, whatever this rank's own phase (and whether it pushed anything): the ranks decide their real-
-            # deposit steps -- their sorts -- independently, and the neighbour may be in a continuity step
+            # EVERY step, whatever the phase (and whether this rank pushed anything): an exchange that depended on the
+            # phase would hang the chain the day two ranks disagreed about it
             send = self._rho_last_jx_plane().reshape(-1)
             if self._jx_plane is None:
                 self._jx_plane = torch.zeros_like(send)

@@ -37,9 +37,10 @@ class Species:
     name: str
     charge: float            # in units of e
     mass: float              # in units of m_e
-    density: object = None   # callable (x, y) -> n [m^-3] or a float
-    ppc: int = 0
+    density: object = None   # callable (x, y[, z]) -> n [m^-3] or a float
+    ppc: object = 0          # particles per cell: an int or a callable (x, y[, z]) -> int
     momentum_sigma: float = 0.0   # thermal u = gamma*beta spread per axis (SetTemperature stand-in)
+    density_min: float = 0.0      # only cells with density > density_min are loaded (core/patch/cpu.py:16,41)
     ispec: int = field(default=-1, init=False)
 
     @property
@@ -51,10 +52,32 @@ class Species:
         return self.mass * constants.M_E
 
 
+@dataclass
+class Electron(Species):
+    """`core/species.py:185-208` without the radiation / photon links (QED is out of scope)"""
+    name: str = "electron"
+    charge: float = field(default=-1, init=False)
+    mass: float = field(default=1.0, init=False)
+
+
+@dataclass
+class Positron(Species):
+    name: str = "positron"
+    charge: float = field(default=1, init=False)
+    mass: float = field(default=1.0, init=False)
+
+
+@dataclass
+class Proton(Species):
+    name: str = "proton"
+    charge: float = field(default=1, init=False)
+    mass: float = field(default=constants.M_P / constants.M_E, init=False)      # core/species.py:219
+
+
 def load_block_device(species, origin, n, d, seed, device, id_prefix=0):
-    """Uniform loading of one block of cells ON THE DEVICE: ``ppc`` particles in every cell whose density is
-    > 0, positions uniform inside the cell, weight ``n d^dim / ppc``, thermal momenta N(0, sigma)
-    (`core/patch/cpu.py:21-75`).  The density callable is user code written for numpy: it is evaluated on
+    """Uniform loading of one block of cells ON THE DEVICE: ``ppc`` particles (a number, or a callable evaluated per
+    cell like the density) in every cell whose density is > ``density_min``, positions uniform inside the cell, weight
+    ``n d^dim / ppc``, thermal momenta N(0, sigma) (`core/patch/cpu.py:7-18,21-45`).  The density callable is user code written for numpy: it is evaluated on
     the host on the CELL grid (small), everything per particle happens on the device (the reference loads on
     the host; at 16 ppc a recycled window column is 5 x 10^5 particles, ~0.1 s of numpy per shift).
     Returns a dict of device tensors x, y(, z), ux, uy, uz, inv_gamma, w, id (may be empty: None).
@@ -66,20 +89,26 @@ def load_block_device(species, origin, n, d, seed, device, id_prefix=0):
     axes = [o + np.arange(m) * dd for o, m, dd in zip(origin, n, d)]
     grids = np.meshgrid(*axes, indexing="ij")
     dens = species.density(*grids) if callable(species.density) else np.full(grids[0].shape, float(species.density))
-    sel = np.nonzero(np.ravel(dens) > 0)[0]
+    dens = np.broadcast_to(np.asarray(dens, dtype=np.float64), grids[0].shape)
+    if callable(species.ppc):          # per cell, truncated like the reference's int(ppc_func(...))
+        ppc_cells = np.broadcast_to(np.asarray(species.ppc(*grids)), grids[0].shape).astype(np.int64).ravel()
+    else:
+        ppc_cells = np.full(dens.size, int(species.ppc), dtype=np.int64)
+    sel = np.nonzero((np.ravel(dens) > float(species.density_min)) & (ppc_cells > 0))[0]
     if sel.size == 0:
         return None
-    ppc = int(species.ppc)
+    ppc = torch.from_numpy(ppc_cells[sel]).to(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(int(np.random.SeedSequence([int(v) & 0xFFFFFFFF for v in seed]).generate_state(1, np.uint64)[0] >> 1)
                     if seed is not None else torch.seed())
     out = {}
-    k = sel.size * ppc
+    k = int(ppc_cells[sel].sum())
     for a, g_, dd in zip("xyz", grids, d):
         c = torch.from_numpy(np.ascontiguousarray(np.ravel(g_)[sel])).to(device).repeat_interleave(ppc)
         out[a] = c + (torch.rand(k, dtype=torch.float64, device=device, generator=gen) - 0.5) * dd
     vol = float(np.prod(d))
-    out["w"] = torch.from_numpy(np.ascontiguousarray(np.ravel(dens)[sel] * vol / ppc)).to(device).repeat_interleave(ppc)
+    out["w"] = torch.from_numpy(np.ascontiguousarray(np.ravel(dens)[sel] * vol / ppc_cells[sel])).to(device) \
+        .repeat_interleave(ppc)
     if species.momentum_sigma:
         for a in ("ux", "uy", "uz"):
             out[a] = torch.randn(k, dtype=torch.float64, device=device, generator=gen) * float(species.momentum_sigma)

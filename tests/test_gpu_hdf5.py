@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 from lambdapic_amd import h5lite
 from lambdapic_amd.callbacks import ExtractSpeciesDensity
-from lambdapic_amd.hdf5 import SaveFieldsToHDF5, SaveParticlesToHDF5, SaveSpeciesDensityToHDF5
+from lambdapic_amd.hdf5 import LoadParticles, SaveFieldsToHDF5, SaveParticlesToHDF5, SaveSpeciesDensityToHDF5
 from lambdapic_amd.simulation import Simulation, Species
 from lambdapic_amd.simulation3d import Simulation3D
 
@@ -204,6 +204,72 @@ def test_particle_files_default_attributes_3d_and_dead_particles(tmp_path):
             assert np.array_equal(f[a][:][oo], d[a][o]), a
     with pytest.raises(ValueError):
         SaveParticlesToHDF5(species=e, prefix=str(tmp_path), attrs=["x", "chi"])._call(sim)
+
+
+# ---- particles back in -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [2, 3])
+def test_load_particles_round_trip(tmp_path, dim):
+    """`tests/test_load_particles.py:11-124,243-...`: save, load into a simulation that starts empty, compare the sets --
+    and the loaded particles are good citizens of the resident store (fresh unique ids, a step runs, charge adds up)"""
+    src, e = _sim2() if dim == 2 else _sim3()
+    src.initialize()
+    names = ["x", "y", "w", "ux", "uz"] + (["z"] if dim == 3 else [])
+    SaveParticlesToHDF5(species=e, prefix=str(tmp_path), interval=1, attrs=names)(src)
+    file = tmp_path / "electrons_particles_000000.h5"
+    dst, e2 = _sim2(species=False) if dim == 2 else _sim3(species=False)
+    e2 = Species("electrons", charge=-1, mass=1, density=None, ppc=0)
+    dst.add_species([e2])
+    dst.initialize()
+    get = (lambda sim: sim.engine.species[0].download()) if dim == 2 else (lambda sim: sim.engine.download_species(0))
+    assert len(get(dst)["x"]) == 0
+    cb = LoadParticles(species=e2, file=str(file))
+    assert cb.stage == "init" and cb.interval(dst)
+    cb(dst)
+    a, b = get(src), get(dst)
+    assert len(b["x"]) == len(a["x"]) == 32 ** dim * 4
+    for k in names:
+        assert np.array_equal(np.sort(a[k]), np.sort(b[k])), k
+    o, oo = np.argsort(a["x"]), np.argsort(b["x"])
+    assert np.array_equal(a["ux"][o], b["ux"][oo])                       # attributes stayed together
+    assert np.array_equal(b["uy"], np.zeros_like(b["uy"]))               # not in the file
+    assert np.allclose(b["inv_gamma"], 1 / np.sqrt(1 + b["ux"] ** 2 + b["uz"] ** 2), rtol=1e-15)
+    assert len(np.unique(b["_id"].view(np.uint64))) == len(b["x"])
+    dst.run(3)
+    d = dst.engine.diagnostics()
+    assert d["nalive"][0] == len(a["x"])
+    assert d["charge"] == pytest.approx(-1.602176634e-19 * a["w"].sum(), rel=1e-9)
+
+
+def test_load_particles_edge_cases(tmp_path):
+    """`tests/test_load_particles.py:126-240`: a file without weights, an empty file, no file; particles outside the box"""
+    sim, _ = _sim2(species=False)
+    e = Species("electrons", charge=-1, mass=1, density=None, ppc=0)
+    sim.add_species([e])
+    sim.initialize()
+    rng = np.random.default_rng(0)
+    with h5lite.File(tmp_path / "incomplete.h5", "w") as f:
+        f.create_dataset("x", data=rng.uniform(0, 3.2e-6, 100))
+        f.create_dataset("y", data=rng.uniform(0, 3.2e-6, 100))
+    with pytest.raises(ValueError):
+        LoadParticles(species=e, file=str(tmp_path / "incomplete.h5"))(sim)
+    with h5lite.File(tmp_path / "empty.h5", "w") as f:
+        for k in ("x", "y", "w"):
+            f.create_dataset(k, data=np.array([]))
+        f.create_dataset("id", data=np.array([], dtype=np.uint64))
+    LoadParticles(species=e, file=str(tmp_path / "empty.h5"))(sim)
+    assert sim.engine.species[0].n == 0
+    with pytest.raises(FileNotFoundError):
+        LoadParticles(species=e, file=str(tmp_path / "nonexistent.h5"))(sim)
+    # the box spans [-dx/2, 31.5 dx): what lies outside belongs to no patch and is dropped
+    x = np.array([-0.6e-7, -0.4e-7, 1.0e-6, 31.4e-7, 31.6e-7, 1.0e-6])
+    y = np.array([1.0e-6, 1.0e-6, 1.0e-6, 1.0e-6, 1.0e-6, 40e-7])
+    with h5lite.File(tmp_path / "edge.h5", "w") as f:
+        f.create_dataset("x", data=x), f.create_dataset("y", data=y), f.create_dataset("w", data=np.arange(6.0) + 1)
+        f.create_dataset("chi", data=np.zeros(6))          # not an attribute of the store: ignored
+    cb = LoadParticles(species=e, file=str(tmp_path / "edge.h5"))
+    cb._batch_size = 4                                      # two batches
+    cb(sim)
+    assert sorted(sim.engine.species[0].download()["w"]) == [2.0, 3.0, 4.0]
 
 
 # ---- two ranks --------------------------------------------------------------------------------------------------------

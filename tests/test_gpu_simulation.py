@@ -278,3 +278,31 @@ def test_one_call_per_step_equals_the_staged_loop():
         assert np.array_equal(da["_id"].view(np.uint64)[oa], db["_id"].view(np.uint64)[ob])
         for k in ("x", "y", "ux", "uy", "uz"):
             assert np.abs(da[k][oa] - db[k][ob]).max() <= 1e-9 * max(np.abs(db[k]).max(), 1e-300), k
+
+
+def test_loading_rules_density_min_ppc_function_and_species_classes():
+    """`core/patch/cpu.py:7-45`: a cell is loaded when its density exceeds ``density_min``, with ``int(ppc(x, y))``
+    particles of weight n dx dy / ppc; `core/species.py:185-221`: Electron / Positron / Proton"""
+    from lambdapic_amd.simulation import Electron, Positron, Proton
+    nx = ny = 32
+    dx = dy = 1e-7
+    bc = {k: "periodic" for k in ("xmin", "xmax", "ymin", "ymax")}
+    sim = Simulation(nx, ny, dx, dy, npatch_x=2, npatch_y=2, boundary_conditions=bc, random_seed=9)
+    ramp = lambda x, y: 1e24 * (x / dx) + 0 * y                     # 0, 1e24, 2e24 ... along x
+    e = Electron(density=ramp, ppc=lambda x, y: 1.9 + (y > 16 * dy) * 2, density_min=4.5e24)
+    p = Proton(density=2e24, ppc=3)
+    pos = Positron(name="e+", density=lambda x, y: 0 * x, ppc=4)   # no cell qualifies
+    sim.add_species([e, p, pos])
+    sim.initialize()
+    assert (e.charge, e.mass, p.charge, pos.charge, pos.mass) == (-1, 1.0, 1, 1, 1.0)
+    assert p.mass == pytest.approx(1836.152673, rel=1e-9) and p.name == "proton" and e.name == "electron"
+    d = sim.engine.species[0].download()
+    ix, iy = np.rint(d["x"] / dx).astype(int), np.rint(d["y"] / dy).astype(int)
+    assert ix.min() == 5                                            # 4e24 is not > 4.5e24
+    cnt = np.zeros((nx, ny), int)
+    np.add.at(cnt, (ix, iy), 1)
+    assert (cnt[:5] == 0).all() and (cnt[5:, :17] == 1).all() and (cnt[5:, 17:] == 3).all()
+    assert np.allclose(d["w"], 1e24 * ix * dx * dy / cnt[ix, iy], rtol=1e-14)
+    assert sim.engine.species[1].n == nx * ny * 3 and sim.engine.species[2].n == 0
+    sim.run(2)
+    assert sim.engine.diagnostics()["nalive"] == [len(d["x"]), nx * ny * 3, 0]
