@@ -121,12 +121,53 @@ def load_block_device(species, origin, n, d, seed, device, id_prefix=0):
     return out
 
 
+def validate_interval(interval):
+    """`callback/callback.py:11-19`: an int >= 1 (steps), a float in (0, 1) (seconds) or a callable(sim) -> bool"""
+    if isinstance(interval, bool) or not (isinstance(interval, (int, float, np.integer)) or callable(interval)):
+        raise TypeError(f"Invalid interval: {interval}. Must be int, float, or Callable")
+    if isinstance(interval, float) and not 0 < interval < 1:
+        raise ValueError(f"Invalid interval: {interval}. Must be between 0 and 1s if it is a float")
+    if isinstance(interval, (int, np.integer)) and interval < 1:
+        raise ValueError(f"Invalid interval: {interval}. Must be greater than 0 if it is an integer")
+
+
+def interval_triggered(sim, interval) -> bool:
+    """`callback/callback.py:22-45`"""
+    if callable(interval):
+        return bool(interval(sim))
+    if isinstance(interval, float):
+        return (sim.time % interval) < sim.dt
+    return sim.itime % int(interval) == 0
+
+
 def callback(stage="end", interval=1):
-    """decorator mirroring `callback/callback.py:48-109`: attaches ``stage`` and ``interval``"""
+    """decorator mirroring `callback/callback.py:48-109`: attaches ``stage`` and ``interval`` (the stage loop asks
+    ``interval`` before it calls -- and before it refreshes the host mirrors for the call)"""
+    validate_interval(interval)
+
     def wrap(fn):
         fn.stage, fn.interval = stage, interval
         return fn
     return wrap
+
+
+class Callback:
+    """base class of the reference's class-style callbacks (`callback/callback.py:111-145`): subclasses set ``stage`` /
+    ``interval`` and define ``_call(sim)``; calling the object runs ``_call`` when the interval says so"""
+    stage = "end"
+    interval = 1
+
+    def __call__(self, sim):
+        validate_interval(self.interval)
+        if not interval_triggered(sim, self.interval):
+            return None
+        ret = self._call(sim)
+        if sim.mpi.size > 1:
+            sim.mpi.comm.Barrier()
+        return ret
+
+    def _call(self, sim):
+        raise NotImplementedError
 
 
 class _Facade:
@@ -556,18 +597,7 @@ class Simulation:
 
     # ---- the stage loop (`simulation.py:937-1130`) ----------------------------------------------------
     def _triggered(self, cbs):
-        out = []
-        for cb in cbs:
-            iv = getattr(cb, "interval", 1)
-            if callable(iv):
-                hit = bool(iv(self))
-            elif isinstance(iv, float):
-                hit = (self.time % iv) < self.dt          # callback/callback.py:41
-            else:
-                hit = self.itime % int(iv) == 0
-            if hit:
-                out.append(cb)
-        return out
+        return [cb for cb in cbs if interval_triggered(self, getattr(cb, "interval", 1))]
 
     def _run_stage(self, table, stage):
         cbs = self._triggered(table.get(stage, []))
@@ -630,6 +660,7 @@ class Simulation:
             self.initialize()
         table = {}
         for cb in callbacks or []:
+            validate_interval(getattr(cb, "interval", 1))
             table.setdefault(getattr(cb, "stage", self.DEFAULT_STAGE), []).append(cb)
         for st in table:
             if st not in self.STAGES:

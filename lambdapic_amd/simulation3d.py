@@ -17,7 +17,8 @@ from .dist import SlabComm
 from .engine3d import ATTRS3, NROWS3, SIDES3, PicEngine3D
 from .fields import FIELD_ATTRS, Fields3D, from_device_layout, to_device_layout
 from .particles import ParticlesBase
-from .simulation import MPIFacade, Simulation, Species, _Facade, callback, load_block_device  # noqa: F401  (shared with 2-D)
+from .simulation import (Callback, MPIFacade, Simulation, Species, _Facade, callback, interval_triggered,  # noqa: F401
+                         load_block_device, validate_interval)          # (shared with 2-D)
 
 
 class Patch3D:
@@ -268,18 +269,7 @@ class Simulation3D:
 
     # ---- the stage loop --------------------------------------------------------------------------------------
     def _triggered(self, cbs):
-        out = []
-        for cb in cbs:
-            iv = getattr(cb, "interval", 1)
-            if callable(iv):
-                hit = bool(iv(self))
-            elif isinstance(iv, float):
-                hit = (self.time % iv) < self.dt          # callback/callback.py:41
-            else:
-                hit = self.itime % int(iv) == 0
-            if hit:
-                out.append(cb)
-        return out
+        return [cb for cb in cbs if interval_triggered(self, getattr(cb, "interval", 1))]
 
     def _run_stage(self, table, stage):
         cbs = self._triggered(table.get(stage, []))
@@ -313,6 +303,7 @@ class Simulation3D:
             self.initialize()
         table = {}
         for cb in callbacks or []:
+            validate_interval(getattr(cb, "interval", 1))
             table.setdefault(getattr(cb, "stage", self.DEFAULT_STAGE), []).append(cb)
         for st in table:
             if st not in self.STAGES:

@@ -3,7 +3,7 @@ bookkeeping, engine argument checks."""
 import numpy as np
 import pytest
 
-from lambdapic_amd.simulation import Simulation, callback
+from lambdapic_amd.simulation import Callback, Simulation, callback
 
 
 def _sim():
@@ -38,6 +38,40 @@ def test_interval_rules_match_the_reference():
     assert hits["picky"] == [1, 4]
     assert hits["every_2p5_dt"] == [it for it in range(12) if ((it * dt) % (2.5 * dt)) < dt]
     assert every3.stage == "start" and every3.interval == 3
+
+
+def test_interval_validation_and_class_style_callbacks():
+    """`callback/callback.py:11-19,111-145`; the reference's `tests/test_callback.py:170-260`"""
+    for bad, err in (("10", TypeError), (None, TypeError), (0, ValueError), (-3, ValueError), (0.0, ValueError),
+                     (1.0, ValueError), (1.5, ValueError), (-0.1, ValueError)):
+        with pytest.raises(err):
+            callback("end", interval=bad)
+    for good in (1, 7, np.int64(3), 1e-15, 0.999, lambda sim: True):
+        callback("end", interval=good)(lambda sim: None)
+    s = _sim()
+    s.initialized = True
+    with pytest.raises(ValueError):
+        bad = lambda sim: None                                       # noqa: E731
+        bad.stage, bad.interval = "end", 0
+        s.run(1, callbacks=[bad])
+
+    class Count(Callback):
+        stage = "start"
+
+        def __init__(self, interval):
+            self.interval, self.seen = interval, []
+
+        def _call(self, sim):
+            self.seen.append(sim.itime)
+            return "ran"
+
+    c = Count(4)
+    for it in range(10):
+        s.itime = it
+        assert c(s) == ("ran" if it % 4 == 0 else None)
+    assert c.seen == [0, 4, 8] and c.stage == "start"
+    with pytest.raises(NotImplementedError):
+        Callback()(s)
 
 
 def test_particle_ids_never_collide():
