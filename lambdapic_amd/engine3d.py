@@ -131,16 +131,19 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self.periodic = tuple(bc[ax + "min"] == "periodic" for ax in "xyz")
         self.cpml_thickness = int(cpml_thickness)
         self.L = lib()
-        fits = nx % _lib.LPA_TILE3_X == 0 and ny % _lib.LPA_TILE3_Y == 0 and nz % _lib.LPA_TILE3_Z == 0
-        if tiled and not fits:
-            raise ValueError("tiled 3-D path needs nx, ny multiples of 4 and nz a multiple of 16")
-        self.tiled = fits if tiled is None else bool(tiled)
+        # Tiles of 4 x 4 x 16 cells; a grid that is no multiple of that ends in partial tiles (the sort counts tiles
+        # with ceil, the kernel's images address the padded array as a torus, so nodes beyond the grid are legal
+        # addresses that no particle reads or deposits to).  Only a slab CHAIN needs whole tile columns along x: its
+        # edge / interior split and arrival bookkeeping count cells in tile columns from both faces.
+        self.tiled = True if tiled is None else bool(tiled)
         self.sort_interval, self.block_particles = int(sort_interval), int(block_particles)
         self.comm = comm or SlabComm(None, periodic=self.periodic[0], single=True)
         if self.comm.periodic != self.periodic[0]:
             raise ValueError("SlabComm(periodic=...) must match the x boundary condition")
         if self.comm.size > 1 and not self.tiled:
             raise ValueError("a slab decomposition needs the tile-sorted store (arrival area)")
+        if self.comm.size > 1 and nx % _lib.LPA_TILE3_X:
+            raise ValueError(f"a 3-D slab needs nx (cells per rank) to be a multiple of {_lib.LPA_TILE3_X}")
         self.migrate_capacity = int(migrate_capacity)
         self.device = torch.device(device)
         if self.device.type != "cuda":

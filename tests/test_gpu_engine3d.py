@@ -43,7 +43,7 @@ def test_3d_step_vs_oracle():
     qe, me = -oracle.E_CHARGE, oracle.M_E
     species = [(qe, me), (-qe, 1836.0 * me)]
     f = Fields3D(nx, ny, nz, dx, dy, dz, 0.0, 0.0, 0.0, 3)
-    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3)
+    eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, tiled=False)      # the global-atomics kernels, any store order
     eng.add_species(*species[0], e)
     eng.add_species(*species[1], ion)
     parts = [copy.deepcopy(e), copy.deepcopy(ion)]
@@ -67,12 +67,15 @@ def test_3d_step_vs_oracle():
         assert_close(got[a], getattr(parts[0], a), 1e-11, what=a)
 
 
-@pytest.mark.parametrize("uth,sort_interval,order", [(0.3, 4, 1), (0.02, 3, 1), (0.3, 3, 2)])
-def test_3d_tiled_step_vs_oracle(uth, sort_interval, order):
+@pytest.mark.parametrize("uth,sort_interval,order,shape", [(0.3, 4, 1, (12, 8, 32)), (0.02, 3, 1, (12, 8, 32)),
+                                                          (0.3, 3, 2, (12, 8, 32)), (0.3, 4, 1, (10, 7, 24)),
+                                                          (0.02, 3, 1, (13, 6, 20)), (0.3, 3, 2, (9, 9, 9))])
+def test_3d_tiled_step_vs_oracle(uth, sort_interval, order, shape):
     """the tile-sorted path: lpa_sort_tiles_3d (4 x 4 x 16-cell tiles) + LDS-tiled kernel + overflow list
     against the oracle's 3-D step.  Hot case: particles drift beyond the tile margin between sorts
-    (overflow list) and wrap around the box; cold case: everything stays on the LDS path."""
-    nx, ny, nz = 12, 8, 32
+    (overflow list) and wrap around the box; cold case: everything stays on the LDS path.  Shapes that are no
+    multiple of the tile end in partial tiles on every axis (one of them smaller than a tile along z)."""
+    nx, ny, nz = shape
     dx, dy, dz = 4e-8, 5e-8, 6e-8
     dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
     rng = np.random.default_rng(5)
@@ -126,7 +129,7 @@ def test_cpml_and_laser_3d_vs_reference_golden(golden, fused):
     dx, dy, dz, dt = (float(g[k]) for k in ("dx", "dy", "dz", "dt"))
     eng = PicEngine3D(nx, ny, nz, dx, dy, dz, ng, boundary_conditions=PML3, cpml_thickness=th)
     eng.fused_cpml = fused          # one launch per update, or kappa sweep + one psi launch per layer
-    assert not eng.tiled and len(eng.pml.layers) == 12
+    assert len(eng.pml.layers) == 12
     for a in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz"):
         eng.upload_field(a, g["in_" + a])
     for it in range(3):
@@ -336,15 +339,16 @@ def _plasma_block_3d(eng, rng, n3, d3, lo_cell, hi_cell, ppc, uth, q, m, dens=1e
     return n
 
 
-@pytest.mark.parametrize("bc", ["periodic", "pml"])
-def test_rho_from_continuity_matches_deposited_rho(bc):
+@pytest.mark.parametrize("bc,shape", [("periodic", (16, 12, 32)), ("pml", (16, 12, 32)), ("periodic", (14, 10, 24)),
+                                      ("pml", (18, 13, 40))])
+def test_rho_from_continuity_matches_deposited_rho(bc, shape):
     """Two engines, same particles, same steps: one deposits rho in every step (the reference's kernel,
     current/current_deposit.h:436-439), the other only on sort steps and advances it with the discrete continuity
     equation in between (LPA_PUSH_NO_RHO, lpa_rho_continuity).  rho agrees on every node of the padded array to 1e-12 of
     its maximum at every step, J / E / B to the summation order.  'pml': absorbing faces -- hot electrons leave the box,
     their charge has to leave rho one step after their last deposit (lpa_rho_absorbed)"""
     import torch
-    nx, ny, nz = 16, 12, 32
+    nx, ny, nz = shape                 # (the last two: partial tiles at the high end of every axis)
     d3 = (4e-8, 5e-8, 6e-8)
     dt = 0.95 / (C * np.sqrt(sum(d ** -2 for d in d3)))
     bcs = {k: bc for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
@@ -356,7 +360,7 @@ def test_rho_from_continuity_matches_deposited_rho(bc):
         eng.rho_continuity = cont
         eng.overflow_sort_fraction = 0       # the fixed sort schedule (the step counts asserted below); these electrons are hot
         rng = np.random.default_rng(4)
-        lo, hi = ((0, 0, 0), (nx, ny, nz)) if bc == "periodic" else ((5, 4, 5), (11, 8, 27))
+        lo, hi = ((0, 0, 0), (nx, ny, nz)) if bc == "periodic" else ((5, 4, 5), (nx - 5, ny - 4, nz - 5))
         n = _plasma_block_3d(eng, rng, (nx, ny, nz), d3, lo, hi, 6, 0.35, qe, me)
         _plasma_block_3d(eng, rng, (nx, ny, nz), d3, lo, hi, 3, 0.002, -qe, 1836 * me)
         return eng, n
