@@ -99,7 +99,13 @@ typedef struct {
                                   pass; a drift gauge for the caller's sort policy).  With the re-seating: [1] movers,
                                   [2] / [3] slots left in the class pools after the class-matched round, counted from
                                   the pools and from the movers without a seat -- they must agree */
-    int32_t class_init, reserved2_;
+    int32_t class_init;
+    int32_t stripe_ranks;      /* IN, lpa_sort_tiles_*: ranks per cell the striped orders keep in stripes -- 0 = the default rule
+                                  (lpa_sort_stripe_ranks), else the number the workspace was sized for with
+                                  lpa_sort_workspace_bytes_ranks (rounded up to a power of two in [32, 1024]).  OUT: the number
+                                  used.  A cell's particles beyond it follow cell by cell behind the stripes of their tile,
+                                  where the lanes of a wave share a cell and the LDS atomics of the tiled kernels serialise:
+                                  a store whose deepest cell (lpa_sort_deepest_cell) exceeds it wants a larger one */
 } lpa_tiling;
 
 #define LPA_TILE_X 8       /* cells per tile along x                                            */
@@ -395,6 +401,13 @@ int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity);
 /* ranks per cell the striped orders of a workspace of this capacity keep in stripes (twice the mean occupancy at full
  * capacity, a power of two in [32, 1024]); a cell's deeper particles follow cell by cell behind the stripes of its tile */
 int32_t lpa_sort_stripe_ranks(const lpa_grid *g, int64_t capacity);
+/* workspace size for an explicit number of striped ranks (lpa_tiling.stripe_ranks; 0 = the default rule): a store that
+ * fills only part of the grid -- a solid target in an empty box -- is deeper where it is occupied than its mean */
+int64_t lpa_sort_workspace_bytes_ranks(const lpa_grid *g, int64_t capacity, int32_t stripe_ranks);
+/* striped orders, two numbers of the last sort (device pointer inside the workspace, next to lpa_sort_live_count: one
+ * read-back serves all): [0] the largest number of particles one cell held, [1] the particles that lay beyond the striped
+ * ranks */
+const int32_t *lpa_sort_deepest_cell(void *workspace);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
                       int32_t order, lpa_tiling *out, void *stream);

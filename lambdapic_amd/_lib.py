@@ -53,7 +53,7 @@ class lpa_tiling(C.Structure):
                 ("blk_end", C.c_void_p), ("n_blocks", C.c_void_p),
                 ("tiles_z", C.c_int32), ("prefix_hint", C.c_int32), ("scratch", C.c_void_p * 8),
                 ("pad_ranks", C.c_void_p), ("slot_class", C.c_void_p), ("aux_slot", C.c_void_p), ("aux_info", C.c_void_p),
-                ("reloc_stats", C.c_void_p), ("class_init", C.c_int32), ("reserved2_", C.c_int32)]
+                ("reloc_stats", C.c_void_p), ("class_init", C.c_int32), ("stripe_ranks", C.c_int32)]
 
 
 class lpa_cpml_axis(C.Structure):
@@ -149,6 +149,8 @@ SIGNATURES = {
     "lpa_deposit_3d": (_i, [_G, _P, _d, _d, _vp]),
     "lpa_sort_workspace_bytes": (_i64, [_G, _i64]),
     "lpa_sort_stripe_ranks": (C.c_int32, [_G, _i64]),
+    "lpa_sort_workspace_bytes_ranks": (_i64, [_G, _i64, C.c_int32]),
+    "lpa_sort_deepest_cell": (_vp, [_vp]),
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
@@ -232,9 +234,11 @@ def lib():
     return _LIB
 
 
-def sort_result(L, wsbuf):
+def sort_result(L, wsbuf, with_deepest=False):
     """live count (slots, for a padded order) of the tile sort that just ran through workspace ``wsbuf`` (a device
-    uint8 tensor); raises when the device refused the sort (``lpa_sort_overflow``).  One host sync."""
+    uint8 tensor); raises when the device refused the sort (``lpa_sort_overflow``).  One host sync.
+    ``with_deepest``: (live count, particles in the deepest cell, particles beyond the striped ranks) from the same
+    read-back."""
     ptr = wsbuf.data_ptr()
     hdr = wsbuf[:64].view(_torch().int32).tolist()
     ovf = hdr[(L.lpa_sort_overflow(ptr) - ptr) // 4]
@@ -245,7 +249,9 @@ def sort_result(L, wsbuf):
                         "work-block table too small" if ovf & 2 else
                         "lpa_tiling.prefix_hint is not confirmed by the workspace header (the source is not the previous "
                         "sort's result)"))
-    return hdr[(L.lpa_sort_live_count(ptr) - ptr) // 4]
+    live = hdr[(L.lpa_sort_live_count(ptr) - ptr) // 4]
+    k = (L.lpa_sort_deepest_cell(ptr) - ptr) // 4
+    return (live, hdr[k], hdr[k + 1]) if with_deepest else live
 
 
 def _torch():

@@ -32,11 +32,15 @@ constexpr int TCELLS = TX * TY;  // 256
 // per cell with 128 striped ranks: 3.5 ms instead of 1.6).  Sized per workspace from the mean occupancy the store can
 // hold: twice the particles per cell at full capacity, as a power of two in [32, 1024] -- C2 (64 per cell): 256 ranks,
 // 34 MB of masks; a 3-D slab at 8 per cell: 32 ranks instead of 128.
-static int stripe_ranks(const lpa_grid *g, int64_t cap, int ntiles) {
+// `requested` > 0 (lpa_tiling.stripe_ranks / lpa_sort_workspace_bytes_ranks): the caller knows better -- a store whose
+// particles sit in a fraction of the grid (a solid target in an empty box) is far deeper where it is occupied than
+// its mean over all tiles; rounded up to a power of two in the same range.
+static int stripe_ranks(const lpa_grid *g, int64_t cap, int ntiles, int requested = 0) {
     (void)g;
     const int64_t per_cell = (cap + (int64_t)ntiles * 256 - 1) / ((int64_t)ntiles * 256);
+    const int64_t want = requested > 0 ? requested : 2 * per_cell;
     int r = 32;
-    while (r < 2 * per_cell && r < 1024) r *= 2;
+    while (r < want && r < 1024) r *= 2;
     return r;
 }
 static_assert(TCELLS == 256, "one workgroup thread per tile cell");
@@ -52,7 +56,9 @@ struct SortHdr {      // first 64 bytes of the workspace
     // destination's capacity; bit 1 = more work blocks than the table holds; bit 2 = the caller's prefix_hint exceeds
     // the tile-ordered prefix this header vouches for
     int32_t overflow;
-    int32_t pad[9];
+    int32_t deepest;  // striped orders: the largest number of particles one cell holds (k_stripe_table) ...
+    int32_t tail;     // ... and the particles that lie beyond the striped ranks (cell by cell behind their tile's stripes)
+    int32_t pad[7];
 };
 constexpr int32_t SORT_OVF_SLOTS = 1, SORT_OVF_BLOCKS = 2, SORT_BAD_HINT = 4;
 constexpr int32_t SORT_MAGIC = 0x4c504131;
@@ -78,9 +84,10 @@ static int tile_count(const lpa_grid *g) {
     return ((g->nx + TX - 1) / TX) * ((g->ny + TY - 1) / TY);
 }
 
-static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w) {
+static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles, char *base, SortWs *w,
+                         int ranks = 0) {
     int nt = tile_count(g);
-    const int RMAX = stripe_ranks(g, cap, nt);
+    const int RMAX = stripe_ranks(g, cap, nt, ranks);
     // + 8: the tiled kernels launch max_blocks workgroups and deal work blocks to them in XCD order
     int64_t maxb = nt + cap / (block_particles > 0 ? block_particles : 4096) + 1 + 8;
     size_t off = 0;
@@ -109,6 +116,15 @@ extern "C" int64_t lpa_sort_workspace_bytes(const lpa_grid *g, int64_t capacity)
     if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0) return -1;  // nz > 1 selects the 3-D tiles
     // sized for the smallest block size accepted by lpa_sort_tiles_2d
     return ws_layout(g, capacity, 1024, nullptr, nullptr);
+}
+
+extern "C" int64_t lpa_sort_workspace_bytes_ranks(const lpa_grid *g, int64_t capacity, int32_t stripe_ranks_) {
+    if (!g || g->nx <= 0 || g->ny <= 0 || capacity < 0 || stripe_ranks_ < 0) return -1;
+    return ws_layout(g, capacity, 1024, nullptr, nullptr, stripe_ranks_);
+}
+
+extern "C" const int32_t *lpa_sort_deepest_cell(void *workspace) {
+    return workspace ? &((SortHdr *)workspace)->deepest : nullptr;
 }
 
 extern "C" int32_t lpa_sort_stripe_ranks(const lpa_grid *g, int64_t capacity) {
@@ -318,11 +334,17 @@ __global__ void __launch_bounds__(256) k_cell_scan(const int32_t *__restrict__ c
 __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict__ cell_cnt,
                                                       unsigned long long *masks, int32_t *apre,
                                                       int32_t *cell_off, int pad_min, int32_t *tile_cnt_out,
-                                                      int32_t *pad_ranks, const int RMAX) {
+                                                      int32_t *pad_ranks, const int RMAX, SortHdr *hdr) {
     __shared__ unsigned long long s_mask[4];
     const int c = threadIdx.x, lane = c & 63, wv = c >> 6;
     const long t = blockIdx.x;
     const int n = cell_cnt[t * TCELLS + c];
+    {   // the deepest cell of the store (for the caller: cells deeper than RMAX leave the stripes)
+        int m = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if (lane == 0 && m > 0) atomicMax(&hdr->deepest, m);
+    }
     int run = 0, ra = 0;
     for (int r = 0; r < RMAX; r++) {
         unsigned long long m = __ballot(n > r);
@@ -346,6 +368,7 @@ __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict_
     int ex = block_excl_scan256(extra, &total_extra);
     cell_off[t * TCELLS + c] = run + ex;
     if (c == 0) {
+        if (total_extra > 0) atomicAdd(&hdr->tail, total_extra);
         // (the padded tile total is rounded up to a whole wave: tile starts stay multiples of 64 slots)
         if (tile_cnt_out) tile_cnt_out[t] = (run + total_extra + 63) & ~63;
         if (pad_ranks) pad_ranks[t] = ra;
@@ -446,6 +469,7 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
         // the per-particle kernels were launched from slot prefix_hint on: everything below must be covered by the
         // tile-ordered prefix, or those particles would be lost -- refuse instead (k_tile_scan keeps the bit)
         hdr->overflow = prefix_hint > (ok ? (long)hdr->n_live : 0l) ? SORT_BAD_HINT : 0;
+        hdr->deepest = hdr->tail = 0;
         hdr->magic = SORT_MAGIC;
         hdr->prev_ntiles = ntiles;
     }
@@ -568,7 +592,8 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     if (dim == 2) gg.nz = 1;
     SortWs w;
     // the work-block table is sized for the slots the DESTINATION can hold (a padded order has more slots than src->n)
-    int64_t need = ws_layout(&gg, dst->n, block_particles, (char *)workspace, &w);
+    LPA_REQUIRE(out->stripe_ranks >= 0, "%s: lpa_tiling.stripe_ranks < 0", name);
+    int64_t need = ws_layout(&gg, dst->n, block_particles, (char *)workspace, &w, out->stripe_ranks);
     if (need > workspace_bytes) {
         lpa_set_error("%s: workspace %lld B < %lld B", name, (long long)workspace_bytes, (long long)need);
         return LPA_ERR_WORKSPACE;
@@ -613,7 +638,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         // the padded tile totals come out of the stripe tables: tables first, then the scan; the destination's
         // positions start as NaN, so every slot the scatter does not fill is a hole
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre, w.cell_off,
-                           LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks, w.rmax);
+                           LPA_PAD_MIN_CELLS, w.tile_cnt, w.pad_ranks, w.rmax, w.hdr);
         LPA_CHECK_LAUNCH("k_stripe_table (padded)");
         if (hipMemsetAsync(dv.x, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
             hipMemsetAsync(dv.y, 0xFF, sizeof(double) * (size_t)dst->n, st) != hipSuccess ||
@@ -630,7 +655,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     LPA_CHECK_LAUNCH("k_tile_scan");
     if (order == LPA_ORDER_STRIPED)
         hipLaunchKernelGGL(k_stripe_table, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.masks, w.apre,
-                           w.cell_off, 0, (int32_t *)nullptr, w.pad_ranks, w.rmax);
+                           w.cell_off, 0, (int32_t *)nullptr, w.pad_ranks, w.rmax, w.hdr);
     else if (!padded)
         hipLaunchKernelGGL(k_cell_scan, dim3(w.ntiles), dim3(256), 0, st, w.cell_cnt, w.tile_off, w.cell_off);
     LPA_CHECK_LAUNCH("k_cell_scan / k_stripe_table");
@@ -677,7 +702,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     out->slot_class = nullptr;   // the caller may attach a class array (and must then set class_init)
     out->class_init = 0;
     out->reloc_stats = nullptr;
-    out->reserved2_ = 0;
+    out->stripe_ranks = w.rmax;   // what the layout used: pass it again (or 0 for the default rule) with the same workspace
     return LPA_OK;
 }
 

@@ -386,30 +386,37 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def _ws(self, sp):
         if sp["ws"] is None:
             cap = sp["data"].shape[1]
-            sp["alt"] = torch.empty_like(sp["data"])
-            nbytes = self.L.lpa_sort_workspace_bytes(self._g(), cap)
+            if sp.get("alt") is None or sp["alt"].shape != sp["data"].shape:
+                sp["alt"] = torch.empty_like(sp["data"])
+            nbytes = self.L.lpa_sort_workspace_bytes_ranks(self._g(), cap, sp.get("stripe_ranks", 0))
             cnt = torch.zeros(4, dtype=torch.int32, device=self.device)   # 0: overflow, 1: arrivals
             sp["ws"] = {"sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
                         "overflow": torch.empty(max(cap, 1), dtype=torch.int32, device=self.device),
                         "counters": cnt, "count": cnt[0:1], "tiling": _lib.lpa_tiling(), "mig": None}
         return sp["ws"]
 
-    def sort(self, i):
+    deep_tail_fraction = 0.005   # see PicEngine2D.sort
+
+    def sort(self, i, _again=False):
         """tile-bin species ``i`` (replaces sort_particles_patches_3d, core/sort/cpu3d.c); drops dead
-        slots; one host sync for the live count"""
+        slots; one host sync for the live count.  Re-sizes the striped ranks for a store that is deeper than its mean
+        over all tiles says (PicEngine2D.sort)"""
         sp = self.species[i]
         ws = self._ws(sp)
         cap = sp["data"].shape[1]
         src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
         ws["tiling"].prefix_hint = int(sp["n_sorted"]) if sp["tiling"] is not None else 0
+        ws["tiling"].stripe_ranks = sp.get("stripe_ranks", 0)
         check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), self.block_particles, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
-        n_live = _lib.sort_result(self.L, ws["sort"])
+        n_live, deepest, tail = _lib.sort_result(self.L, ws["sort"], True)
         area = self.arrival_area()
         cnts = ws["counters"].tolist()
-        if sp["tiling"] is not None:
+        if _again:
+            pass
+        elif sp["tiling"] is not None:
             self._adapt_sort_interval(sp, cnts[0], sp["n_sorted"])   # cnts[0]: the overflow list of the last push
         else:
             self._first_sort_interval(sp)
@@ -434,6 +441,12 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         sp["since"] = 0
         self._rho_sorted()
         self._reset_free_slots(ws)
+        used = ws["tiling"].stripe_ranks
+        if not _again and used < 1024 and self.order == _lib.LPA_ORDER_STRIPED and \
+                tail > self.deep_tail_fraction * max(n_live, 1):
+            sp["stripe_ranks"] = min(1024, deepest + deepest // 4)
+            sp["ws"], sp["tiling"] = None, None
+            self.sort(i, _again=True)
 
     FREE_SLOT_DEPTH = 64
 

@@ -298,13 +298,22 @@ def _expected_tile_sequence(cnt, order, rmax=128):
     return np.concatenate(exp)
 
 
-@pytest.mark.parametrize("order", [STRIPED, CELL_MAJOR, 2, 3])
-def test_cell_sort_properties(order):
+def keys_of(x, y, nx, ny, dx, dy):
+    """tile-major cell key of the 2-D tile sort (tiles of 8 x 32 cells)"""
+    tiles_y = (ny + 31) // 32
+    i = np.clip(np.floor(x / dx + 0.5).astype(int), 0, nx - 1)
+    j = np.clip(np.floor(y / dy + 0.5).astype(int), 0, ny - 1)
+    return ((i // 8) * tiles_y + j // 32) * 256 + (i % 8) * 32 + (j % 32)
+
+
+@pytest.mark.parametrize("order,adapt", [(STRIPED, False), (CELL_MAJOR, False), (2, False), (3, False), (STRIPED, True)])
+def test_cell_sort_properties(order, adapt):
     """reference tests/test_sort.py:38-117,201-251 restated for the device sort: per-cell counts
     equal a numpy histogram, tiles are contiguous and in order, inside a tile the particles are cell
     by cell (CELL_MAJOR), rank by rank with cells ascending inside a rank (STRIPED) or the same inside each
     column of the tile (COLUMN), the multiset of live particles is preserved, dead / NaN particles are dropped,
-    re-sorting keeps the keys."""
+    re-sorting keeps the keys.  ``adapt``: the engine re-sizes the striped ranks for the deep cells (its default; the
+    other cases switch that off and pin the un-striped tail of the default rule)."""
     import torch
     from lambdapic_amd.engine import PicEngine2D
     rng = np.random.default_rng(9)
@@ -326,17 +335,23 @@ def test_cell_sort_properties(order):
     eng.add_species(QE, ME, capacity=2 * n if order == 2 else n + 64)     # LPA_ORDER_PADDED stores holes
     eng.species[0].upload([p])
     assert eng.species[0].n == live.sum()
+    if not adapt:
+        eng.deep_tail_fraction = 2.0
     eng.sort(0)
     rmax = int(eng.L.lpa_sort_stripe_ranks(eng._g(), eng.species[0].capacity))
-    assert 32 <= rmax < 2000 // 3           # the deep cells below (667 particles each) do leave the stripes
+    assert 32 <= rmax < 2000 // 3           # the deep cells below (~600 live particles each) do leave the default stripes
+    used = eng._ws[id(eng.species[0])]["tiling"].stripe_ranks
+    if adapt:                               # 3 % of the store lay beyond them: re-sized for the deepest cell + 25 %
+        deep = np.bincount(keys_of(p.x[live], p.y[live], nx, ny, dx, dy)).max()
+        assert used == 1024 and deep * 1.25 > 512 and eng.species[0].stripe_ranks == deep + deep // 4
+        rmax = used
+    else:
+        assert used == rmax
     out = eng.species[0].download()
     assert out["x"].size == live.sum()
-    tiles_y = (ny + 31) // 32
 
     def keys(x, y):
-        i = np.clip(np.floor(x / dx + 0.5).astype(int), 0, nx - 1)
-        j = np.clip(np.floor(y / dy + 0.5).astype(int), 0, ny - 1)
-        return ((i // 8) * tiles_y + j // 32) * 256 + (i % 8) * 32 + (j % 32)
+        return keys_of(x, y, nx, ny, dx, dy)
 
     k_out = keys(out["x"], out["y"])
     assert np.array_equal(np.bincount(k_out), np.bincount(keys(p.x[live], p.y[live])))

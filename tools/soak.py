@@ -22,6 +22,7 @@ ap.add_argument("--c3", type=int, default=3000)
 ap.add_argument("--c5", type=int, default=400)
 ap.add_argument("--fraction", type=float, default=None, help="engine.overflow_sort_fraction (0: fixed sort interval)")
 ap.add_argument("--min-interval", type=int, default=None)
+ap.add_argument("--deep-tail", type=float, default=None, help="engine.deep_tail_fraction (2: never re-size the stripes)")
 a = ap.parse_args()
 LAM, NC, C = T.LAM, T.NC, T.C
 
@@ -31,6 +32,8 @@ def tune(eng):
         eng.overflow_sort_fraction = a.fraction
     if a.min_interval is not None:
         eng.min_sort_interval = a.min_interval
+    if a.deep_tail is not None:
+        eng.deep_tail_fraction = a.deep_tail
 
 
 def c3(nsteps):
@@ -130,7 +133,7 @@ def c5(nsteps):
         umax = max(float(sp["data"][3, : sp["n"]].nan_to_num().abs().max()) for sp in eng.species)
         print(f"C5 slab step {it + 1:4d}: {1e3 * (time.perf_counter() - t0) / 40:.2f} ms/step (check included), alive "
               f"{d['nalive']}, max|ux| {umax:.1f}, sort_interval_now {[sp.get('sort_interval_now') for sp in eng.species]}, "
-              f"rho steps {dict(eng.rho_steps)}", flush=True)
+              f"rho steps {dict(eng.rho_steps)}, stripe ranks {[sp.get('stripe_ranks', 0) for sp in eng.species]}", flush=True)
         t0 = time.perf_counter()
     assert T._unique_ids(eng) and 0 < live()[2] <= n_init and checks == nsteps // 40
     print("C5 soak ok", flush=True)
