@@ -65,7 +65,7 @@ def build_engine(args, comm, device, nx=None):
         g = lambda: torch.randn(hi - lo, device=device, dtype=torch.float64, generator=gen)
         s.arr("x")[lo:hi] = eng.x0 + ((cell // ny).double() + r() - 0.5) * dx
         s.arr("y")[lo:hi] = ((cell % ny).double() + r() - 0.5) * dy
-        ux, uy, uz = g() * u_th, g() * u_th, g() * u_th
+        ux, uy, uz = g() * u_th + getattr(args, "drift", 0.0), g() * u_th, g() * u_th
         s.arr("ux")[lo:hi], s.arr("uy")[lo:hi], s.arr("uz")[lo:hi] = ux, uy, uz
         s.arr("inv_gamma")[lo:hi] = 1.0 / torch.sqrt(1 + ux * ux + uy * uy + uz * uz)
         s.arr("w")[lo:hi] = n_c * dx * dy / ppc
@@ -658,6 +658,7 @@ def main():
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
+    ap.add_argument("--drift", type=float, default=0.0, help="mean u_x of the plasma (off-benchmark: a relativistic flow)")
     ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread per axis (C2: 0.0442 = 1 keV); "
                                                               "other values: off-benchmark sweeps (tools/sweep_uth2d.sh)")
     ap.add_argument("--inv-gamma", default="recomputed", choices=["recomputed", "streamed"],

@@ -15,6 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=128); ap.add_argument("--ny", type=int, default=256)
 ap.add_argument("--nz", type=int, default=256); ap.add_argument("--ppc", type=int, default=4)
 ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--foil", type=float, default=0.0, help="target thickness in um (0: everything beyond x = 1 um)")
+ap.add_argument("--deep-tail", type=float, default=None, help="engine.deep_tail_fraction (2: never re-size the stripes)")
 a = ap.parse_args()
 C = constants.C_LIGHT
 lam = 0.8e-6
@@ -22,11 +24,13 @@ dx, dy, dz = lam / 20, lam / 10, lam / 10                    # example/laser-tar
 nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
 sim = Simulation3D(a.nx, a.ny, a.nz, dx, dy, dz, npatch_x=a.nx // 32, npatch_y=a.ny // 64, npatch_z=a.nz // 64,
                    random_seed=1, sort_interval=10)
-dens = lambda x, y, z: np.where(x > 1e-6, nc, 0.0)           # :37-42
+dens = lambda x, y, z: np.where((x > 1e-6) & ((a.foil == 0) | (x < 1e-6 + a.foil * 1e-6)), nc, 0.0)       # :37-42
 sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=a.ppc, momentum_sigma=0.01))
 sim.add_species(Species("p", charge=1, mass=1836.0, density=dens, ppc=a.ppc))
 t0 = time.perf_counter()
 sim.initialize()
+if a.deep_tail is not None:
+    sim.engine.deep_tail_fraction = a.deep_tail
 t_init = time.perf_counter() - t0
 laser = GaussianLaser3D(a0=10.0, l0=lam, w0=2e-6, ctau=3e-6, x0=6e-6)   # :44-51 (shortened pulse)
 sim.run(12, callbacks=[laser])
