@@ -52,6 +52,10 @@ static inline GridV make_gridv(const lpa_grid *g, int dim) {
     return v;
 }
 
+#ifndef LPA_ABS_OFFSETS
+#define LPA_ABS_OFFSETS 0
+#endif
+
 struct PartV {
     long n;
     double *x, *y, *z, *ux, *uy, *uz, *ig, *w;

@@ -363,6 +363,16 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         if ((part == LPA_PART_EDGE) != edge) return;  // block-uniform
     }
     const int begin = blk_begin[wb], end = blk_end[wb];
+    // The attribute and scratch arrays, rebased to the block's first slot (once per workgroup, on the scalar unit): the
+    // 32-bit byte offsets of the accesses below are relative to it -- a work block holds a few thousand slots -- so a
+    // store is limited by the int32 slot numbers of the sort's tables (2^31), not by 2^32 bytes per array (2^29 slots).
+    const int rb = LPA_ABS_OFFSETS ? 0 : begin;     // (LPA_ABS_OFFSETS=1: the old absolute offsets, for A/B timing builds)
+    p.x += rb; p.y += rb; p.ux += rb; p.uy += rb; p.uz += rb; p.w += rb;
+    if (!NOIG) p.ig += rb;
+    if (DEFER) {
+#pragma unroll
+        for (int c = 0; c < 7; c++) sc.a[c] += rb;
+    }
     const int tx0 = (tile / tiles_y) * TX, ty0 = (tile % tiles_y) * TY;  // first node of the tile
     const int rx0 = tx0 - HALO, ry0 = ty0 - HALO;                            // first node of the region
     const int lane = threadIdx.x & 63;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     // software pipeline: the seven attribute loads of the NEXT iteration are issued before the current
     // particle is processed, so their HBM latency hides under the VALU / LDS work of this one
     // particle attributes are addressed as uniform base + 32-bit byte offset (the sorted range is far
-    // below 2^29 particles): one VALU instruction per access instead of a 64-bit address each
+    // relative to the work block's first slot): one VALU instruction per access instead of a 64-bit address each
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
     auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
     // the particle attributes stream through once per step: non-temporal (see lpa_particles3d.hip)
@@ -430,7 +440,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     {
         const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
         if (ip0 < end) {
-            const uint32_t o = (uint32_t)ip0 * 8u;
+            const uint32_t o = (uint32_t)(ip0 - rb) * 8u;
             nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
             if (!NOIG) nig = ldp(p.ig, o);
             nw = ldp(p.w, o);
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         {
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {
-                const uint32_t o = (uint32_t)ipn * 8u;
+                const uint32_t o = (uint32_t)(ipn - rb) * 8u;
                 nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o); nuz = ldp(p.uz, o);
                 if (!NOIG) nig = ldp(p.ig, o);
                 nw = ldp(p.w, o);
@@ -581,7 +591,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 report_absorbed_2d(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                    k.dep.c_rho * w);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
-            const uint32_t o = (uint32_t)ip * 8u;
+            const uint32_t o = (uint32_t)(ip - rb) * 8u;
             // diagnostic builds (wrong physics; profiles/r03_k1_streams.txt): what the attribute stores cost
 #if defined(LPA_ABLATE_NO_PSTORE)          // none at all
             if (xs == 1.2345e300) { stp(p.x, o, xs); stp(p.y, o, ys); stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); }
@@ -615,7 +625,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             const bool fast = valid && !cross && ix1 - tx0 == lxn && iy1 - ty0 == lyn;
             if (valid && !fast) {              // changed cell, or not (any more) in its slot's cell: second pass
                 const int slot = atomicAdd(&s_ncross, 1);
-                const uint32_t o = (uint32_t)(begin + slot) * 8u;
+                const uint32_t o = (uint32_t)(begin - rb + slot) * 8u;
                 st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
                 st(sc.a[4], o, uz); st(sc.a[5], o, ig); st(sc.a[6], o, w);
             }
@@ -667,7 +677,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (valid) {
                 if (DEFER && (cross || (RELOC && mover))) {
                     const int slot = atomicAdd(&s_ncross, 1);
-                    const uint32_t o = (uint32_t)(begin + slot) * 8u;
+                    const uint32_t o = (uint32_t)(begin - rb + slot) * 8u;
 #ifndef LPA_ABLATE_NO_PARK   // diagnostic build (wrong physics, with LPA_ABLATE_NO_PASS2): what the seven parking stores cost
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
                     st(sc.a[4], o, uz); if (!NOIG) st(sc.a[5], o, ig); st(sc.a[6], o, w);
@@ -783,7 +793,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (RELOC) info = rl.aux_info[begin + i];
             const bool first = RELOC && i == (int)threadIdx.x;
             if (!(info & RL_DEP) && !(first && (info & RL_MOV))) continue;
-            const uint32_t o = (uint32_t)(begin + i) * 8u;
+            const uint32_t o = (uint32_t)(begin - rb + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
                          uz = ld(sc.a[4], o), ig = NOIG ? inv_gamma_of(ux, uy, uz) : ld(sc.a[5], o), w = ld(sc.a[6], o);
 #if LPA_K1_VARIANTS
@@ -832,7 +842,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         if (RELOC) {
             // the mover's state (as parked: before the periodic fold) goes to slot `dst`
             auto seat = [&](int dst) {
-                const uint32_t od = (uint32_t)dst * 8u;
+                const uint32_t od = (uint32_t)(dst - rb) * 8u;
                 double x = m[0], y = m[1];
                 finish_position_2d(x, y, k);
                 st(p.x, od, x); st(p.y, od, y);
@@ -1003,7 +1013,7 @@ extern "C" int lpa_push_deposit_tiled_part_2d(const lpa_grid *g, const lpa_parti
                 "lpa_push_deposit_tiled_2d: c*dt exceeds a cell (CFL); use lpa_push_deposit_2d");
     if (t->n_sorted == 0) return LPA_OK;
     // particle attributes are addressed with 32-bit byte offsets inside the kernel
-    LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_2d: more than 2^29 particles in one store");
+    LPA_REQUIRE(p->n < (1ll << 31) - 1, "lpa_push_deposit_tiled_2d: more than 2^31 - 2 slots in one store");
     GridV gv = make_gridv(g, 2);
     PartV pv = make_partv(p);
     PushK k = make_pushk(pp, g);

@@ -497,11 +497,21 @@ __device__ __forceinline__ void tile_flush(const GridV &g, int wrap, const TileC
 // On entry the images are ready and *s_ncross == 0 (both behind a barrier); on exit every lane has issued its LDS atomics
 // (the caller puts a barrier before it reads s_j or starts the next species).
 template <bool DEFER, bool RHO>
-__device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, const PushK3 &k, const int begin,
-                                             const int end, const Scratch8 &sc, uint32_t *overflow,
+__device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, const PushK3 &k, const int begin,
+                                             const int end, const Scratch8 &sc_, uint32_t *overflow,
                                              uint32_t *overflow_count, const TileCtx &tc,
                                              double (*s_j)[K13Geom<RHO>::R3N], double *s_eb, int *s_ncross_p) {
     constexpr int NJ = K13Geom<RHO>::NJ, R3ZS = K13Geom<RHO>::R3ZS;
+    // the attribute and scratch arrays rebased to the pass' first slot (uniform: scalar adds): the 32-bit byte offsets
+    // below are relative to it, so a store is limited by the sort's int32 slot numbers (2^31), not by 2^32 bytes per array
+    PartV p = p_;
+    Scratch8 sc = sc_;
+    const int rb = LPA_ABS_OFFSETS ? 0 : begin;     // (LPA_ABS_OFFSETS=1: the old absolute offsets, for A/B timing builds)
+    p.x += rb; p.y += rb; p.z += rb; p.ux += rb; p.uy += rb; p.uz += rb; p.ig += rb; p.w += rb;
+    if (DEFER) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) sc.a[c] += rb;
+    }
     const int *t0 = tc.t0, *r0 = tc.r0, *e0 = tc.e0;
     const int lane = threadIdx.x & 63;
     int &s_ncross = *s_ncross_p;
@@ -523,7 +533,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, con
     {
         const int ip0 = begin + (int)(threadIdx.x & ~63u) + lane;
         if (ip0 < end) {
-            const uint32_t o = (uint32_t)ip0 * 8u;
+            const uint32_t o = (uint32_t)(ip0 - rb) * 8u;
             nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nz_ = ldp(p.z, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o);
             nuz = ldp(p.uz, o); nig = ldp(p.ig, o); nw = ldp(p.w, o);
         }
@@ -539,7 +549,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, con
         {
             const int ipn = ip + (int)blockDim.x;
             if (ipn < end) {
-                const uint32_t o = (uint32_t)ipn * 8u;
+                const uint32_t o = (uint32_t)(ipn - rb) * 8u;
                 nx_ = ldp(p.x, o); ny_ = ldp(p.y, o); nz_ = ldp(p.z, o); nux = ldp(p.ux, o); nuy = ldp(p.uy, o);
                 nuz = ldp(p.uz, o); nig = ldp(p.ig, o); nw = ldp(p.w, o);
             }
@@ -669,13 +679,13 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, con
             if (finish_position_3d(xs, ys, zs, k) && k.absorbed)    // rare: a particle reached an open face
                 report_absorbed(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                 (z + vz * 0.5 * k.dt - g.z0) * inv_dz, k.c_rho * w);
-            const uint32_t o = (uint32_t)ip * 8u;
+            const uint32_t o = (uint32_t)(ip - rb) * 8u;
             stp(p.x, o, xs); stp(p.y, o, ys); stp(p.z, o, zs);
             stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); stp(p.ig, o, ig);
         }
         if (DEFER && cross) {   // parked: deposited by the second pass (unfolded position: the window is local)
             const int slot = atomicAdd(&s_ncross, 1);
-            const uint32_t o = (uint32_t)(begin + slot) * 8u;
+            const uint32_t o = (uint32_t)(begin - rb + slot) * 8u;
             st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, z); st(sc.a[3], o, ux); st(sc.a[4], o, uy);
             st(sc.a[5], o, uz); st(sc.a[6], o, ig); st(sc.a[7], o, w);
             continue;
@@ -727,7 +737,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p, con
 #else
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
 #endif
-            const uint32_t o = (uint32_t)(begin + i) * 8u;
+            const uint32_t o = (uint32_t)(begin - rb + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), z = ld(sc.a[2], o), ux = ld(sc.a[3], o),
                          uy = ld(sc.a[4], o), uz = ld(sc.a[5], o), ig = ld(sc.a[6], o), w = ld(sc.a[7], o);
             const double vx = ux * LPA_C * ig, vy = uy * LPA_C * ig, vz = uz * LPA_C * ig;
@@ -986,7 +996,7 @@ extern "C" int lpa_push_deposit_tiled_part_3d(const lpa_grid *g, const lpa_parti
     LPA_REQUIRE(p->is_dead == nullptr,
                 "lpa_push_deposit_tiled_3d: tile-binned stores carry no is_dead array (dead = NaN x)");
     if (t->n_sorted == 0) return LPA_OK;
-    LPA_REQUIRE(p->n < (1ll << 29), "lpa_push_deposit_tiled_3d: more than 2^29 particles in one store");
+    LPA_REQUIRE(p->n < (1ll << 31) - 1, "lpa_push_deposit_tiled_3d: more than 2^31 - 2 slots in one store");
     MultiArgs m;
     m.ns = 1;
     MultiSp &d = m.s[0];
@@ -1020,8 +1030,8 @@ extern "C" int lpa_push_deposit_tiled_multi_3d(const lpa_grid *g, int32_t nspeci
         LPA_REQUIRE(t[s]->tiles_x == (g->nx + T3X - 1) / T3X && t[s]->tiles_y == (g->ny + T3Y - 1) / T3Y &&
                         t[s]->tiles_z == (g->nz + T3Z - 1) / T3Z,
                     "lpa_push_deposit_tiled_multi_3d: tiling does not match the grid");
-        LPA_REQUIRE(p[s]->is_dead == nullptr && p[s]->n < (1ll << 29),
-                    "lpa_push_deposit_tiled_multi_3d: tile-binned stores carry no is_dead array and hold < 2^29 particles");
+        LPA_REQUIRE(p[s]->is_dead == nullptr && p[s]->n < (1ll << 31) - 1,
+                    "lpa_push_deposit_tiled_multi_3d: tile-binned stores carry no is_dead array and hold < 2^31 - 1 slots");
         LPA_REQUIRE(pp[s]->wrap == pp[0]->wrap && pp[s]->flags == pp[0]->flags && pp[s]->dt == pp[0]->dt,
                     "lpa_push_deposit_tiled_multi_3d: the species of one launch share wrap, flags and dt");
         if (t[s]->n_sorted == 0) continue;

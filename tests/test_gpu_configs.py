@@ -324,3 +324,61 @@ def test_c5_slab_full_size_two_species():
     assert checks == 6
     assert 0 < live()[2] <= n_init
     assert _unique_ids(eng)          # through 24 steps, 3 re-sorts and the absorption at six faces
+
+
+# ---- a store with more than 2^29 slots (an MI355X holds 2^31 of them; the arrays are then > 4 GB each) ---------------
+def test_store_beyond_2_29_slots():
+    """The tiled kernels address the attribute arrays with 32-bit byte offsets -- relative to the work block since round
+    3, so that a store is limited by the sort's int32 slot numbers, not by 4 GB per array.  554 M electrons in one store:
+    every slot is pushed exactly once (low and high slots alike move by v dt), nothing is lost, the charge is exact."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 130 * 2 ** 30:
+        pytest.skip("needs ~110 GB of device memory")
+    nx = ny = 1024
+    ppc = 528
+    n = nx * ny * ppc
+    assert n > (1 << 29) + (1 << 23)
+    dx = dy = LAM / 20
+    dt = 0.95 / (C * np.sqrt(dx ** -2 + dy ** -2))
+    eng = PicEngine2D(nx, ny, dx, dy, device="cuda:0", sort_interval=20)
+    q, m = -constants.E_CHARGE, constants.M_E
+    eng.add_species(q, m, capacity=n + 4096)
+    s = eng.species[0].cset
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    chunk = 1 << 25
+    for lo in range(0, n, chunk):
+        hi = min(lo + chunk, n)
+        cell = torch.arange(lo, hi, device="cuda") // ppc
+        r = lambda: torch.rand(hi - lo, device="cuda", dtype=torch.float64, generator=gen)
+        s.arr("x")[lo:hi] = ((cell // ny).double() + r() - 0.5) * dx
+        s.arr("y")[lo:hi] = ((cell % ny).double() + r() - 0.5) * dy
+        for a in ("ux", "uy", "uz"):
+            s.arr(a)[lo:hi] = torch.randn(hi - lo, device="cuda", dtype=torch.float64, generator=gen) * 0.05
+        s.arr("w")[lo:hi] = 1e-3 * NC * dx * dy / ppc          # tenuous: the fields stay negligible
+        s.id[lo:hi] = torch.arange(lo, hi, device="cuda")
+        del cell
+    s.arr("inv_gamma")[:n] = torch.rsqrt(1 + s.arr("ux")[:n] ** 2 + s.arr("uy")[:n] ** 2 + s.arr("uz")[:n] ** 2)
+    eng.species[0].n = n
+    eng.step(dt)                                   # sorts: the slots are final for the next 19 steps
+    sp = eng.species[0]
+    assert sp.n_sorted == n and sp.n >= n
+    c = sp.cset
+    picks = torch.cat([torch.arange(0, 4096, device="cuda"), torch.arange((1 << 29) - 2048, (1 << 29) + 2048, device="cuda"),
+                       torch.arange(n - 4096, n, device="cuda")])
+    before = {a: c.arr(a)[picks].clone() for a in ("x", "y", "ux", "uy", "uz")}
+    ids = c.id[picks].clone()
+    eng.step(dt)
+    c = eng.species[0].cset
+    assert torch.equal(c.id[picks], ids)           # no sort in between: same particles in the same slots
+    ig = torch.rsqrt(1 + before["ux"] ** 2 + before["uy"] ** 2 + before["uz"] ** 2)
+    for a, u, L, d in (("x", "ux", nx * dx, dx), ("y", "uy", ny * dy, dy)):
+        move = c.arr(a)[picks] - before[a]
+        move = move - torch.round(move / L) * L     # periodic fold
+        want = before[u] * ig * C * dt
+        assert (move - want).abs().max().item() <= 1e-6 * d          # (the field of a 1e-3 n_c plasma bends it a little)
+        assert (move.abs() > 1e-4 * d).float().mean().item() > 0.95   # they did move, high slots included
+    d = eng.diagnostics()
+    assert d["nalive"][0] == n
+    qw = q * c.arr("w")[:n].sum().item()
+    charge = eng.grid.view("rho").sum().item() * dx * dy
+    assert abs(charge - qw) <= 1e-12 * abs(qw)
