@@ -102,7 +102,8 @@ typedef struct {
     int32_t class_init;
     int32_t stripe_ranks;      /* IN, lpa_sort_tiles_*: ranks per cell the striped orders keep in stripes -- 0 = the default rule
                                   (lpa_sort_stripe_ranks), else the number the workspace was sized for with
-                                  lpa_sort_workspace_bytes_ranks (rounded up to a power of two in [32, 1024]).  OUT: the number
+                                  lpa_sort_workspace_bytes_ranks (rounded up to a power of two in [32, 16384], as long as the table -- 32 bytes per
+                                  tile and rank -- stays below 1 GiB).  OUT: the number
                                   used.  A cell's particles beyond it follow cell by cell behind the stripes of their tile,
                                   where the lanes of a wave share a cell and the LDS atomics of the tiled kernels serialise:
                                   a store whose deepest cell (lpa_sort_deepest_cell) exceeds it wants a larger one */

@@ -14,6 +14,7 @@ import os as _os
 LIB_PATH = Path(_os.environ.get("LPA_LIB_PATH", HERE / "liblambdapic_amd.so"))
 
 LPA_TILE_X = 8
+LPA_MAX_STRIPE_RANKS = 16384      # what lpa_tiling.stripe_ranks may ask for (the default rule stops at 1024)
 LPA_TILE_Y = 32
 LPA_ORDER_CELL_MAJOR = 0
 LPA_ORDER_STRIPED = 1

@@ -39,8 +39,11 @@ static int stripe_ranks(const lpa_grid *g, int64_t cap, int ntiles, int requeste
     (void)g;
     const int64_t per_cell = (cap + (int64_t)ntiles * 256 - 1) / ((int64_t)ntiles * 256);
     const int64_t want = requested > 0 ? requested : 2 * per_cell;
+    // the default rule stops at 1024; a request may go on to 16384 as long as the mask table (32 bytes per tile and rank)
+    // stays below 1 GiB
+    const int64_t rcap = requested > 0 ? 16384 : 1024;
     int r = 32;
-    while (r < want && r < 1024) r *= 2;
+    while (r < want && r < rcap && (requested <= 0 || r < 1024 || (int64_t)ntiles * (2 * r) * 32 <= (1ll << 30))) r *= 2;
     return r;
 }
 static_assert(TCELLS == 256, "one workgroup thread per tile cell");
@@ -488,6 +491,7 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
 #endif
 constexpr int ST_THREADS = LPA_ST_THREADS, ST_PT = LPA_ST_PT, ST_W = LPA_ST_W;   // threads, particles per thread and chunk, window slots
 constexpr int ST_BITS = 65536;                               // destination slots covered by one bitmap pass
+constexpr int ST_RUN = 4, ST_SLICES = 16;                    // chunks per run, workgroups per tile (see the kernel)
 
 __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     AttrList al, const SortHdr *hdr, const int32_t *__restrict__ tile_off_prev,
@@ -497,11 +501,17 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     const int32_t *__restrict__ cell_cnt, int rmax) {
     __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
+    __shared__ int s_band[2];                   // lowest / highest destination of the chunk inside its own tile
     if (!hdr->prev_valid || hdr->overflow) return;
     const int t = blockIdx.x;
     const int sb = tile_off_prev[t], se = tile_off_prev[t + 1];
     const int db0 = tile_off[t], de0 = tile_off[t + 1];   // destination range of the same tile
-    for (int c0 = sb; c0 < se; c0 += ST_THREADS * ST_PT) {
+    // gridDim.y workgroups share a deep tile: runs of ST_RUN consecutive chunks go round the slices (the chunks are
+    // independent of each other).  A tile of up to ST_RUN chunks -- C2's hold two -- belongs to slice 0 alone, which is
+    // dispatched first (tile index fastest); the other slices' workgroups of such a tile return at once.
+    int ci = 0;
+    for (int c0 = sb; c0 < se; c0 += ST_THREADS * ST_PT, ci++) {
+        if ((ci / ST_RUN) % (int)gridDim.y != (int)blockIdx.y) continue;   // block-uniform
         int dest[ST_PT];                                   // -1: dead, dropped
 #pragma unroll
         for (int j = 0; j < ST_PT; j++) {
@@ -512,9 +522,28 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                 if (ck != KEY_DEAD) dest[j] = (int)dest_slot(ck, rank[ip], striped, cell_base, tile_off, cell_off, masks, apre, rmax, cell_cnt);
             }
         }
-        // (a tile with more than ST_BITS particles is covered in several passes)
-        for (int db = db0; db < de0 || db == db0; db += ST_BITS) {
-            const int de = min(de0, db + ST_BITS);
+        // The band of the tile's destination range this chunk writes to.  Ranks follow the order of the source (the
+        // count pass walks a tile chunk by chunk), so a chunk of a deep tile lands in a narrow band of it: walking the
+        // whole range for every chunk is quadratic in the tile's population (16 tiles of 10^6 particles: 160 ms a sort).
+        if (threadIdx.x == 0) { s_band[0] = de0; s_band[1] = db0 - 1; }
+        __syncthreads();
+        {
+            int lo = de0, hi = db0 - 1;
+#pragma unroll
+            for (int j = 0; j < ST_PT; j++)
+                if (dest[j] >= db0 && dest[j] < de0) { lo = min(lo, dest[j]); hi = max(hi, dest[j]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+            if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&s_band[0], lo); atomicMax(&s_band[1], hi); }
+        }
+        __syncthreads();
+        // (window starts stay on the tile's own ST_W grid: whole lines whatever the band)
+        const int bb = s_band[1] >= s_band[0] ? db0 + (s_band[0] - db0) / ST_W * ST_W : db0;
+        const int be = s_band[1] >= s_band[0] ? s_band[1] + 1 : db0;
+        bool first_pass = true;
+        // (a band of more than ST_BITS slots is covered in several passes)
+        for (int db = bb; db < be || first_pass; db += ST_BITS) {
+            const int de = min(be, db + ST_BITS);
             for (int i = threadIdx.x; i < ST_BITS / 32; i += ST_THREADS) s_bits[i] = 0u;
             __syncthreads();
 #pragma unroll
@@ -544,7 +573,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                         v[j] = dest[j] >= 0 ? src[ip] : 0.0;
                     }
                     // changed tile: the scattered store (a few per cent of the particles), first pass only
-                    if (db == db0 && dest[j] >= 0 && (dest[j] < db0 || dest[j] >= de0)) dst[dest[j]] = v[j];
+                    if (first_pass && dest[j] >= 0 && (dest[j] < db0 || dest[j] >= de0)) dst[dest[j]] = v[j];
                 }
                 for (int wb = db; wb < de; wb += ST_W, phase++) {
                     double *buf = s_val[LPA_ST_NBUF == 2 ? (phase & 1) : 0];
@@ -565,7 +594,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
                 }
             }
             __syncthreads();   // before the bitmap / buffers are reused
-            if (de0 <= db0) break;
+            first_pass = false;
         }
     }
 }
@@ -672,7 +701,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         const int striped = order == LPA_ORDER_COLUMN ? 2 + (dim == 3 ? 4 : 5)
                                                       : (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
-        hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
+        hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles, ST_SLICES), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
                            w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt, w.rmax);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
         const long nb = (src->n + 255) / 256 - first_block;

@@ -548,13 +548,15 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         sp.steps_since_sort = 0
         self._rho_sorted()
         self._reset_free_slots(ws, ws["tiling"].tiles_x, ws["tiling"].tiles_y, _lib.LPA_TILE_X)
-        used = ws["tiling"].stripe_ranks
-        if not _again and used < 1024 and self.order == _lib.LPA_ORDER_STRIPED and \
-                tail > self.deep_tail_fraction * max(n_live, 1):
-            sp.stripe_ranks = min(1024, deepest + deepest // 4)
+        used, want = ws["tiling"].stripe_ranks, min(_lib.LPA_MAX_STRIPE_RANKS, deepest + deepest // 4)
+        if not _again and want > used and used < getattr(sp, "stripe_ranks_limit", 1 << 30) and \
+                self.order == _lib.LPA_ORDER_STRIPED and tail > self.deep_tail_fraction * max(n_live, 1):
+            sp.stripe_ranks = want
             self._ws.pop(id(sp), None)              # a workspace with room for the deeper stripes; its header knows
             sp.tiling = None                        # nothing of this order: a full sort, no prefix hint
             self.sort(ispec, _again=True)
+            if self._ws[id(sp)]["tiling"].stripe_ranks < want:     # the table would not fit (1 GiB): do not ask again
+                sp.stripe_ranks_limit = self._ws[id(sp)]["tiling"].stripe_ranks
 
     FREE_SLOT_DEPTH = 64
 

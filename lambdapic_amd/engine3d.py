@@ -441,12 +441,14 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         sp["since"] = 0
         self._rho_sorted()
         self._reset_free_slots(ws)
-        used = ws["tiling"].stripe_ranks
-        if not _again and used < 1024 and self.order == _lib.LPA_ORDER_STRIPED and \
-                tail > self.deep_tail_fraction * max(n_live, 1):
-            sp["stripe_ranks"] = min(1024, deepest + deepest // 4)
+        used, want = ws["tiling"].stripe_ranks, min(_lib.LPA_MAX_STRIPE_RANKS, deepest + deepest // 4)
+        if not _again and want > used and used < sp.get("stripe_ranks_limit", 1 << 30) and \
+                self.order == _lib.LPA_ORDER_STRIPED and tail > self.deep_tail_fraction * max(n_live, 1):
+            sp["stripe_ranks"] = want
             sp["ws"], sp["tiling"] = None, None
             self.sort(i, _again=True)
+            if sp["ws"]["tiling"].stripe_ranks < want:             # the table would not fit (1 GiB): do not ask again
+                sp["stripe_ranks_limit"] = sp["ws"]["tiling"].stripe_ranks
 
     FREE_SLOT_DEPTH = 64
 
