@@ -405,9 +405,9 @@ int32_t lpa_sort_stripe_ranks(const lpa_grid *g, int64_t capacity);
 /* workspace size for an explicit number of striped ranks (lpa_tiling.stripe_ranks; 0 = the default rule): a store that
  * fills only part of the grid -- a solid target in an empty box -- is deeper where it is occupied than its mean */
 int64_t lpa_sort_workspace_bytes_ranks(const lpa_grid *g, int64_t capacity, int32_t stripe_ranks);
-/* striped orders, two numbers of the last sort (device pointer inside the workspace, next to lpa_sort_live_count: one
- * read-back serves all): [0] the largest number of particles one cell held, [1] the particles that lay beyond the striped
- * ranks */
+/* three numbers of the last sort (device pointer inside the workspace, next to lpa_sort_live_count: one read-back serves
+ * all): [0] the largest number of particles one cell held and [1] the particles that lay beyond the striped ranks (striped
+ * orders), [2] the tiles that hold at least one particle */
 const int32_t *lpa_sort_deepest_cell(void *workspace);
 int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,

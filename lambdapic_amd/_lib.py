@@ -238,8 +238,8 @@ def lib():
 def sort_result(L, wsbuf, with_deepest=False):
     """live count (slots, for a padded order) of the tile sort that just ran through workspace ``wsbuf`` (a device
     uint8 tensor); raises when the device refused the sort (``lpa_sort_overflow``).  One host sync.
-    ``with_deepest``: (live count, particles in the deepest cell, particles beyond the striped ranks) from the same
-    read-back."""
+    ``with_deepest``: (live count, particles in the deepest cell, particles beyond the striped ranks, tiles in use,
+    work blocks) from the same read-back."""
     ptr = wsbuf.data_ptr()
     hdr = wsbuf[:64].view(_torch().int32).tolist()
     ovf = hdr[(L.lpa_sort_overflow(ptr) - ptr) // 4]
@@ -252,7 +252,7 @@ def sort_result(L, wsbuf, with_deepest=False):
                         "sort's result)"))
     live = hdr[(L.lpa_sort_live_count(ptr) - ptr) // 4]
     k = (L.lpa_sort_deepest_cell(ptr) - ptr) // 4
-    return (live, hdr[k], hdr[k + 1]) if with_deepest else live
+    return (live, hdr[k], hdr[k + 1], hdr[k + 2], hdr[1]) if with_deepest else live
 
 
 def _torch():

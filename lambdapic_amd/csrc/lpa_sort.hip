@@ -61,7 +61,8 @@ struct SortHdr {      // first 64 bytes of the workspace
     int32_t overflow;
     int32_t deepest;  // striped orders: the largest number of particles one cell holds (k_stripe_table) ...
     int32_t tail;     // ... and the particles that lie beyond the striped ranks (cell by cell behind their tile's stripes)
-    int32_t pad[7];
+    int32_t tiles_in_use;   // tiles that hold at least one particle (k_tile_scan)
+    int32_t pad[6];
 };
 constexpr int32_t SORT_OVF_SLOTS = 1, SORT_OVF_BLOCKS = 2, SORT_BAD_HINT = 4;
 constexpr int32_t SORT_MAGIC = 0x4c504131;
@@ -278,8 +279,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
         __syncthreads();
     }
     int32_t off = s_part[tid] - sum, boff = s_blk[tid] - sb;
+    int used = 0;
     for (int t = lo; t < hi; t++) {
         int32_t c = tile_cnt[t];
+        used += c > 0;
         tile_off[t] = off;
         int nb = (c + block_particles - 1) / block_particles;
         for (int b = 0; b < nb && boff + b < max_blocks; b++) {
@@ -292,6 +295,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, const int32_t *t
         off += c;
         boff += nb;
     }
+    if (used) atomicAdd(&hdr->tiles_in_use, used);
     if (tid == 1023) {
         tile_off[ntiles] = s_part[1023];
         hdr->n_live = s_part[1023];
@@ -472,7 +476,7 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
         // the per-particle kernels were launched from slot prefix_hint on: everything below must be covered by the
         // tile-ordered prefix, or those particles would be lost -- refuse instead (k_tile_scan keeps the bit)
         hdr->overflow = prefix_hint > (ok ? (long)hdr->n_live : 0l) ? SORT_BAD_HINT : 0;
-        hdr->deepest = hdr->tail = 0;
+        hdr->deepest = hdr->tail = hdr->tiles_in_use = 0;
         hdr->magic = SORT_MAGIC;
         hdr->prev_ntiles = ntiles;
     }

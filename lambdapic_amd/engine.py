@@ -500,7 +500,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
                                        ws["sort"].numel(), bp, self.order,
                                        C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
-        n_live, deepest, tail = _lib.sort_result(self.L, ws["sort"], True)    # sync point (once per sort_interval steps)
+        n_live, deepest, tail, _, _ = _lib.sort_result(self.L, ws["sort"], True)    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]
         if _again:

@@ -52,7 +52,7 @@ class FusedStepMixin:
                 self.sort(i)
             self._decide_phase()
         d.continuity = int(self._no_rho)
-        d.fuse_species = int(self.dim == 3 and self.fuse_species)
+        d.fuse_species = int(self.dim == 3 and self.fuse_species and self.fuse_worthwhile())
         if self.absorb and self.rho_continuity and self._rho_available():
             lst, cnt, cap = self._absorbed_bufs()
             d.absorbed, d.absorbed_count, d.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap

@@ -7,12 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lambdapic_amd import constants
 from lambdapic_amd.engine3d import PicEngine3D
 
-def run(n3, tiled, steps=24):
+def run(n3, tiled, steps=24, ppc=8):
     lam = 0.8e-6
     d3 = (lam / 20, lam / 10, lam / 10)
     dt = 0.95 / (constants.C_LIGHT * np.sqrt(sum(d ** -2 for d in d3)))
     eng = PicEngine3D(*n3, *d3, 3, tiled=tiled, sort_interval=10)
-    ppc, dev = 8, eng.device
+    dev = eng.device
     n = int(np.prod(n3)) * ppc
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     cell = torch.arange(n, device=dev) // ppc
@@ -36,8 +36,11 @@ def run(n3, tiled, steps=24):
     d = eng.diagnostics()
     return ms, n, d["field_energy"], d["kinetic"][0]
 
-for n3 in ((64, 256, 256), (64, 254, 250)):
-    for tiled in (True, False):
-        ms, n, fe, ke = run(n3, tiled)
+cases = [((64, 256, 256), 8, (True, False)), ((64, 254, 250), 8, (True, False))]
+if len(sys.argv) > 1:          # nx ny nz ppc: one shape on the tiled path (e.g. deep tiles: 16 16 64 1024)
+    cases = [(tuple(int(v) for v in sys.argv[1:4]), int(sys.argv[4]), (True,))]
+for n3, ppc, modes in cases:
+    for tiled in modes:
+        ms, n, fe, ke = run(n3, tiled, ppc=ppc)
         print(f"{n3} tiled={tiled}: {ms:.2f} ms/step, {n / ms / 1e6:.2f} G particle-updates/s, field energy {fe:.6e}, kinetic {ke:.9e}", flush=True)
         torch.cuda.empty_cache()
