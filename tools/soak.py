@@ -20,6 +20,7 @@ import test_gpu_configs as T                                                    
 ap = argparse.ArgumentParser()
 ap.add_argument("--c3", type=int, default=3000)
 ap.add_argument("--c5", type=int, default=400)
+ap.add_argument("--c4", type=int, default=0, help="steps of the LWFA config (4096 x 512 cells, window at c with injection)")
 ap.add_argument("--fraction", type=float, default=None, help="engine.overflow_sort_fraction (0: fixed sort interval)")
 ap.add_argument("--min-interval", type=int, default=None)
 ap.add_argument("--deep-tail", type=float, default=None, help="engine.deep_tail_fraction (2: never re-size the stripes)")
@@ -68,6 +69,42 @@ def c3(nsteps):
               f"{dict(eng.rho_steps)}", flush=True)
     assert T._unique_ids(eng) and 0 < sum(eng.diagnostics()["nalive"]) <= n_init
     print("C3 soak ok", flush=True)
+
+
+def c4(nsteps):
+    from lambdapic_amd.laser import SimpleLaser2D
+    from lambdapic_amd.simulation import MovingWindow, Simulation, Species
+    nx, ny, ppc = 4096, 512, 16
+    dx = dy = LAM / 20
+    sim = Simulation(nx, ny, dx, dy, npatch_x=nx // 64, npatch_y=ny // 64, random_seed=1, sort_interval=20)
+    Ly = ny * dy
+    dens = lambda x, y: np.where((x > 1e-6) & (y > 1e-6) & (y < Ly - 1e-6), 0.01 * NC, 0.0)
+    sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=ppc))
+    sim.initialize()
+    eng = sim.engine
+    tune(eng)
+    cbs = [SimpleLaser2D(a0=2.0, w0=5e-6, ctau=5e-6, l0=LAM), MovingWindow(velocity=C, start_time=0.03 * sim.Lx / C)]
+    sim.run(5, callbacks=cbs)
+    n_init = T._live_qw_2d(eng)[2]
+    ledger = T._Ledger(sim)
+    done = 0
+    while done < nsteps:
+        seg = min(500, nsteps - done)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        checks, absorbed = T._run_checked(sim, cbs, nsteps=seg, every=50, ledger=ledger)
+        torch.cuda.synchronize()
+        done += seg
+        d = eng.diagnostics()
+        umax = max(float(sp.cset.arr("ux")[: sp.n].nan_to_num().abs().max()) for sp in eng.species)
+        print(f"C4 step {done:5d}: {1e3 * (time.perf_counter() - t0) / seg:.3f} ms/step (checks included), alive "
+              f"{d['nalive']}, shifts {ledger.shifts}, dropped {ledger.dropped}, injected {ledger.injected}, checks {checks}, "
+              f"max|ux| {umax:.1f}, sort_interval_now {[getattr(sp, 'sort_interval_now', None) for sp in eng.species]}, "
+              f"stripe ranks {[getattr(sp, 'stripe_ranks', 0) for sp in eng.species]}", flush=True)
+    n_end = sum(eng.diagnostics()["nalive"])
+    assert T._unique_ids(eng) and 0 < n_end <= n_init - ledger.dropped + ledger.injected
+    assert n_end >= n_init - ledger.dropped + ledger.injected - 0.02 * n_init
+    print("C4 soak ok", flush=True)
 
 
 def c5(nsteps):
@@ -141,6 +178,9 @@ def c5(nsteps):
 
 if a.c3:
     c3(a.c3)
+    torch.cuda.empty_cache()
+if a.c4:
+    c4(a.c4)
     torch.cuda.empty_cache()
 if a.c5:
     c5(a.c5)
