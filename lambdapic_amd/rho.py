@@ -8,8 +8,9 @@ LDS array is what bounds those kernels).  Rules (VERDICT r2
 
 * a REAL deposit (the reference's kernel, everything zeroed first) re-anchors rho in every step in which a store is
   sorted -- which includes the step after an upload from the host mirrors, an append / injection and a window shift,
-  all of which force a sort -- and in every step while ``rho_continuity_blocked`` is set (a callback reads per-species
-  rho between the species' deposits, or the split pusher path deposits with the standalone kernel);
+  all of which force a sort -- and in every step while ``rho_continuity_blocked`` is set (the stage loops set it for the steps in
+  which a callback reads per-species rho between the species' deposits, and while the split pusher path deposits with
+  the standalone kernel);
 * particles the kernels absorb at open faces are reported on the device (``lpa_push_params.absorbed``) in every step and
   their charge leaves rho at the start of the next continuity step (``lpa_rho_absorbed``) -- exactly when the
   reference's next deposit no longer contains them.  The list holds 1/32 of the particle slots (at least 65 536

@@ -671,15 +671,18 @@ class Simulation:
         # host callbacks may read ex_part..bz_part
         self.engine.write_part_eb = any(not getattr(cb, "device_native", False) for cb in callbacks or [])
         unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
-        # rho between two sorts comes from the continuity equation (rho.py) unless a callback reads per-species rho
-        # between the species' deposits, or the split path deposits with the standalone kernel
-        self.engine.rho_continuity_blocked = bool(table.get("current_deposition")) or not unified
+        # rho between two sorts comes from the continuity equation (rho.py) unless the split path deposits with the
+        # standalone kernel, or -- decided step by step below -- a callback reads per-species rho between the deposits
+        self.engine.rho_continuity_blocked = not unified
         self._run_stage(table, "init")
         # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         for self.istep in range(self.itime, self.itime + nsteps):
             self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
+            # a step in which a 'current_deposition' callback runs deposits rho for real (it reads per-species rho); the
+            # steps in between carry rho on from there (a density diagnostic every 100 steps costs one real deposit)
+            self.engine.rho_continuity_blocked = not unified or bool(self._triggered(table.get("current_deposition", [])))
             self._run_stage(table, "start")
             if self._fused_step(table, unified):
                 self._run_stage(table, "maxwell_2")

@@ -317,8 +317,7 @@ class Simulation3D:
         if nsteps is None:
             nsteps = int(sim_time / self.dt) if sim_time is not None else \
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
-        # a callback between the species' deposits reads per-species rho: every step deposits rho for real
-        self.engine.rho_continuity_blocked = bool(table.get("current_deposition"))
+        self.engine.rho_continuity_blocked = False      # (decided step by step below)
         self._run_stage(table, "init")
         # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
@@ -326,6 +325,8 @@ class Simulation3D:
         eng = self.engine
         for self.istep in range(self.itime, self.itime + nsteps):
             self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
+            # a callback between the species' deposits reads per-species rho: that step deposits rho for real
+            self.engine.rho_continuity_blocked = bool(self._triggered(table.get("current_deposition", [])))
             self._run_stage(table, "start")
             if self._fused_step(table):
                 self._run_stage(table, "maxwell_2")

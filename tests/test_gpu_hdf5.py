@@ -349,3 +349,23 @@ def test_two_ranks_write_the_files_of_one(tmp_path):
                 assert np.abs(x - y).max() <= 1e-9 * max(np.abs(x).max(), 1e-300), (n, k)
     with h5lite.File(two / "sel" / "000008.h5", "r") as f:
         assert f["jx"].shape == (13, 16) and f.attrs["slice"] == "[3::5, ::2]"
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_a_sparse_density_diagnostic_costs_one_real_deposit_per_trigger(dim):
+    """a 'current_deposition' callback needs per-species rho only in the steps it runs in: those deposit rho for real, the
+    others keep advancing it with the continuity equation -- and the density it extracts is the one an every-step
+    diagnostic sees at the same step"""
+    def run(interval):
+        sim, e = _sim2() if dim == 2 else _sim3()
+        sim.add_species([Species("ions", charge=1, mass=1836.0, density=(lambda *x: np.full_like(x[0], 1.5e25)), ppc=2)])
+        sim.initialize()
+        sim.engine.overflow_sort_fraction = 0
+        cb = ExtractSpeciesDensity(sim, e, interval=interval)
+        sim.run(13, callbacks=[cb])
+        return cb.density, dict(sim.engine.rho_steps)
+    often, steps_often = run(1)
+    sparse, steps_sparse = run(6)                  # triggers at itime 0, 6, 12
+    assert steps_often["continuity"] == 0
+    assert steps_sparse["continuity"] >= 8 and steps_sparse["anchor"] <= 5      # 3 triggers + the sorts
+    assert np.abs(sparse - often).max() <= 1e-10 * np.abs(often).max()
