@@ -600,6 +600,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if self._noig():
             pp.flags |= _lib.LPA_PUSH_NO_IG
             sp.ig_stale = True
+        else:
+            sp.refresh_inv_gamma()      # this launch streams inv_gamma: it must be there (a no-op unless it is stale)
         return pp
 
     def _noig(self):

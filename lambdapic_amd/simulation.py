@@ -611,6 +611,20 @@ class Simulation:
         if host_cbs:
             self.upload()
 
+    def _host_callback_near(self, host_cbs, last_step):
+        """will a mirror-reading callback run before the NEXT push overwrites ex_part ... bz_part -- in this step, or in
+        the next one's stages before its push?  (An interval FUNCTION cannot be asked about the next step: taken as yes.)"""
+        for cb in host_cbs:
+            iv = getattr(cb, "interval", 1)
+            if callable(iv) or interval_triggered(self, iv) or (last_step and getattr(cb, "stage", "") == "final"):
+                return True
+            if isinstance(iv, float):
+                if ((self.time + self.dt) % iv) < self.dt:
+                    return True
+            elif (self.itime + 1) % int(iv) == 0:
+                return True
+        return False
+
     def update_lists(self):
         """the reference re-points its facades at the (possibly re-allocated) per-patch arrays
         (`simulation/simulation.py:781-824`; called by RestartDump.load).  The facades here hold no array
@@ -668,8 +682,10 @@ class Simulation:
         if nsteps is None:
             nsteps = int(sim_time / self.dt) if sim_time is not None else \
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
-        # host callbacks may read ex_part..bz_part
-        self.engine.write_part_eb = any(not getattr(cb, "device_native", False) for cb in callbacks or [])
+        # host callbacks may read ex_part..bz_part: the pushes that precede one write them (decided step by step below;
+        # registering a diagnostic that runs every 100 steps must not cost six more attribute streams in every step)
+        host_cbs = [cb for cb in callbacks or [] if not getattr(cb, "device_native", False)]
+        self.engine.write_part_eb = bool(host_cbs)
         unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
         # rho between two sorts comes from the continuity equation (rho.py) unless the split path deposits with the
         # standalone kernel, or -- decided step by step below -- a callback reads per-species rho between the deposits
@@ -678,11 +694,13 @@ class Simulation:
         # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
-        for self.istep in range(self.itime, self.itime + nsteps):
+        self.itime_end = self.itime + nsteps
+        for self.istep in range(self.itime, self.itime_end):
             self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
             # a step in which a 'current_deposition' callback runs deposits rho for real (it reads per-species rho); the
             # steps in between carry rho on from there (a density diagnostic every 100 steps costs one real deposit)
             self.engine.rho_continuity_blocked = not unified or bool(self._triggered(table.get("current_deposition", [])))
+            self.engine.write_part_eb = self._host_callback_near(host_cbs, self.istep == self.itime_end - 1)
             self._run_stage(table, "start")
             if self._fused_step(table, unified):
                 self._run_stage(table, "maxwell_2")

@@ -306,3 +306,42 @@ def test_loading_rules_density_min_ppc_function_and_species_classes():
     assert sim.engine.species[1].n == nx * ny * 3 and sim.engine.species[2].n == 0
     sim.run(2)
     assert sim.engine.diagnostics()["nalive"] == [len(d["x"]), nx * ny * 3, 0]
+
+
+def test_part_eb_is_written_for_the_steps_a_host_callback_reads():
+    """ex_part ... bz_part (the fields the last push saw, `core/particles.py:63-67`) cost the fused kernel six more
+    attribute streams and keep inv_gamma in the stream: they are written in the pushes that precede a mirror-reading
+    callback, not in every step of a run that registers one -- and what the callback reads is what an always-writing run
+    shows it"""
+    def run(always):
+        sim, _ = _sim(nx=32, ny=32, ppc=8)
+        sim.initialize()
+        if always:
+            sim._host_callback_near = lambda cbs, last: True
+        seen, flags = [], []
+
+        @callback("end", interval=7)
+        def reader(s):
+            parts = [p.particles[0] for p in s.patches]
+            ids = np.concatenate([q._id.view(np.uint64)[~q.is_dead] for q in parts])
+            o = np.argsort(ids)
+            seen.append({a: np.concatenate([getattr(q, a)[~q.is_dead] for q in parts])[o]
+                         for a in ("ex_part", "ey_part", "bz_part", "inv_gamma", "ux")})
+
+        @callback("maxwell_2", interval=1)
+        def watch(s):
+            flags.append((s.itime, bool(s.engine.write_part_eb), bool(s.engine.species[0].ig_stale)))
+        watch.device_native = True
+        sim.run(16, callbacks=[reader, watch])
+        return seen, flags
+    a, flags = run(False)
+    b, flags_b = run(True)
+    assert [f[1] for f in flags] == [it % 7 in (0, 6) for it in range(16)]      # the trigger step and the one before it
+    assert all(f[1] for f in flags_b)
+    assert any(f[2] for f in flags) and not any(f[2] for f in flags_b)            # lazy inv_gamma ran in between
+    assert len(a) == len(b) == 3
+    for x, y in zip(a, b):
+        for k in x:
+            scale = max(np.abs(y[k]).max(), 1e-300)
+            assert np.abs(x[k] - y[k]).max() <= 1e-9 * scale, k
+    assert np.abs(a[-1]["ex_part"]).max() > 0 and np.abs(a[0]["ex_part"]).max() == 0     # (the first push saw E = 0)
