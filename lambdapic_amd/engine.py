@@ -207,6 +207,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # the fused kernel stores the gathered E/B per particle (the reference's ex_part..bz_part side
         # effect, +48 B/particle) only when asked: callbacks that read them set this
         self.write_part_eb = False
+        self.sort_part_eb = False  # the sort moves ex_part ... bz_part too (see sort)
         self._rho_init()     # rho from the continuity equation between two real deposits: see rho.py
 
     def _rho_available(self):
@@ -487,7 +488,11 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         sp = self.species[ispec]
         ws = self._ws_checked(sp)
         src, dst = sp.cset, sp.other()
-        ps, pd = src.cstruct(sp.n), dst.cstruct(dst.capacity)
+        # ex_part ... bz_part are what the LAST push saw: the push that follows this sort rewrites them (or nobody reads
+        # them before one that does, Simulation._host_callback_near), so the sort leaves them where they are -- six of
+        # thirteen attribute arrays.  The split pusher path has stages between the sort and its interpolation: it asks
+        # for them to travel (sort_part_eb).
+        ps, pd = src.cstruct(sp.n, eb=self.sort_part_eb), dst.cstruct(dst.capacity, eb=self.sort_part_eb)
         if self._noig():          # nobody reads the store's inv_gamma before a refresh: the sort need not move it
             ps.inv_gamma = pd.inv_gamma = None
             sp.ig_stale = True

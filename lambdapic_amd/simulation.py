@@ -690,6 +690,7 @@ class Simulation:
         # rho between two sorts comes from the continuity equation (rho.py) unless the split path deposits with the
         # standalone kernel, or -- decided step by step below -- a callback reads per-species rho between the deposits
         self.engine.rho_continuity_blocked = not unified
+        self.engine.sort_part_eb = not unified      # (pusher-stage callbacks may look at ex_part between sort and interpolation)
         self._run_stage(table, "init")
         # a RestartDump among the callbacks may ask for a last dump (signal): simulation.py:889-894
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
