@@ -70,6 +70,7 @@ constexpr int32_t SORT_MAGIC = 0x4c504131;
 struct SortWs {
     SortHdr *hdr;
     int32_t *cell_cnt, *cell_off, *cell_base, *tile_cnt, *tile_off, *tile_off_prev, *blk_tile, *blk_begin, *blk_end, *apre;
+    int32_t *run_off;   // [ntiles + 1] k_scatter_tiled's work list: first run (ST_RUN chunks of the old tile) of each tile
     int32_t *pad_ranks;
     unsigned long long *masks;
     uint32_t *key, *rank;
@@ -105,6 +106,7 @@ static int64_t ws_layout(const lpa_grid *g, int64_t cap, int32_t block_particles
     p = take(sizeof(int32_t) * nt); if (w) w->pad_ranks = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off = (int32_t *)p;
     p = take(sizeof(int32_t) * (nt + 1)); if (w) w->tile_off_prev = (int32_t *)p;
+    p = take(sizeof(int32_t) * (nt + 1)); if (w) w->run_off = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_tile = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_begin = (int32_t *)p;
     p = take(sizeof(int32_t) * maxb); if (w) w->blk_end = (int32_t *)p;
@@ -350,7 +352,9 @@ __global__ void __launch_bounds__(256) k_stripe_table(const int32_t *__restrict_
         int m = n;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-        if (lane == 0 && m > 0) atomicMax(&hdr->deepest, m);
+        // (65 000 tiles x 4 waves on one address would cost more than the table: most waves see a maximum that is
+        // already there -- a stale read only lets a redundant atomic through)
+        if (lane == 0 && m > *(volatile int32_t *)&hdr->deepest) atomicMax(&hdr->deepest, m);
     }
     int run = 0, ra = 0;
     for (int r = 0; r < RMAX; r++) {
@@ -466,22 +470,6 @@ struct AttrList {
     double *dst[16];
 };
 
-__global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile_off_prev, int ntiles,
-                            long src_n, long prefix_hint) {
-    for (int t = threadIdx.x; t <= ntiles; t += blockDim.x) tile_off_prev[t] = tile_off[t];
-    if (threadIdx.x == 0) {
-        bool ok = hdr->magic == SORT_MAGIC && hdr->prev_ntiles == ntiles && hdr->n_live <= src_n;
-        hdr->prev_valid = ok ? 1 : 0;
-        hdr->prev_n = ok ? hdr->n_live : 0;
-        // the per-particle kernels were launched from slot prefix_hint on: everything below must be covered by the
-        // tile-ordered prefix, or those particles would be lost -- refuse instead (k_tile_scan keeps the bit)
-        hdr->overflow = prefix_hint > (ok ? (long)hdr->n_live : 0l) ? SORT_BAD_HINT : 0;
-        hdr->deepest = hdr->tail = hdr->tiles_in_use = 0;
-        hdr->magic = SORT_MAGIC;
-        hdr->prev_ntiles = ntiles;
-    }
-}
-
 #ifndef LPA_ST_NBUF
 #define LPA_ST_NBUF 2
 #endif
@@ -495,27 +483,75 @@ __global__ void k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile
 #endif
 constexpr int ST_THREADS = LPA_ST_THREADS, ST_PT = LPA_ST_PT, ST_W = LPA_ST_W;   // threads, particles per thread and chunk, window slots
 constexpr int ST_BITS = 65536;                               // destination slots covered by one bitmap pass
-constexpr int ST_RUN = 4, ST_SLICES = 16;                    // chunks per run, workgroups per tile (see the kernel)
+constexpr int ST_RUN = 4;                                    // chunks of an old tile per workgroup (see the kernel)
+
+__global__ void __launch_bounds__(1024) k_save_prev(SortHdr *hdr, const int32_t *tile_off, int32_t *tile_off_prev,
+                                                    int32_t *run_off, int ntiles, long src_n, long prefix_hint) {
+    for (int t = threadIdx.x; t <= ntiles; t += blockDim.x) tile_off_prev[t] = tile_off[t];
+    {   // the tile-staged scatter's work list: a tile of c chunks is ceil(c / ST_RUN) runs, an empty tile none
+        __shared__ int32_t s_runs[1024];
+        const int tid = threadIdx.x, per = (ntiles + 1023) / 1024;
+        const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
+        constexpr int RUN_SLOTS = ST_RUN * ST_THREADS * ST_PT;
+        int32_t sum = 0;
+        for (int t = lo; t < hi; t++) sum += (tile_off[t + 1] - tile_off[t] + RUN_SLOTS - 1) / RUN_SLOTS;
+        s_runs[tid] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int32_t a = tid >= o ? s_runs[tid - o] : 0;
+            __syncthreads();
+            s_runs[tid] += a;
+            __syncthreads();
+        }
+        int32_t off = s_runs[tid] - sum;
+        for (int t = lo; t < hi; t++) {
+            run_off[t] = off;
+            off += (tile_off[t + 1] - tile_off[t] + RUN_SLOTS - 1) / RUN_SLOTS;
+        }
+        if (tid == 1023) run_off[ntiles] = s_runs[1023];
+    }
+    if (threadIdx.x == 0) {
+        bool ok = hdr->magic == SORT_MAGIC && hdr->prev_ntiles == ntiles && hdr->n_live <= src_n;
+        hdr->prev_valid = ok ? 1 : 0;
+        hdr->prev_n = ok ? hdr->n_live : 0;
+        // the per-particle kernels were launched from slot prefix_hint on: everything below must be covered by the
+        // tile-ordered prefix, or those particles would be lost -- refuse instead (k_tile_scan keeps the bit)
+        hdr->overflow = prefix_hint > (ok ? (long)hdr->n_live : 0l) ? SORT_BAD_HINT : 0;
+        hdr->deepest = hdr->tail = hdr->tiles_in_use = 0;
+        hdr->magic = SORT_MAGIC;
+        hdr->prev_ntiles = ntiles;
+    }
+}
 
 __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
     AttrList al, const SortHdr *hdr, const int32_t *__restrict__ tile_off_prev,
     const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank, const int32_t *__restrict__ cell_base,
     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ cell_off,
     const unsigned long long *__restrict__ masks, const int32_t *__restrict__ apre, int striped,
-    const int32_t *__restrict__ cell_cnt, int rmax) {
+    const int32_t *__restrict__ cell_cnt, int rmax, const int32_t *__restrict__ run_off, int ntiles) {
     __shared__ double s_val[LPA_ST_NBUF][ST_W]; // double buffered: one barrier per (attribute, window)
     __shared__ uint32_t s_bits[ST_BITS / 32];   // slots of the tile's destination range this chunk fills
     __shared__ int s_band[2];                   // lowest / highest destination of the chunk inside its own tile
     if (!hdr->prev_valid || hdr->overflow) return;
-    const int t = blockIdx.x;
-    const int sb = tile_off_prev[t], se = tile_off_prev[t + 1];
+    // One workgroup per RUN of ST_RUN chunks of an old tile (k_save_prev's list: a tile of up to ST_RUN chunks -- C2's hold
+    // two -- is one workgroup as before, a deep tile is shared by as many as it has runs, an empty tile costs none; the
+    // chunks are independent of each other).  The launch covers an upper bound of the runs.
+    const int w = blockIdx.x;
+    if (w >= run_off[ntiles]) return;
+    int t;
+    {   // the tile this run belongs to: last t with run_off[t] <= w (uniform binary search)
+        int lo_ = 0, hi_ = ntiles;
+        while (hi_ - lo_ > 1) {
+            const int mid = (lo_ + hi_) >> 1;
+            if (run_off[mid] <= w) lo_ = mid; else hi_ = mid;
+        }
+        t = lo_;
+    }
+    const int run = w - run_off[t];
+    const int sb = tile_off_prev[t] + run * (ST_RUN * ST_THREADS * ST_PT);
+    const int se = min(tile_off_prev[t + 1], sb + ST_RUN * ST_THREADS * ST_PT);
     const int db0 = tile_off[t], de0 = tile_off[t + 1];   // destination range of the same tile
-    // gridDim.y workgroups share a deep tile: runs of ST_RUN consecutive chunks go round the slices (the chunks are
-    // independent of each other).  A tile of up to ST_RUN chunks -- C2's hold two -- belongs to slice 0 alone, which is
-    // dispatched first (tile index fastest); the other slices' workgroups of such a tile return at once.
-    int ci = 0;
-    for (int c0 = sb; c0 < se; c0 += ST_THREADS * ST_PT, ci++) {
-        if ((ci / ST_RUN) % (int)gridDim.y != (int)blockIdx.y) continue;   // block-uniform
+    for (int c0 = sb; c0 < se; c0 += ST_THREADS * ST_PT) {
         int dest[ST_PT];                                   // -1: dead, dropped
 #pragma unroll
         for (int j = 0; j < ST_PT; j++) {
@@ -646,7 +682,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
     const long hint = out->prefix_hint;
     LPA_REQUIRE(hint >= 0 && hint <= src->n, "%s: prefix_hint outside the source", name);
     const long first_block = hint / 256;       // per-particle kernels start here (see lpa_tiling.prefix_hint)
-    hipLaunchKernelGGL(k_save_prev, dim3(1), dim3(1024), 0, st, w.hdr, w.tile_off, w.tile_off_prev, w.ntiles,
+    hipLaunchKernelGGL(k_save_prev, dim3(1), dim3(1024), 0, st, w.hdr, w.tile_off, w.tile_off_prev, w.run_off, w.ntiles,
                        (long)src->n, hint);
     LPA_CHECK_LAUNCH("k_save_prev");
     if (src->n > 0) {
@@ -705,8 +741,11 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         const int striped = order == LPA_ORDER_COLUMN ? 2 + (dim == 3 ? 4 : 5)
                                                       : (int)(order == LPA_ORDER_STRIPED || order == LPA_ORDER_PADDED);
         // tile-ordered prefix of the source (re-sorts): staged per tile; does nothing on a first sort
-        hipLaunchKernelGGL(k_scatter_tiled, dim3(w.ntiles, ST_SLICES), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
-                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt, w.rmax);
+        // (runs <= tiles in use + slots / run size: the bound below; workgroups beyond the list return at once)
+        const long runs_max = (long)w.ntiles + src->n / ((long)ST_RUN * ST_THREADS * ST_PT) + 1;
+        hipLaunchKernelGGL(k_scatter_tiled, dim3((unsigned)runs_max), dim3(ST_THREADS), 0, st, al, w.hdr, w.tile_off_prev,
+                           w.key, w.rank, w.cell_base, w.tile_off, w.cell_off, w.masks, w.apre, striped, w.cell_cnt, w.rmax,
+                           w.run_off, w.ntiles);
         LPA_CHECK_LAUNCH("k_scatter_tiled");
         const long nb = (src->n + 255) / 256 - first_block;
         if (nb > 0) {
