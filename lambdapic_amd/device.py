@@ -130,14 +130,24 @@ class ParticleSet:
 
     def __init__(self, capacity, device, with_eb=False):
         self.capacity = int(capacity)
-        names = list(PART_CORE) + (list(PART_EB) if with_eb else [])
-        self.data = torch.empty((len(names), self.capacity), dtype=torch.float64, device=device)
-        self.names = names
+        self.core = list(PART_CORE)
+        self.names = self.core + (list(PART_EB) if with_eb else [])
+        # ``data``: the core attributes.  ex_part ... bz_part (what the last push saw, for host callbacks) get their six
+        # rows when somebody first asks for them -- a run without mirror-reading callbacks never does, and a set holds
+        # 64 instead of 112 bytes per slot
+        self.data = torch.empty((len(self.core), self.capacity), dtype=torch.float64, device=device)
+        self.eb = None
         self.id = torch.zeros(self.capacity, dtype=torch.int64, device=device)
         self.with_eb = with_eb
 
     def arr(self, name) -> torch.Tensor:
-        return self.data[self.names.index(name)]
+        if name in PART_EB:
+            if not self.with_eb:
+                raise KeyError(name)
+            if self.eb is None:
+                self.eb = torch.zeros((len(PART_EB), self.capacity), dtype=torch.float64, device=self.data.device)
+            return self.eb[PART_EB.index(name)]
+        return self.data[self.core.index(name)]
 
     def cstruct(self, n, eb=True) -> _lib.lpa_particles:
         p = _lib.lpa_particles()
@@ -197,6 +207,9 @@ class DeviceParticles:
         new = ParticleSet(int(capacity), self.device, self.with_eb)
         old = self.cset
         new.data[:, : self.n].copy_(old.data[:, : self.n])
+        if old.eb is not None:
+            new.arr(PART_EB[0])
+            new.eb[:, : self.n].copy_(old.eb[:, : self.n])
         new.id[: self.n].copy_(old.id[: self.n])
         self.sets = [new, None]
         self.cur = 0
@@ -229,8 +242,9 @@ class DeviceParticles:
         self.refresh_inv_gamma()
         st = {k: v for k, v in self.__dict__.items() if k not in ("sets", "tiling", "device")}
         s = self.cset
-        st.update(device=str(self.device), names=list(s.names), data_host=to_host(s.data[:, : self.n]),
-                  id_host=to_host(s.id[: self.n]))
+        kept = list(s.core) + (list(PART_EB) if s.eb is not None else [])
+        rows = s.data[:, : self.n] if s.eb is None else torch.cat([s.data[:, : self.n], s.eb[:, : self.n]])
+        st.update(device=str(self.device), names=kept, data_host=to_host(rows), id_host=to_host(s.id[: self.n]))
         return st
 
     def __setstate__(self, st):
@@ -238,8 +252,10 @@ class DeviceParticles:
         self.__dict__.update(st)
         self.device = restore_device(st["device"])
         s = ParticleSet(self.capacity, self.device, self.with_eb)
-        assert s.names == names
-        s.data[:, : self.n].copy_(torch.from_numpy(data))
+        assert names[: len(s.core)] == s.core and len(names) in (len(s.core), len(s.names))
+        rows = torch.from_numpy(data)
+        for k, a in enumerate(names):          # (the particle-field rows only when the dumped set carried them)
+            s.arr(a)[: self.n].copy_(rows[k])
         s.id[: self.n].copy_(torch.from_numpy(ids))
         self.sets, self.cur = [s, None], 0
         self.n_sorted, self.tiling = 0, None

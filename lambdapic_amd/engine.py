@@ -904,7 +904,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             cnt = torch.tensor([float(idx.numel())], dtype=torch.float64, device=self.device)
             got = torch.zeros_like(cnt)
             self.comm.exchange(cnt, torch.zeros_like(cnt), torch.zeros_like(cnt), got)
-            rows = len(st.names) + 1                      # attributes + id (bit pattern)
+            rows = len(st.core) + 1                       # core attributes + id (bit pattern); the next push rewrites ex_part ...
             out = torch.empty((rows, idx.numel()), dtype=torch.float64, device=self.device)
             out[:-1] = st.data[:, idx]
             out[-1] = st.id[idx].view(torch.float64)
@@ -946,8 +946,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             if self.comm.size > 1:
                 sp.steps_since_sort = 1 << 30
             return
-        rows = torch.zeros((len(sp.cset.names), k), dtype=torch.float64, device=self.device)
-        for i, a in enumerate(sp.cset.names):
+        rows = torch.zeros((len(sp.cset.core), k), dtype=torch.float64, device=self.device)
+        for i, a in enumerate(sp.cset.core):
             if a in dev:
                 rows[i] = dev[a]
         self._append_device(sp, rows, dev["id"])
@@ -962,8 +962,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                 sp.steps_since_sort = 1 << 30
             return
         st = sp.cset
-        rows = torch.zeros((len(st.names), k), dtype=torch.float64)
-        for i, a in enumerate(st.names):
+        rows = torch.zeros((len(st.core), k), dtype=torch.float64)
+        for i, a in enumerate(st.core):
             if a in host:
                 rows[i] = torch.from_numpy(np.ascontiguousarray(host[a], dtype=np.float64))
         ids = torch.from_numpy(np.ascontiguousarray(host["_id"]).view(np.int64)) if "_id" in host \

@@ -187,12 +187,13 @@ def live_attributes(sim, species, names):
             sp.refresh_inv_gamma()
         s, n = sp.cset, sp.n
         live = ~torch.isnan(s.arr("x")[:n])
-        rows = {a: s.arr(a)[:n] for a in s.names}
         ids = s.id[:n]
-        rows["_id"] = ids.view(torch.float64)
+        have = list(s.names) + ["_id"]
+        rows = {a: (ids.view(torch.float64) if a == "_id" else s.arr(a)[:n]) for a in names if a in have}
     missing = [a for a in names if a not in rows]
     if missing:
-        raise ValueError(f"the resident store of {species.name!r} has no attribute {missing}; it holds {sorted(rows)}")
+        have = sorted(rows) if sim.dimension == 3 else sorted(have)
+        raise ValueError(f"the resident store of {species.name!r} has no attribute {missing}; it holds {have}")
     out = {a: rows[a][live].cpu().numpy() for a in names}
     out["id"] = ids[live].cpu().numpy().view(np.uint64)
     return out
