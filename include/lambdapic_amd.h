@@ -417,6 +417,16 @@ int lpa_sort_tiles_2d(const lpa_grid *g, const lpa_particles *src, const lpa_par
 int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
                       int32_t order, lpa_tiling *out, void *stream);
+/* the same sorts with every particle binned where it will be `ahead` seconds down its straight path (x + v * ahead; 0 =
+ * the plain sorts).  For stores the caller re-sorts every T steps because their particles outrun the tile margin: binned
+ * for the middle of the interval (ahead = T dt / 2) the order stays usable about twice as long.  Any binning gives the
+ * same results from the tiled kernels (what does not fit a tile's staged region takes their overflow list) */
+int lpa_sort_tiles_ahead_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                            void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                            int32_t order, lpa_tiling *out, double ahead, void *stream);
+int lpa_sort_tiles_ahead_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                            void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                            int32_t order, lpa_tiling *out, double ahead, void *stream);
 /* number of live particles after the last sort (device pointer inside the workspace); for LPA_ORDER_PADDED: the slots
  * of the order (live + holes + the 64-slot rounding of every tile -- up to 4/3 n + 63 per tile) */
 const int32_t *lpa_sort_live_count(void *workspace);

@@ -154,6 +154,8 @@ SIGNATURES = {
     "lpa_sort_deepest_cell": (_vp, [_vp]),
     "lpa_sort_tiles_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
     "lpa_sort_tiles_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _vp]),
+    "lpa_sort_tiles_ahead_2d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _d, _vp]),
+    "lpa_sort_tiles_ahead_3d": (_i, [_G, _P, _P, _vp, _i64, C.c_int32, C.c_int32, _T, _d, _vp]),
     "lpa_sort_live_count": (_vp, [_vp]),
     "lpa_sort_overflow": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp, _vp]),

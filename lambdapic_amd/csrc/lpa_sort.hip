@@ -174,11 +174,19 @@ __device__ __forceinline__ uint32_t cell_rank(bool live, uint32_t ck, int32_t *c
 struct KeyGeom {
     int dim, nx, ny, nz, tiles_y, tiles_z;
     double x0, y0, z0, inv_dx, inv_dy, inv_dz;
+    double ahead = 0.0;   // c x look-ahead time: bin by where the particle will be then (lpa_sort_tiles_ahead_*)
 };
 
 __device__ __forceinline__ uint32_t cell_key(const PartV &p, long ip, const KeyGeom &k) {
     double x = p.x[ip], y = p.y[ip];
     if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return KEY_DEAD;
+    [[maybe_unused]] double zz = 0.0;
+    if (k.ahead != 0.0) {   // (uniform) ballistic look-ahead: x + v t; 1 / gamma from the momenta (the store's may be stale)
+        const double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip];
+        const double s = k.ahead * rsqrt_nr(fma(uz, uz, fma(uy, uy, fma(ux, ux, 1.0))));
+        x = fma(ux, s, x); y = fma(uy, s, y);
+        zz = uz * s;
+    }
     int is = ifloor((x - k.x0) * k.inv_dx + 0.5), js = ifloor((y - k.y0) * k.inv_dy + 0.5);
     is = is < 0 ? 0 : (is >= k.nx ? k.nx - 1 : is);
     js = js < 0 ? 0 : (js >= k.ny ? k.ny - 1 : js);
@@ -188,6 +196,7 @@ __device__ __forceinline__ uint32_t cell_key(const PartV &p, long ip, const KeyG
     }
     double z = p.z[ip];
     if (isnan(z)) return KEY_DEAD;
+    z += zz;
     int ks = ifloor((z - k.z0) * k.inv_dz + 0.5);
     ks = ks < 0 ? 0 : (ks >= k.nz ? k.nz - 1 : ks);
     int tile = ((is / T3X) * k.tiles_y + js / T3Y) * k.tiles_z + ks / T3Z;
@@ -641,7 +650,8 @@ __global__ void __launch_bounds__(ST_THREADS) k_scatter_tiled(
 
 static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_particles *src,
                       const lpa_particles *dst, void *workspace, int64_t workspace_bytes,
-                      int32_t block_particles, int32_t order, lpa_tiling *out, void *stream) {
+                      int32_t block_particles, int32_t order, lpa_tiling *out, void *stream, double ahead = 0.0) {
+    LPA_REQUIRE(ahead >= 0.0 && ahead == ahead, "%s: bad look-ahead time", name);
     LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && (dim == 2 || (g->nz > 1 && g->dz > 0)),
                 "%s: bad grid", name);
     // inv_gamma may be left out of BOTH stores: a store whose fused kernels run with LPA_PUSH_NO_IG holds a stale array
@@ -691,6 +701,7 @@ static int sort_tiles(int dim, const char *name, const lpa_grid *g, const lpa_pa
         kg.tiles_y = tiles_y; kg.tiles_z = tiles_z;
         kg.x0 = g->x0; kg.y0 = g->y0; kg.z0 = dim == 3 ? g->z0 : 0.0;
         kg.inv_dx = 1.0 / g->dx; kg.inv_dy = 1.0 / g->dy; kg.inv_dz = dim == 3 ? 1.0 / g->dz : 0.0;
+        kg.ahead = LPA_C * ahead;
         // tile-ordered prefix (re-sorts): LDS counters per old tile; does nothing on a first sort
         hipLaunchKernelGGL(k_cell_count_tiled, dim3(w.ntiles), dim3(512), 0, st, sv, kg, w.hdr, w.tile_off_prev,
                            w.cell_cnt, w.cell_base, w.key, w.rank);
@@ -790,6 +801,24 @@ extern "C" int lpa_sort_tiles_3d(const lpa_grid *g, const lpa_particles *src, co
                                  int32_t order, lpa_tiling *out, void *stream) {
     return sort_tiles(3, "lpa_sort_tiles_3d", g, src, dst, workspace, workspace_bytes, block_particles, order,
                       out, stream);
+}
+
+// The same sorts with the cells taken `ahead` seconds down every particle's straight path (x + v * ahead): a store the
+// caller re-sorts every T steps because its particles outrun the tile margin stays valid about twice as long when it is
+// binned for the MIDDLE of the interval (ahead = T dt / 2) -- the kernels accept any binning (what does not fit a tile's
+// staged region takes the overflow list), so this is a work partition, not a change of results.
+extern "C" int lpa_sort_tiles_ahead_2d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                                       int32_t order, lpa_tiling *out, double ahead, void *stream) {
+    return sort_tiles(2, "lpa_sort_tiles_ahead_2d", g, src, dst, workspace, workspace_bytes, block_particles, order,
+                      out, stream, ahead);
+}
+
+extern "C" int lpa_sort_tiles_ahead_3d(const lpa_grid *g, const lpa_particles *src, const lpa_particles *dst,
+                                       void *workspace, int64_t workspace_bytes, int32_t block_particles,
+                                       int32_t order, lpa_tiling *out, double ahead, void *stream) {
+    return sort_tiles(3, "lpa_sort_tiles_ahead_3d", g, src, dst, workspace, workspace_bytes, block_particles, order,
+                      out, stream, ahead);
 }
 
 // =====================================================================================================

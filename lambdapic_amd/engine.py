@@ -475,6 +475,16 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         return self._ws[key]
 
     deep_tail_fraction = 0.005   # re-size the stripes when this share of a store lies beyond them (see sort)
+    sort_lookahead = True        # a store the controller re-sorts early is binned for the middle of its interval
+
+    def _sort_ahead(self, sp):
+        """look-ahead time of the sort (lpa_sort_tiles_ahead_*): half the interval the controller runs the store on, once
+        that is shorter than ``sort_interval`` -- i.e. its particles outrun the tile margin.  Cold stores: 0 (the plain
+        sort, two attribute streams less in its count pass)."""
+        now = sp.get("sort_interval_now") if isinstance(sp, dict) else getattr(sp, "sort_interval_now", None)
+        if not self.sort_lookahead or self.comm.size > 1 or now is None or now >= self.sort_interval:
+            return 0.0
+        return 0.5 * now * getattr(self, "_dt_hint", 0.0)
 
     def sort(self, ispec, _again=False):
         """tile-bin species ``ispec`` (drops dead slots).  One host sync (live count read-back).
@@ -502,9 +512,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
         ws["tiling"].prefix_hint = int(sp.n_sorted) if sp.tiling is not None else 0
         ws["tiling"].stripe_ranks = getattr(sp, "stripe_ranks", 0)
-        check(self.L.lpa_sort_tiles_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), bp, self.order,
-                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_2d")
+        check(self.L.lpa_sort_tiles_ahead_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
+                                             ws["sort"].numel(), bp, self.order,
+                                             C.byref(ws["tiling"]), self._sort_ahead(sp), self.stream), "lpa_sort_tiles_2d")
         n_live, deepest, tail, _, _ = _lib.sort_result(self.L, ws["sort"], True)    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]

@@ -396,6 +396,10 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         return sp["ws"]
 
     deep_tail_fraction = 0.005   # see PicEngine2D.sort
+    sort_lookahead = True
+    from .engine import PicEngine2D as _E2
+    _sort_ahead = _E2._sort_ahead
+    del _E2
 
     def fuse_worthwhile(self):
         """One launch for all species (a workgroup per TILE: one E / B staging for every species; also the faster form for
@@ -416,9 +420,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
         ws["tiling"].prefix_hint = int(sp["n_sorted"]) if sp["tiling"] is not None else 0
         ws["tiling"].stripe_ranks = sp.get("stripe_ranks", 0)
-        check(self.L.lpa_sort_tiles_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
-                                       ws["sort"].numel(), self.block_particles, self.order,
-                                       C.byref(ws["tiling"]), self.stream), "lpa_sort_tiles_3d")
+        check(self.L.lpa_sort_tiles_ahead_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
+                                             ws["sort"].numel(), self.block_particles, self.order,
+                                             C.byref(ws["tiling"]), self._sort_ahead(sp), self.stream), "lpa_sort_tiles_3d")
         n_live, deepest, tail, sp["tiles_in_use"], sp["n_blocks"] = _lib.sort_result(self.L, ws["sort"], True)
         area = self.arrival_area()
         cnts = ws["counters"].tolist()

@@ -510,6 +510,9 @@ def _run_3d_open(rank, world, port, q, stress=False):
         warnings.simplefilter("ignore", RuntimeWarning)
         eng.ABSORBED_MIN_CAPACITY = 8
         eng._rho_particle_slots = lambda: 0
+        # (an undersized list is exact again from the next real deposit on, rho.py `_check_absorbed`: the single slab runs
+        # the chain's fixed sort clock here, so that both runs re-deposit in the same steps while the list grows)
+        eng.overflow_sort_fraction = 0
     ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
     w = np.full(n, 3e27 * dx * dy * dz / ppc)
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
