@@ -165,6 +165,15 @@ class SlabComm:
                          device="cpu" if on_host else torch.cuda.current_device())
         return float(self.allreduce_sum(t)[0]) > 0.0
 
+    def allmin(self, value: float) -> float:
+        """minimum over the ranks (one small all-reduce on the control group; every rank must call it in the same step)"""
+        if self.size == 1:
+            return float(value)
+        on_host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if on_host else torch.cuda.current_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t[0])
+
     def reduce_diagnostics(self, d: dict) -> dict:
         """sum a diagnostics() dict (floats, ints and lists of them) over the ranks: one all-reduce"""
         if self.size == 1:

@@ -225,7 +225,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             # steps, and a sort step is such a step), whatever a rank's own stores look like -- a slab that was empty
             # pushes its first arrivals with the global kernel until the common sort -- plus the forced re-sorts, which
             # every rank is told at once (window shifts, uploads)
-            return self._chain_clock >= self.sort_interval or sp.steps_since_sort >= (1 << 29)
+            return self._chain_clock >= self._chain_interval() or sp.steps_since_sort >= (1 << 29)
         return sp.tiling is None or sp.steps_since_sort >= min(self.sort_interval, getattr(sp, "sort_interval_now", 1 << 30))
 
     def _first_sort_interval(self, sp, cset, comps, d, margin):
@@ -233,7 +233,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         (one reduction over the momenta; a 1 keV plasma gets the full ``sort_interval``), the controller takes it from
         there"""
         dt = getattr(self, "_dt_hint", None)
-        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or sp.n == 0:
+        if self.overflow_sort_fraction <= 0 or not dt or sp.n == 0:
             return
         u = [cset.arr(a)[: sp.n] for a in ("ux", "uy", "uz")]
         live = ~torch.isnan(cset.arr("x")[: sp.n])
@@ -245,7 +245,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
         """called by sort() with the overflow count of the last push of the interval that just ended"""
-        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 \
+        if self.overflow_sort_fraction <= 0 or n_sorted_before <= 0 \
                 or sp.steps_since_sort > self.sort_interval:          # (forced sorts of stale stores tell nothing)
             return
         now = min(getattr(sp, "sort_interval_now", self.sort_interval), self.sort_interval)
@@ -260,6 +260,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def _rho_particle_slots(self):
         return sum(sp.capacity for sp in self.species)
+
+    def _species_sort_interval(self, sp):
+        return getattr(sp, "sort_interval_now", None) if sp.n else None
 
     def _rho_last_jx_plane(self):
         return self.grid.view("jx")[self.ng + self.nx - 1]
@@ -482,7 +485,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         that is shorter than ``sort_interval`` -- i.e. its particles outrun the tile margin.  Cold stores: 0 (the plain
         sort, two attribute streams less in its count pass)."""
         now = sp.get("sort_interval_now") if isinstance(sp, dict) else getattr(sp, "sort_interval_now", None)
-        if not self.sort_lookahead or self.comm.size > 1 or now is None or now >= self.sort_interval:
+        if self.comm.size > 1:          # a slab chain sorts on its common clock
+            now = self._chain_interval()
+        if not self.sort_lookahead or now is None or now >= self.sort_interval:
             return 0.0
         return 0.5 * now * getattr(self, "_dt_hint", 0.0)
 
@@ -521,7 +526,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if _again:
             pass                                                     # (the controller saw the first pass)
         elif sp.tiling is not None:
-            self._adapt_sort_interval(sp, cnts[0], sp.n_sorted)      # cnts[0]: the overflow list of the last push
+            self._adapt_sort_interval(sp, cnts[0] + cnts[2], sp.n_sorted)      # the overflow lists of the last push (interior + edge part)
         else:
             self._first_sort_interval(sp, src, ("ux", "uy"), (self.dx, self.dy), _lib.LPA_TILE_MARGIN)
         if arrivals > ws["area"]:

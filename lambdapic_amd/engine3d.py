@@ -214,14 +214,14 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
         a species whose last intervals ended with a long overflow list (see PicEngine2D.overflow_sort_fraction)"""
         if self.comm.size > 1:      # slab chain: one clock for all ranks and species (PicEngine2D.sort_due)
-            return self._chain_clock >= self.sort_interval or sp["since"] >= (1 << 29)
+            return self._chain_clock >= self._chain_interval() or sp["since"] >= (1 << 29)
         return sp["tiling"] is None or sp["since"] >= min(self.sort_interval, sp.get("sort_interval_now", 1 << 30))
 
     def _first_sort_interval(self, sp):
         """see PicEngine2D._first_sort_interval (3-D tiles keep a margin of ONE cell)"""
         dt = getattr(self, "_dt_hint", None)
         n = sp["n"]
-        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or not dt or n == 0:
+        if self.overflow_sort_fraction <= 0 or not dt or n == 0:
             return
         dta = sp["data"]
         u = [dta[k, :n] for k in (3, 4, 5)]
@@ -235,7 +235,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):
         """called by sort() with the overflow count of the last push of the interval that just ended"""
-        if self.overflow_sort_fraction <= 0 or self.comm.size > 1 or n_sorted_before <= 0 or sp["since"] > self.sort_interval:
+        if self.overflow_sort_fraction <= 0 or n_sorted_before <= 0 or sp["since"] > self.sort_interval:
             return
         now = min(sp.get("sort_interval_now", self.sort_interval), self.sort_interval)
         f = overflow / n_sorted_before
@@ -249,6 +249,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def _rho_particle_slots(self):
         return sum(int(sp["data"].shape[1]) for sp in self.species)
+
+    def _species_sort_interval(self, sp):
+        return sp.get("sort_interval_now") if sp["n"] else None
 
     def _rho_last_jx_plane(self):
         return self.view("jx")[self.ng + self.n[0] - 1]
@@ -429,7 +432,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         if _again:
             pass
         elif sp["tiling"] is not None:
-            self._adapt_sort_interval(sp, cnts[0], sp["n_sorted"])   # cnts[0]: the overflow list of the last push
+            self._adapt_sort_interval(sp, cnts[0] + cnts[2], sp["n_sorted"])   # the overflow lists of the last push (interior + edge part)
         else:
             self._first_sort_interval(sp)
         if cnts[1] > area:

@@ -108,10 +108,27 @@ class RhoContinuityMixin:
         """does ANY slab of the chain absorb particles?  (the same answer on every rank)"""
         return any(v != "periodic" for v in self.bc.values())
 
+    _chain_interval_now = None      # slab chains: what the ranks agreed on at their last common sort (None: sort_interval)
+
+    def _chain_interval(self):
+        now = self._chain_interval_now
+        return self.sort_interval if now is None else max(1, min(self.sort_interval, int(now)))
+
     def _tick_chain_clock(self):
-        """slab chains: ONE sort / real-deposit clock for all ranks and species (engines: ``sort_due``)"""
+        """slab chains: ONE sort / real-deposit clock for all ranks and species (engines: ``sort_due``).  Its period follows
+        the overflow lists like a single slab's sort interval does, with what every rank knows: at the end of a step in
+        which the clock made every rank sort, the ranks take the minimum of the intervals their species' controllers ask
+        for (one scalar all-reduce per sort step; the host is synchronised by the sorts' read-backs anyway)."""
         if self.comm.size > 1:
-            self._chain_clock = 1 if self._chain_clock >= self.sort_interval else self._chain_clock + 1
+            due = self._chain_clock >= self._chain_interval()
+            if due and getattr(self, "overflow_sort_fraction", 0) > 0:
+                mine = [self._species_sort_interval(sp) for sp in self.species]
+                self._chain_interval_now = self.comm.allmin(min([self.sort_interval] + [m for m in mine if m is not None]))
+            self._chain_clock = 1 if due else self._chain_clock + 1
+
+    def _species_sort_interval(self, sp):
+        """the interval a species' controller asks for (engines: ``sort_interval_now``), None without an opinion"""
+        raise NotImplementedError
 
     def _rho_sorted(self):
         """called by sort(): a sort at the sorter stage (before reset_current) makes this step a real-deposit step"""

@@ -740,3 +740,67 @@ def test_slab_migration_vs_reference_golden(golden):
             assert np.array_equal(got[a][o], exp[a][r]), (rank, a)
         total += got["x"].size
     assert total == sum(int((~g[f"pin{k}_is_dead"]).sum()) for k in range(4))       # nobody lost, nobody doubled
+
+
+# ---- the chain's common sort clock follows the overflow lists ----------------------------------------------------------
+def _run_hot_chain(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lambdapic_amd.dist import SlabComm
+    from lambdapic_amd.engine import PicEngine2D
+    comm = SlabComm(None)
+    dx, dy, dt, x, y, u, ig, w = _problem()
+    u = u * (2.0 if rank == 0 else 0.05)         # rank 0's half is relativistically hot, rank 1's is cold
+    ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
+    nx = NXG // world
+    eng = PicEngine2D(nx, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=12, block_particles=1024, migrate_capacity=16384)
+    lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
+    mine = (x >= lo) & (x < hi)
+    n = int(mine.sum())
+    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=4 * n + 40000)
+    s = eng.species[0].cset
+    for name, arr in (("x", x), ("y", y), ("ux", u[0]), ("uy", u[1]), ("uz", u[2]), ("inv_gamma", ig), ("w", w)):
+        s.arr(name)[:n] = torch.from_numpy(arr[mine]).cuda()
+    s.id[:n] = torch.from_numpy(np.nonzero(mine)[0]).cuda()
+    eng.species[0].n = n
+    hist, sorts = [], []
+    for it in range(48):
+        before = eng.rho_steps["anchor"]
+        eng.step(dt)
+        hist.append(eng._chain_interval())
+        sorts.append(eng.species[0].steps_since_sort == 1)      # (a sort ran at the start of this step)
+    d = eng.diagnostics(reduce=True)
+    q.put((rank, hist, sorts, d["nalive"][0], d["charge"], float(w.sum()) * -1.602176634e-19))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chain_sort_clock_follows_the_overflow_lists():
+    """One clock for all ranks (rho.py) -- but its period is no longer fixed: at every common sort the ranks agree on the
+    shortest interval any species' controller asks for.  Rank 0 holds a relativistically hot plasma, rank 1 a cold one:
+    both end up sorting every few steps, in the same steps, and nothing is lost on the way."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_hot_chain, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    (_, h0, s0, n0, c0, qw), (_, h1, s1, n1, c1, _) = res
+    assert h0 == h1 and s0 == s1                      # the same interval and the same sort steps on both ranks
+    assert h0[0] == 12 or h0[0] < 12                  # (the first sort's speed estimate may already shorten it)
+    assert min(h0) <= 4 and h0[-1] <= 6               # ... and the hot half drives it down for the whole chain
+    assert sum(s0) >= 8
+    assert n0 == NXG * NY * PPC
+    assert c0 == pytest.approx(qw, rel=1e-9)
