@@ -102,7 +102,10 @@ def _worker(rank, world, port, nx_loc, ny, q):
         ok_diag = d == {"field_energy": 1.5 * w + w * (w - 1) / 2, "charge": -2.0 * w,
                         "kinetic": [0.25 * w * (w - 1) / 2, 1.0 * w], "nalive": [10 * w + w * (w - 1) // 2, 7 * w]} \
             and all(isinstance(v, int) for v in d["nalive"])
-        q.put((rank, bool(ok_guard), bool(ok_fold) and bool(ok_diag) and ok_many))
+        # the control-plane votes of the slab chain (rho.py): OR of a flag, minimum of the sort intervals asked for
+        ok_votes = comm.any(rank == world - 1) and not comm.any(False) and comm.allmin(7.0 + rank) == 7.0 \
+            and comm.allmin(20 - rank) == 20 - (world - 1)
+        q.put((rank, bool(ok_guard), bool(ok_fold) and bool(ok_diag) and ok_many and bool(ok_votes)))
     finally:
         dist.destroy_process_group()
 
