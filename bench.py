@@ -55,6 +55,8 @@ def build_engine(args, comm, device, nx=None):
                       order=_lib.LPA_ORDER_PADDED if padded else _lib.LPA_ORDER_STRIPED)
     if getattr(args, "fixed_sort", False):
         eng.overflow_sort_fraction = 0
+    if getattr(args, "lookahead_cold", False):
+        eng.sort_lookahead_cold = True
     # (the padded order stores a few per cent of holes and rounds every tile to 64 slots)
     eng.add_species(q, m, capacity=int(1.12 * n) + 65536 if padded else n + 4096)
     s = eng.species[0].cset
@@ -660,6 +662,7 @@ def main():
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
     ap.add_argument("--reseat", action="store_true", help="A/B: with the in-kernel cell-index sort (off by default)")
+    ap.add_argument("--lookahead-cold", action="store_true", help="experiment: bin every sort half an interval ahead")
     ap.add_argument("--fixed-sort", action="store_true", help="off-benchmark: sort on the fixed interval only "
                                                               "(engine.overflow_sort_fraction = 0)")
     ap.add_argument("--drift", type=float, default=0.0, help="mean u_x of the plasma (off-benchmark: a relativistic flow)")

@@ -22,6 +22,7 @@ take the laser (``laser_inject``); ``shift_window`` moves the slab chain (Moving
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -479,6 +480,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     deep_tail_fraction = 0.005   # re-size the stripes when this share of a store lies beyond them (see sort)
     sort_lookahead = True        # a store the controller re-sorts early is binned for the middle of its interval
+    # ... and one on the full interval too: the particles' mean distance from the cells they were binned for halves, the
+    # order ages half as fast (C2: K1 1.658 -> 1.601 ms, step -2 %; LPA_SORT_LOOKAHEAD_COLD=0 for A/B runs)
+    sort_lookahead_cold = os.environ.get("LPA_SORT_LOOKAHEAD_COLD", "1") != "0"
 
     def _sort_ahead(self, sp):
         """look-ahead time of the sort (lpa_sort_tiles_ahead_*): half the interval the controller runs the store on, once
@@ -487,6 +491,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         now = sp.get("sort_interval_now") if isinstance(sp, dict) else getattr(sp, "sort_interval_now", None)
         if self.comm.size > 1:          # a slab chain sorts on its common clock
             now = self._chain_interval()
+        if self.sort_lookahead_cold and self.sort_lookahead:      # (experiment: also for stores on the full interval)
+            return 0.5 * min(now or self.sort_interval, self.sort_interval) * getattr(self, "_dt_hint", 0.0)
         if not self.sort_lookahead or now is None or now >= self.sort_interval:
             return 0.0
         return 0.5 * now * getattr(self, "_dt_hint", 0.0)

@@ -401,6 +401,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     deep_tail_fraction = 0.005   # see PicEngine2D.sort
     sort_lookahead = True
     from .engine import PicEngine2D as _E2
+    sort_lookahead_cold = _E2.sort_lookahead_cold
     _sort_ahead = _E2._sort_ahead
     del _E2
 
