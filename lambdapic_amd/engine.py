@@ -241,7 +241,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         v2 = [torch.where(live, c * c / (1 + u[0] ** 2 + u[1] ** 2 + u[2] ** 2), torch.zeros_like(c)) for c in u[: len(comps)]]
         nl = max(int(live.sum().item()), 1)
         cells = max(float(torch.sqrt(w.sum() / nl).item()) * constants.C_LIGHT * dt / dd for w, dd in zip(v2, d))
-        est = int(margin / max(2.5 * cells, 1e-12))
+        est = int(margin / max(2.5 * cells, 1e-12)) * (2 if self.sort_lookahead else 1)   # (binned for mid-interval: +- T / 2)
         sp.sort_interval_now = max(self.min_sort_interval, min(self.sort_interval, est))
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):

@@ -230,7 +230,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         nl = max(int(live.sum().item()), 1)
         cells = max(float(torch.sqrt(torch.where(live, c * c / g2, torch.zeros_like(c)).sum() / nl).item())
                     * constants.C_LIGHT * dt / dd for c, dd in zip(u, self.d))
-        est = int(_lib.LPA_TILE3_MARGIN / max(2.5 * cells, 1e-12))
+        est = int(_lib.LPA_TILE3_MARGIN / max(2.5 * cells, 1e-12)) * (2 if self.sort_lookahead else 1)
         sp["sort_interval_now"] = max(self.min_sort_interval, min(self.sort_interval, est))
 
     def _adapt_sort_interval(self, sp, overflow, n_sorted_before):

@@ -453,7 +453,7 @@ class Simulation:
 
     def __init__(self, nx, ny, dx, dy, npatch_x=1, npatch_y=1, nsteps=None, sim_time=None, dt_cfl=0.95,
                  n_guard=3, boundary_conditions=None, cpml_thickness=6, random_seed=None, device="cuda:0",
-                 comm=None, sort_interval=16, capacity_factor=1.5):
+                 comm=None, sort_interval=32, capacity_factor=1.5):
         # reference default: PML on all four sides (simulation.py:157-162)
         bc = dict(boundary_conditions or {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")})
         if dt_cfl > 1.0:
