@@ -218,6 +218,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
     def _rho_sort_due(self):
         return any(self.sort_due(sp) for sp in self.species if sp.n or self.comm.size > 1)
 
+    def _rho_forced_sort_due(self):
+        return any(sp.n and (sp.tiling is None or sp.steps_since_sort >= (1 << 29)) for sp in self.species)
+
     def sort_due(self, sp):
         """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
         a species whose last intervals ended with a long overflow list (``_adapt_sort_interval``)"""
@@ -508,6 +511,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         re-sized for the deepest cell + 25 % and the store sorted once more, here and now."""
         sp = self.species[ispec]
         ws = self._ws_checked(sp)
+        forced = _again or sp.tiling is None or sp.steps_since_sort >= (1 << 29)     # (no valid order: rho.py _rho_sorted)
         src, dst = sp.cset, sp.other()
         # ex_part ... bz_part are what the LAST push saw: the push that follows this sort rewrites them (or nobody reads
         # them before one that does, Simulation._host_callback_near), so the sort leaves them where they are -- six of
@@ -572,7 +576,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             ws["tiling"].class_init = 0
         sp.tiling = ws["tiling"]
         sp.steps_since_sort = 0
-        self._rho_sorted()
+        self._rho_sorted(forced)
         self._reset_free_slots(ws, ws["tiling"].tiles_x, ws["tiling"].tiles_y, _lib.LPA_TILE_X)
         used, want = ws["tiling"].stripe_ranks, min(_lib.LPA_MAX_STRIPE_RANKS, deepest + deepest // 4)
         if not _again and want > used and used < getattr(sp, "stripe_ranks_limit", 1 << 30) and \

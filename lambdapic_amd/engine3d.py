@@ -210,6 +210,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def _rho_sort_due(self):
         return any(self.sort_due(sp) for sp in self.species)     # (an engine without species: nothing to re-deposit)
 
+    def _rho_forced_sort_due(self):
+        return any(sp["n"] and (sp["tiling"] is None or sp["since"] >= (1 << 29)) for sp in self.species)
+
     def sort_due(self, sp):
         """the sorter's rule: whenever the store is not tile ordered, and every ``sort_interval`` steps -- or sooner for
         a species whose last intervals ended with a long overflow list (see PicEngine2D.overflow_sort_fraction)"""
@@ -419,6 +422,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         over all tiles says (PicEngine2D.sort)"""
         sp = self.species[i]
         ws = self._ws(sp)
+        forced = _again or sp["tiling"] is None or sp["since"] >= (1 << 29)
         cap = sp["data"].shape[1]
         src, dst = self._cstruct(sp["data"], sp["n"]), self._cstruct(sp["alt"], cap)
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
@@ -455,7 +459,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             ws["tiling"].scratch[c] = sp["alt"][c].data_ptr() if self.defer_crossers else None
         sp["tiling"] = ws["tiling"]
         sp["since"] = 0
-        self._rho_sorted()
+        self._rho_sorted(forced)
         self._reset_free_slots(ws)
         used, want = ws["tiling"].stripe_ranks, min(_lib.LPA_MAX_STRIPE_RANKS, deepest + deepest // 4)
         if not _again and want > used and used < sp.get("stripe_ranks_limit", 1 << 30) and \

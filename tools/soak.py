@@ -23,6 +23,7 @@ ap.add_argument("--c5", type=int, default=400)
 ap.add_argument("--c4", type=int, default=0, help="steps of the LWFA config (4096 x 512 cells, window at c with injection)")
 ap.add_argument("--fraction", type=float, default=None, help="engine.overflow_sort_fraction (0: fixed sort interval)")
 ap.add_argument("--min-interval", type=int, default=None)
+ap.add_argument("--relaxed-anchor", action="store_true", help="experiment: engine.anchor_every_sort = False")
 ap.add_argument("--no-lookahead", action="store_true", help="plain sorts (engine.sort_lookahead = False)")
 ap.add_argument("--deep-tail", type=float, default=None, help="engine.deep_tail_fraction (2: never re-size the stripes)")
 a = ap.parse_args()
@@ -38,6 +39,8 @@ def tune(eng):
         eng.deep_tail_fraction = a.deep_tail
     if a.no_lookahead:
         eng.sort_lookahead = False
+    if a.relaxed_anchor:
+        eng.anchor_every_sort = False
 
 
 def c3(nsteps):
