@@ -527,9 +527,11 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
         ws["tiling"].prefix_hint = int(sp.n_sorted) if sp.tiling is not None else 0
         ws["tiling"].stripe_ranks = getattr(sp, "stripe_ranks", 0)
+        ahead = self._sort_ahead(sp)
         check(self.L.lpa_sort_tiles_ahead_2d(self._g(), C.byref(ps), C.byref(pd), ws["sort"].data_ptr(),
                                              ws["sort"].numel(), bp, self.order,
-                                             C.byref(ws["tiling"]), self._sort_ahead(sp), self.stream), "lpa_sort_tiles_2d")
+                                             C.byref(ws["tiling"]), ahead, self.stream), "lpa_sort_tiles_2d")
+        sp.sort_ahead_used = ahead
         n_live, deepest, tail, _, _ = _lib.sort_result(self.L, ws["sort"], True)    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]
@@ -596,7 +598,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         ws["fs"] = None
         if self.comm.size == 1:
             return
-        cols = int(np.ceil((self.sort_interval + 2) / tile_x))
+        cols = int(np.ceil((1.5 * self.sort_interval + 2) / tile_x))      # (age + the sort's look-ahead of up to half an interval)
         if 2 * cols > tiles_x:
             return
         n = 2 * cols * tiles_per_col
@@ -689,7 +691,10 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         travel.  Uses the actual age of the order (a disabled sorter makes it grow).  0 = no overlap
         possible (slab too thin for that much drift)."""
         age = max([sp.steps_since_sort for sp in self.species if sp.n] + [0]) + 1
-        drift = constants.C_LIGHT * dt / self.dx * age + 4.0     # + the 3 nodes a deposit window reaches, + 1
+        # (+ how far ahead of its position the sort may have binned a particle: one that sits at the face and moves inward
+        # is filed that much further in)
+        ahead = max([getattr(sp, "sort_ahead_used", 0.0) for sp in self.species] + [0.0]) * constants.C_LIGHT / self.dx
+        drift = constants.C_LIGHT * dt / self.dx * age + 4.0 + ahead     # + the 3 nodes a deposit window reaches, + 1
         cols = int(np.ceil(drift / _lib.LPA_TILE_X))
         return cols if 2 * cols < self.nx // _lib.LPA_TILE_X else 0
 
@@ -697,7 +702,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         """tile columns at each x face that can hold particles which left the slab during the ``age`` steps
         since the sort (each step moves a particle less than one cell: the tiled push requires
         c dt <= dx); 0 = scan everything"""
-        cols = int(np.ceil((age + 1) / _lib.LPA_TILE_X))
+        # (+ the sort's look-ahead: a particle that turned round after the sort was filed that much further in)
+        ahead = max([getattr(sp, "sort_ahead_used", 0.0) for sp in self.species] + [0.0]) * constants.C_LIGHT / self.dx
+        cols = int(np.ceil((age + 1 + ahead) / _lib.LPA_TILE_X))
         return cols if 2 * cols <= self.nx // _lib.LPA_TILE_X else 0
 
     def push_deposit_overlapped(self, dt):

@@ -428,9 +428,11 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         # a re-sort: the first n_sorted slots are the previous sort's result (lpa_tiling.prefix_hint)
         ws["tiling"].prefix_hint = int(sp["n_sorted"]) if sp["tiling"] is not None else 0
         ws["tiling"].stripe_ranks = sp.get("stripe_ranks", 0)
+        ahead = self._sort_ahead(sp)
         check(self.L.lpa_sort_tiles_ahead_3d(self._g(), C.byref(src), C.byref(dst), ws["sort"].data_ptr(),
                                              ws["sort"].numel(), self.block_particles, self.order,
-                                             C.byref(ws["tiling"]), self._sort_ahead(sp), self.stream), "lpa_sort_tiles_3d")
+                                             C.byref(ws["tiling"]), ahead, self.stream), "lpa_sort_tiles_3d")
+        sp["sort_ahead_used"] = ahead
         n_live, deepest, tail, sp["tiles_in_use"], sp["n_blocks"] = _lib.sort_result(self.L, ws["sort"], True)
         area = self.arrival_area()
         cnts = ws["counters"].tolist()
@@ -478,7 +480,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         t = ws["tiling"]
         if self.comm.size == 1:
             return
-        cols = int(np.ceil((self.sort_interval + 2) / _lib.LPA_TILE3_X))
+        cols = int(np.ceil((1.5 * self.sort_interval + 2) / _lib.LPA_TILE3_X))     # (age + the sort's look-ahead)
         if 2 * cols > t.tiles_x:
             return
         n = 2 * cols * t.tiles_y * t.tiles_z
@@ -557,7 +559,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         m = ws["mig"]
         xlo = self.x0 - self.d[0] / 2
         xhi = self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
-        cols = int(np.ceil((sp["since"] + 1) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
+        ahead = sp.get("sort_ahead_used", 0.0) * constants.C_LIGHT / self.d[0]      # (see PicEngine2D.leaver_columns)
+        cols = int(np.ceil((sp["since"] + 1 + ahead) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
         if not (cols and 2 * cols <= self.n[0] // _lib.LPA_TILE3_X):
             cols = 0
         fs = ws.get("fs") if (self.reuse_slots and cols) else None
@@ -851,7 +854,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def edge_columns(self, dt):
         """see PicEngine2D.edge_columns (the sort, when due, runs inside the edge pass: age 0 then)"""
         age = max([0 if sp["since"] >= self.sort_interval else sp["since"] for sp in self.species] + [0]) + 1
-        drift = constants.C_LIGHT * dt / self.d[0] * age + 4.0   # + the 3 nodes a deposit window reaches, + 1
+        ahead = max([sp.get("sort_ahead_used", 0.0) for sp in self.species] + [0.0]) * constants.C_LIGHT / self.d[0]
+        drift = constants.C_LIGHT * dt / self.d[0] * age + 4.0 + ahead   # + the 3 nodes a deposit window reaches, + 1; + the sort's look-ahead
         cols = int(np.ceil(drift / _lib.LPA_TILE3_X))
         return cols if 2 * cols < self.n[0] // _lib.LPA_TILE3_X else 0
 

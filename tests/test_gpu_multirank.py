@@ -43,7 +43,7 @@ def _problem():
     return dx, dy, dt, x, y, u, ig, w
 
 
-def _run(rank, world, port, q, left_only=False):
+def _run(rank, world, port, q, left_only=False, long_ahead=False):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -53,9 +53,13 @@ def _run(rank, world, port, q, left_only=False):
     comm = SlabComm(None, single=(world == 1))
     dx, dy, dt, x, y, u, ig, w = _problem()
     nx = NXG // world
-    eng = PicEngine2D(nx, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
+    eng = PicEngine2D(nx, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=20 if long_ahead else 5, block_particles=1024,
                       migrate_capacity=4096)
     eng.overlap = world == 2       # 2 ranks: J / rho guard exchange behind the interior tiles; 3 ranks: in line
+    if long_ahead:                 # the sort bins TEN steps ahead (fixed clock of 20): a relativistic particle is filed up to
+        eng.overflow_sort_fraction = 0      # 6.7 cells from where it is -- most of a tile column
+        u = u * 6.0
+        ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
     mine = (x >= lo) & (x < hi)
     if left_only:                   # plasma in the left 40 % of the box only: the last rank starts without a particle
@@ -91,11 +95,11 @@ def _run(rank, world, port, q, left_only=False):
         dist.destroy_process_group()
 
 
-def _launch(world, left_only=False):
+def _launch(world, left_only=False, long_ahead=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q, left_only)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, left_only, long_ahead)) for r in range(world)]
     for p in procs:
         p.daemon = True
         p.start()
@@ -804,3 +808,21 @@ def test_chain_sort_clock_follows_the_overflow_lists():
     assert sum(s0) >= 8
     assert n0 == NXG * NY * PPC
     assert c0 == pytest.approx(qw, rel=1e-9)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_look_ahead_binning_on_a_chain(world):
+    """the sort files a particle where it will be half an interval on (lpa_sort_tiles_ahead_2d) -- on a chain the edge /
+    interior split of the overlapped push and the leaver scan count tile columns from the faces, so they have to allow for
+    particles that sit closer to a face than their tile says (engine.edge_columns / leaver_columns).  A long fixed clock
+    (20 steps: ten steps of look-ahead) on a relativistic version of the base test's plasma: 2 ranks (overlapped exchange)
+    and 3 ranks against the single slab"""
+    t1, f1 = _launch(1, long_ahead=True)
+    t, f = _launch(world, long_ahead=True)
+    assert np.array_equal(t[:, 3], t1[:, 3])                          # live count
+    np.testing.assert_allclose(t[:, 0], t1[:, 0], rtol=1e-9)          # field energy
+    np.testing.assert_allclose(t[:, 2], t1[:, 2], rtol=1e-10)         # kinetic energy
+    assert np.abs(t[:, 1] - t1[:, 1]).max() <= 1e-12 * NXG * NY * PPC * 1.7e27 * (0.8e-6 / 20) ** 2 / PPC * 1.602176634e-19
+    for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho"):
+        scale = np.abs(f1[a]).max()
+        assert np.abs(f[a] - f1[a]).max() <= 1e-8 * scale, a
