@@ -562,6 +562,43 @@ int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead, double *c
                     int64_t *bucket_bound_min, int64_t *bucket_bound_max, void *workspace,
                     int64_t workspace_bytes, int64_t *nbuf, void *stream);
 
+/* ---- slab-to-slab transport (replaces the MPI point-to-point traffic of MPIManager2D/3D, core/mpi/mpi_manager.py:96-298
+ *      and core/mpi/sync_fields2d.c:365-640: Isend / Irecv per (patch, boundary, attribute) on duplicated communicators).
+ *      A communicator connects this rank with its two x neighbours in a ring (periodic x) or chain (open x).  One
+ *      EXCHANGE is a grouped set of face messages enqueued on a stream, no host synchronisation:
+ *        send_lo -> the left neighbour (arrives there as its recv_hi), send_hi -> the right neighbour (its recv_lo).
+ *      Four counts in doubles, one per buffer; what one rank sends through a face must be what its neighbour receives
+ *      through the opposite one (n_send_lo here == n_recv_hi of the left neighbour, ...).  A zero count skips that
+ *      buffer, a face without a neighbour (chain end) is skipped.  Every rank must pass the same number of messages in
+ *      the same order -- messages between one pair of ranks match in posting order (RCCL has no tags): per message the
+ *      sends are posted (hi, lo), the receives (lo, hi).
+ *      Kinds:
+ *        LPA_COMM_RCCL      ncclSend / ncclRecv inside one ncclGroupStart / End per exchange, on the caller's stream,
+ *                           device-to-device over xGMI.  The RCCL library is dlopen'ed (`librccl_path`, NULL =
+ *                           "librccl.so": the one the process has loaded already, e.g. PyTorch's) -- the library has no
+ *                           link-time dependency on it.  rank 0 makes the 128-byte id (lpa_comm_unique_id), the caller
+ *                           distributes it (any side channel) and every rank calls lpa_comm_create_rccl.
+ *        LPA_COMM_LOOPBACK  one process plays EVERY rank of a ring of identical slabs: what leaves through the high face
+ *                           comes back through the low one and vice versa, one copy kernel per exchange (size-1 periodic
+ *                           ring; with `size` = 2 the engines treat the slab as rank 0 of a 2-slab ring whose other slab is
+ *                           its translated copy -- every kernel of the N > 1 path runs, no wire). */
+typedef struct lpa_comm lpa_comm;
+#define LPA_COMM_RCCL 1
+#define LPA_COMM_LOOPBACK 2
+typedef struct {
+    const double *send_lo, *send_hi;
+    double *recv_lo, *recv_hi;
+    int64_t n_send_lo, n_send_hi, n_recv_lo, n_recv_hi;
+} lpa_face_msg;
+int lpa_comm_unique_id(void *id128, const char *librccl_path);
+int lpa_comm_create_rccl(lpa_comm **out, const void *id128, int32_t rank, int32_t size, int32_t periodic,
+                         const char *librccl_path);
+int lpa_comm_create_loopback(lpa_comm **out, int32_t size, int32_t periodic);
+int lpa_comm_destroy(lpa_comm *c);
+/* kind, rank, size, left, right (-1 = none), version of the transport library (NCCL_VERSION_CODE form; 0 = loopback) */
+int lpa_comm_info(const lpa_comm *c, int32_t info[6]);
+int lpa_comm_exchange(lpa_comm *c, const lpa_face_msg *msgs, int32_t nmsgs, void *stream);
+
 /* ---- one time step of ONE slab in one host call: the no-callback stage sequence of Simulation.run
  *      (simulation/simulation.py:937-1122) -- E half step + E guards, B half step + B guards, current reset, fused push +
  *      deposit of every species (tiled kernel + overflow list + loose particles, or the global kernel for an unsorted
@@ -569,10 +606,30 @@ int lpa_bucket_sort(double *x, double *y, double *z, uint8_t *is_dead, double *c
  *      inject], B guards, E half step + E guards.  Enqueues exactly the launches the per-stage entry points above
  *      would, in that order; `first_stage .. last_stage` (inclusive) selects a sub-range, so a caller with a callback
  *      at some stage splits the step there.  Not included: the sort (it needs the host for the live count -- the
- *      caller sorts before the step when due), slab-to-slab exchanges (single slab only) and anything a callback does.
+ *      caller sorts before the step when due) and anything a callback does.
  *      `continuity` != 0: this is a step between two real deposits, see LPA_PUSH_NO_RHO (the kernels skip rho,
  *      LPA_STAGE_RESET keeps it and takes out the absorbed particles' charge, LPA_STAGE_FOLD advances it).
- *      ev_start / ev_stop (optional): hipEvent_t recorded on `stream` around the species' tiled launch. */
+ *      ev_start / ev_stop (optional): hipEvent_t recorded on `stream` around the species' tiled launch.
+ *
+ *      SLAB RANKS (`slab` != NULL: one of several x slabs, mpi.sync_* of simulation.py:948-960,1043-1080,1104-1118): the
+ *      guard stages also exchange the x faces through slab->comm -- E / B planes straight from and into the field
+ *      arrays (x planes are contiguous: no pack / unpack launch) --, LPA_STAGE_FOLD sends the J / rho guard planes and
+ *      every species' leavers in ONE exchange (guard planes straight from the arrays into slab->cur_r_*; they are added to the
+ *      interior edge and the sent planes zeroed by one launch; arrivals are unpacked by one launch per species), and
+ *      on continuity steps the left neighbour's folded jx plane rides with the B planes of LPA_STAGE_B2_GUARD, after
+ *      which rho is advanced (instead of at LPA_STAGE_FOLD).  Stores must be tile ordered (arrival area behind
+ *      n_sorted).  With slab->comm == NULL the caller moves the faces itself (another transport): the stages then do
+ *      the work of a single slab with `local_axes` and the caller packs / exchanges / unpacks between sub-ranges. */
+typedef struct {
+    double *s_lo, *s_hi, *r_lo, *r_hi;  /* face messages of this species: 1 + LPA_MIG_NATTR * capacity doubles each */
+    int32_t *cursor;                    /* arrival-area cursor (device) */
+    int32_t *surplus;                   /* leavers that did not fit a message (device, may be NULL) */
+    const lpa_free_slots *fs;           /* NULL: arrivals go to the arrival area only */
+    int64_t area_capacity;
+    int32_t edge_cols;                  /* leaver scan: tile columns at each face (lpa_migrate_pack_edges_x), 0 = all slots */
+    int32_t reserved_;
+} lpa_step_migrate;
+
 typedef struct {
     lpa_particles p;            /* the store as of this step (p.n = slots in use) */
     const lpa_tiling *t;        /* NULL: unsorted store, everything through the global kernel */
@@ -580,7 +637,19 @@ typedef struct {
     lpa_push_params pp;         /* q, m, wrap, lo / hi, alo / ahi; dt, flags and the absorbed list are set by lpa_step */
     uint32_t *overflow, *overflow_count;
     void *ev_start, *ev_stop;
+    lpa_step_migrate mig;       /* slab ranks only */
 } lpa_step_species;
+
+typedef struct {
+    lpa_comm *comm;             /* NULL: the caller exchanges between sub-ranges */
+    double xlo, xhi;            /* a particle with x < xlo / x > xhi leaves through the low / high face */
+    double shift_lo, shift_hi;  /* added to x of what arrives through the low / high face (periodic wrap at the box ends) */
+    int64_t migrate_capacity;
+    double *cur_r_lo, *cur_r_hi;    /* 4 * ng * plane doubles each: the neighbours' J / rho guard planes */
+    double *jx_left_plane;          /* plane doubles (continuity steps: the left neighbour's folded jx at its node nx-1) */
+    int32_t rho_exchange;           /* != 0: the jx plane travels in LPA_STAGE_B2_GUARD (every step: all ranks alike) */
+    int32_t reserved_;
+} lpa_step_slab;
 
 typedef struct {
     lpa_grid grid;
@@ -590,13 +659,19 @@ typedef struct {
     const lpa_cpml_axis *e_axes[3], *b_axes[3];   /* all NULL: plain Yee update; else the fused CPML descriptors */
     int32_t nspecies, continuity;
     int32_t fuse_species;       /* 3-D: push all tile-ordered species with ONE lpa_push_deposit_tiled_multi_3d launch */
-    int32_t reserved_;
+    int32_t flags;              /* LPA_STEP_* */
     const lpa_step_species *species;
     double *absorbed;           /* see lpa_push_params.absorbed (NULL: no face absorbs) */
     uint32_t *absorbed_count;
     int64_t absorbed_capacity;
+    const lpa_step_slab *slab;  /* NULL: single slab */
 } lpa_step_desc;
 
+/* LPA_STEP_DEFER_E2_GUARDS: LPA_STAGE_E2 leaves the E guard cells stale (no wrap, no exchange).  For a caller that runs
+ * several steps back to back with nothing reading E in between: the next step starts with another E half step followed by
+ * its own guard stage (simulation.py:1112-1118, then :946-952 of the following step) and the E update itself never reads
+ * E guards -- one launch and, between slabs, one message round less per step.  The LAST step of such a run must not set it. */
+#define LPA_STEP_DEFER_E2_GUARDS 1
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

@@ -77,19 +77,41 @@ class lpa_free_slots(C.Structure):
     _fields_ = [("count", C.c_void_p), ("slot", C.c_void_p), ("edge_cols", C.c_int32), ("depth", C.c_int32)]
 
 
+class lpa_face_msg(C.Structure):
+    _fields_ = [("send_lo", C.c_void_p), ("send_hi", C.c_void_p), ("recv_lo", C.c_void_p), ("recv_hi", C.c_void_p),
+                ("n_send_lo", C.c_int64), ("n_send_hi", C.c_int64), ("n_recv_lo", C.c_int64), ("n_recv_hi", C.c_int64)]
+
+
+class lpa_step_migrate(C.Structure):
+    _fields_ = [("s_lo", C.c_void_p), ("s_hi", C.c_void_p), ("r_lo", C.c_void_p), ("r_hi", C.c_void_p),
+                ("cursor", C.c_void_p), ("surplus", C.c_void_p), ("fs", C.POINTER(lpa_free_slots)),
+                ("area_capacity", C.c_int64), ("edge_cols", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class lpa_step_species(C.Structure):
     _fields_ = [("p", lpa_particles), ("t", C.POINTER(lpa_tiling)), ("n_sorted", C.c_int64), ("pp", lpa_push_params),
-                ("overflow", C.c_void_p), ("overflow_count", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("overflow", C.c_void_p), ("overflow_count", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                ("mig", lpa_step_migrate)]
+
+
+class lpa_step_slab(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("xlo", C.c_double), ("xhi", C.c_double), ("shift_lo", C.c_double),
+                ("shift_hi", C.c_double), ("migrate_capacity", C.c_int64), ("cur_r_lo", C.c_void_p),
+                ("cur_r_hi", C.c_void_p), ("jx_left_plane", C.c_void_p), ("rho_exchange", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class lpa_step_desc(C.Structure):
     _fields_ = [("grid", lpa_grid), ("dim", C.c_int32), ("local_axes", C.c_int32), ("dt", C.c_double), ("eps0", C.c_double),
                 ("e_axes", C.POINTER(lpa_cpml_axis) * 3), ("b_axes", C.POINTER(lpa_cpml_axis) * 3),
-                ("nspecies", C.c_int32), ("continuity", C.c_int32), ("fuse_species", C.c_int32), ("reserved_", C.c_int32),
+                ("nspecies", C.c_int32), ("continuity", C.c_int32), ("fuse_species", C.c_int32), ("flags", C.c_int32),
                 ("species", C.POINTER(lpa_step_species)),
-                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64)]
+                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64),
+                ("slab", C.POINTER(lpa_step_slab))]
 
 
+LPA_COMM_RCCL, LPA_COMM_LOOPBACK = 1, 2
+LPA_STEP_DEFER_E2_GUARDS = 1
 LPA_STAGE_E1, LPA_STAGE_B1, LPA_STAGE_RESET, LPA_STAGE_PUSH, LPA_STAGE_FOLD, LPA_STAGE_B2, LPA_STAGE_B2_GUARD, \
     LPA_STAGE_E2 = range(8)
 
@@ -177,6 +199,12 @@ SIGNATURES = {
     "lpa_bucket_sort_workspace_bytes": (_i64, [_i64, _i64]),
     "lpa_bucket_sort": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.c_int32, _i64, _i64, _i64, _i64, _d, _d, _d,
                              _d, _d, _d, C.c_int32, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "lpa_comm_unique_id": (_i, [_vp, C.c_char_p]),
+    "lpa_comm_create_rccl": (_i, [C.POINTER(_vp), _vp, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]),
+    "lpa_comm_create_loopback": (_i, [C.POINTER(_vp), C.c_int32, C.c_int32]),
+    "lpa_comm_destroy": (_i, [_vp]),
+    "lpa_comm_info": (_i, [_vp, C.POINTER(C.c_int32)]),
+    "lpa_comm_exchange": (_i, [_vp, C.POINTER(lpa_face_msg), C.c_int32, _vp]),
     "lpa_step": (_i, [C.POINTER(lpa_step_desc), _i, _i, _vp]),
     "lpa_diag_fields": (_i, [_G, _d, _d, _vp, _vp]),
     "lpa_diag_particles": (_i, [_P, _d, _vp, _vp]),

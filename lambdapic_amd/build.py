@@ -15,7 +15,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "liblambdapic_amd.so"
 SOURCES = ["lpa_fields.hip", "lpa_particles.hip", "lpa_particles3d.hip", "lpa_sort.hip", "lpa_patches.hip",
-           "lpa_rho.hip", "lpa_step.hip", "lpa_patches3d.hip"]
+           "lpa_rho.hip", "lpa_step.hip", "lpa_patches3d.hip", "lpa_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 
@@ -32,7 +32,7 @@ def build_variant(name: str, defines, extra_flags=()) -> Path:
     out = CSRC / "build" / f"liblambdapic_amd_{name}.so"
     out.parent.mkdir(exist_ok=True)
     cmd = [_hipcc(), *FLAGS, *extra_flags, *[f"-D{d}" for d in defines], "-shared", *[str(CSRC / s) for s in SOURCES],
-           "-o", str(out)]
+           "-ldl", "-o", str(out)]
     subprocess.run(cmd, check=True)
     return out
 
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
     if rebuilt or not LIB.exists():
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-ldl", "-o", str(LIB)]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -35,6 +35,21 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
     return 1;
 }
 
+// ---- internal helpers shared between the translation units (not part of the C ABI; used by lpa_step) --------------
+// zero up to 32 device words in one launch (the per-step counters: overflow lists, message headers)
+int lpai_zero_words(uint32_t *const *words, int n, void *stream);
+// slab ranks, after the J / rho guard planes of the neighbours arrived in r_lo / r_hi ([4][ng][plane] each, NULL = no
+// neighbour on that face): interior edge += received planes, and the guard planes this rank sent away are zeroed
+int lpai_fold_faces(const lpa_grid *g, const double *r_lo, const double *r_hi, void *stream);
+// lpa_migrate_pack_edges_x / lpa_migrate_pack_x without their header memsets (zero_headers == 0: the caller zeroed them)
+int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
+                      double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
+                      int zero_headers, void *stream);
+// lpa_migrate_unpack(_tiled) of BOTH faces in one launch (fs == NULL: arrival area only)
+int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs,
+                         int64_t first_slot, int64_t area_capacity, int32_t *cursor, const double *buf_lo,
+                         const double *buf_hi, int64_t capacity, double shift_lo, double shift_hi, void *stream);
+
 // ---- kernel-side views (passed by value) ---------------------------------------------------------
 struct GridV {
     int nx, ny, nz, ng, NX, NY, NZ;

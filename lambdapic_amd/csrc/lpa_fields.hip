@@ -1014,6 +1014,54 @@ extern "C" int lpa_halo_faces(const lpa_grid *g, int op, int which, double *buf_
 }
 
 // =====================================================================================================
+// helpers of lpa_step (internal): per-step counter reset, and the slab form of the J / rho face fold
+// =====================================================================================================
+struct Words32 { uint32_t *w[32]; };
+
+__global__ void k_zero_words(Words32 a, int n) {
+    if ((int)threadIdx.x < n) *a.w[threadIdx.x] = 0u;
+}
+
+int lpai_zero_words(uint32_t *const *words, int n, void *stream) {
+    for (int done = 0; done < n; done += 32) {
+        Words32 a;
+        const int k = n - done < 32 ? n - done : 32;
+        for (int i = 0; i < k; i++) a.w[i] = words[done + i];
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, (hipStream_t)stream, a, k);
+        LPA_CHECK_LAUNCH("lpai_zero_words");
+    }
+    return LPA_OK;
+}
+
+// blockIdx.z = face; the received planes are added to the interior edge (fill of sync_currents,
+// core/mpi/sync_fields2d.c:76-102) and the guard planes that travelled to that neighbour are zeroed (:44-74)
+__global__ void __launch_bounds__(256) k_fold_faces(Ptr6 f, const double *r_lo, const double *r_hi, long plane, long nx,
+                                                    int ng) {
+    const long n = (long)ng * plane;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double *r = blockIdx.z == 0 ? r_lo : r_hi;
+    if (!r) return;
+    double *a = f.p[blockIdx.y];
+    const long edge = (blockIdx.z == 0 ? (long)ng : nx) * plane + t;      // interior edge planes
+    const long guard = (blockIdx.z == 0 ? 0L : nx + ng) * plane + t;      // my guard planes on that face
+    a[edge] += r[(long)blockIdx.y * n + t];
+    a[guard] = 0.0;
+}
+
+int lpai_fold_faces(const lpa_grid *g, const double *r_lo, const double *r_hi, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx >= g->ng, "lpai_fold_faces: bad grid");
+    if (!r_lo && !r_hi) return LPA_OK;
+    const long plane = (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1);
+    const long n = (long)g->ng * plane;
+    dim3 grid((unsigned)((n + 255) / 256), 4, 2);
+    hipLaunchKernelGGL(k_fold_faces, grid, dim3(256), 0, (hipStream_t)stream, cur_ptrs(g), r_lo, r_hi, plane,
+                       (long)g->nx, g->ng);
+    LPA_CHECK_LAUNCH("lpai_fold_faces");
+    return LPA_OK;
+}
+
+// =====================================================================================================
 // field diagnostics over the interior (reference tests/test_numerical_heating.py:19-37)
 // =====================================================================================================
 __global__ void __launch_bounds__(256) k_diag_fields(GridV g, double ce, double cb, double dv,

@@ -1128,3 +1128,119 @@ extern "C" int lpa_migrate_unpack_tiled(const lpa_particles *p, const lpa_grid *
     LPA_CHECK_LAUNCH("lpa_migrate_unpack_tiled");
     return LPA_OK;
 }
+
+// =====================================================================================================
+// internal forms used by lpa_step on slab ranks: pack without the header memsets (lpa_step zeroes every per-step
+// counter with one launch), unpack of both faces in one launch
+// =====================================================================================================
+int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
+                      double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
+                      int zero_headers, void *stream) {
+    if (zero_headers)
+        return edge_cols > 0 ? lpa_migrate_pack_edges_x(p, t, edge_cols, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, stream)
+                             : lpa_migrate_pack_x(p, xlo, xhi, buf_lo, buf_hi, capacity, surplus, stream);
+    LPA_REQUIRE(lpa_part_ok(p, 2) && buf_lo && buf_hi && capacity > 0 && xlo < xhi, "lpai_migrate_pack: bad args");
+    if (p->n == 0) return LPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (edge_cols <= 0) {
+        hipLaunchKernelGGL(k_migrate_pack_x, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, st, make_partv(p), xlo, xhi,
+                           buf_lo, buf_hi, (long)capacity, surplus);
+        LPA_CHECK_LAUNCH("lpai_migrate_pack");
+        return LPA_OK;
+    }
+    LPA_REQUIRE(!fs || (free_slots_ok(fs, t) && fs->edge_cols >= edge_cols), "lpai_migrate_pack: bad free-slot stacks");
+    LPA_REQUIRE(t && t->tile_off && t->tiles_x > 0 && t->tiles_y > 0 && t->n_sorted >= 0 && t->n_sorted <= p->n &&
+                    2 * edge_cols <= t->tiles_x, "lpai_migrate_pack: bad tiling / edge_cols");
+    const int per_col = t->tiles_y * (t->tiles_z > 0 ? t->tiles_z : 1);
+    const int ntiles = t->tiles_x * per_col;
+    long nblk = (p->n + 255) / 256;
+    if (nblk > 16384) nblk = 16384;
+    hipLaunchKernelGGL(k_migrate_pack_edges_x, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), t->tile_off, ntiles,
+                       edge_cols * per_col, (long)t->n_sorted, xlo, xhi, buf_lo, buf_hi, (long)capacity,
+                       make_free_slots(fs, t), surplus);
+    LPA_CHECK_LAUNCH("lpai_migrate_pack");
+    return LPA_OK;
+}
+
+__global__ void __launch_bounds__(256) k_migrate_unpack2(PartV p, KeyGeom kg, int ntiles, FreeSlots fs, long first_slot,
+                                                         long area_cap, int32_t *cursor, const double *buf_lo,
+                                                         const double *buf_hi, long cap, double shift_lo,
+                                                         double shift_hi) {
+    const double *buf = blockIdx.y == 0 ? buf_lo : buf_hi;
+    const double shift_x = blockIdx.y == 0 ? shift_lo : shift_hi;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)*(const unsigned long long *)buf;
+    if (n > cap) n = cap;
+    if ((long)blockIdx.x * blockDim.x >= n) return;      // (block-uniform: nothing of this block's range arrived)
+    const bool active = t < n;
+    const double *d = buf + 1;
+    const double x = active ? d[0 * cap + t] + shift_x : 0.0, y = active ? d[1 * cap + t] : 0.0,
+                 z = (active && kg.dim == 3) ? d[2 * cap + t] : 0.0;
+    long o = -1;
+    if (fs.count && active && !(isnan(x) || isnan(y) || isnan(z))) {
+        int is = ifloor((x - kg.x0) * kg.inv_dx + 0.5), js = ifloor((y - kg.y0) * kg.inv_dy + 0.5);
+        is = is < 0 ? 0 : (is >= kg.nx ? kg.nx - 1 : is);
+        js = js < 0 ? 0 : (js >= kg.ny ? kg.ny - 1 : js);
+        int tile;
+        if (kg.dim == 2) {
+            tile = (is / TX) * kg.tiles_y + js / TY;
+        } else {
+            int ks = ifloor((z - kg.z0) * kg.inv_dz + 0.5);
+            ks = ks < 0 ? 0 : (ks >= kg.nz ? kg.nz - 1 : ks);
+            tile = ((is / T3X) * kg.tiles_y + js / T3Y) * kg.tiles_z + ks / T3Z;
+        }
+        int e = edge_index(tile, ntiles, fs.edge_tiles);
+        if (e >= 0) {
+            int k = atomicSub(&fs.count[e], 1) - 1;
+            if (k >= 0) o = fs.slot[(long)e * fs.depth + k];
+            else atomicAdd(&fs.count[e], 1);
+        }
+    }
+    {
+        long slot = area_slot_wave(active && o < 0, cursor);
+        if (!active) return;
+        if (o < 0) {
+            if (slot >= area_cap) return;  // cursor > area_cap tells the host the area overflowed
+            o = first_slot + slot;
+        }
+    }
+    p.x[o] = x;
+    p.y[o] = y;
+    if (p.z) p.z[o] = d[2 * cap + t];
+    p.ux[o] = d[3 * cap + t];
+    p.uy[o] = d[4 * cap + t];
+    p.uz[o] = d[5 * cap + t];
+    p.ig[o] = d[6 * cap + t];
+    p.w[o] = d[7 * cap + t];
+    if (p.id) p.id[o] = (unsigned long long)__double_as_longlong(d[8 * cap + t]);
+    if (p.dead) p.dead[o] = 0;
+}
+
+int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs,
+                         int64_t first_slot, int64_t area_capacity, int32_t *cursor, const double *buf_lo,
+                         const double *buf_hi, int64_t capacity, double shift_lo, double shift_hi, void *stream) {
+    LPA_REQUIRE(p && p->x && p->y && p->ux && p->uy && p->uz && p->inv_gamma && p->w && buf_lo && buf_hi && cursor &&
+                    capacity > 0 && first_slot >= 0 && area_capacity >= 0,
+                "lpai_migrate_unpack2: bad args");
+    if (area_capacity == 0 && !fs) return LPA_OK;
+    KeyGeom kg{};
+    int ntiles = 0;
+    if (fs) {
+        LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && t && t->tiles_x > 0 && t->tiles_y > 0 &&
+                        free_slots_ok(fs, t), "lpai_migrate_unpack2: bad grid / tiling / free-slot stacks");
+        const int dim = t->tiles_z > 0 ? 3 : 2;
+        LPA_REQUIRE(dim == 2 || (p->z && g->nz > 1 && g->dz > 0), "lpai_migrate_unpack2: 3-D tiling needs z");
+        kg.dim = dim; kg.nx = g->nx; kg.ny = g->ny; kg.nz = dim == 3 ? g->nz : 1;
+        kg.tiles_y = t->tiles_y; kg.tiles_z = dim == 3 ? t->tiles_z : 1;
+        kg.x0 = g->x0; kg.y0 = g->y0; kg.z0 = g->z0;
+        kg.inv_dx = 1.0 / g->dx; kg.inv_dy = 1.0 / g->dy; kg.inv_dz = dim == 3 ? 1.0 / g->dz : 0.0;
+        ntiles = t->tiles_x * t->tiles_y * (dim == 3 ? t->tiles_z : 1);
+    } else {
+        kg.dim = p->z ? 3 : 2;
+    }
+    hipLaunchKernelGGL(k_migrate_unpack2, dim3((unsigned)((capacity + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream,
+                       make_partv(p), kg, ntiles, make_free_slots(fs, t), (long)first_slot, (long)area_capacity, cursor,
+                       buf_lo, buf_hi, (long)capacity, shift_lo, shift_hi);
+    LPA_CHECK_LAUNCH("lpai_migrate_unpack2");
+    return LPA_OK;
+}

@@ -5,7 +5,42 @@
 // stage loop issues a 2-D laser-target step (config C3: ~20 launches) no faster than the GPU executes it.  lpa_step
 // enqueues the same launches, in the same order, from C: the host cost drops from ~15 us to ~3 us per launch and the
 // step becomes GPU bound.  It calls the public entry points of this library -- nothing is re-implemented here.
+//
+// Slab ranks (d->slab): the guard stages also move the x faces through the slab's transport (lpa_comm.hip), from C, on
+// the same stream -- where the reference brackets its intra-rank work with mpi.sync_*_start / _wait
+// (simulation.py:948-960, 1043-1080, 1104-1118).  x planes are contiguous in the field arrays, so E / B guard planes are
+// sent from and received into the arrays themselves (no pack / unpack launch); the J / rho guard planes leave from the
+// arrays and are added by one launch; four message rounds per step (B1 | J + rho + every species' leavers | B2 + the jx
+// plane of the continuity update | E2, E1 of the next step when the caller defers the E2 guards).
 #include "lpa_common.hpp"
+
+static long plane_of(const lpa_grid *g) { return (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1); }
+
+// E (which = 1) or B (which = 2) guard planes between slabs: my interior edge planes become the neighbours' guard planes
+static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx, void *st) {
+    const lpa_step_slab *sl = d->slab;
+    const lpa_grid *g = &d->grid;
+    const long plane = plane_of(g), n = (long)g->ng * plane;
+    double *f[3] = {which == 1 ? g->ex : g->bx, which == 1 ? g->ey : g->by, which == 1 ? g->ez : g->bz};
+    lpa_face_msg m[4];
+    for (int c = 0; c < 3; c++) {
+        m[c].send_lo = f[c] + (long)g->ng * plane;            // interior rows [0, ng)
+        m[c].send_hi = f[c] + (long)g->nx * plane;            // interior rows [nx - ng, nx)
+        m[c].recv_lo = f[c];                                  // my low guard
+        m[c].recv_hi = f[c] + (long)(g->nx + g->ng) * plane;  // my high guard
+        m[c].n_send_lo = m[c].n_send_hi = m[c].n_recv_lo = m[c].n_recv_hi = n;
+    }
+    int nm = 3;
+    if (with_jx) {
+        // rho continuity: the backward difference of jx at my node 0 needs the LEFT neighbour's folded jx at its last node
+        m[3].send_lo = nullptr; m[3].recv_hi = nullptr; m[3].n_send_lo = m[3].n_recv_hi = 0;
+        m[3].send_hi = g->jx + (long)(g->ng + g->nx - 1) * plane;
+        m[3].recv_lo = sl->jx_left_plane;
+        m[3].n_send_hi = m[3].n_recv_lo = plane;
+        nm = 4;
+    }
+    return lpa_comm_exchange(sl->comm, m, nm, st);
+}
 
 static int step_fields(const lpa_step_desc *d, bool efield, void *st) {
     const lpa_grid *g = &d->grid;
@@ -48,11 +83,6 @@ static int step_push_fused_3d(const lpa_step_desc *d, void *st, bool *done) {
         n++;
     }
     if (n == 0) return LPA_OK;
-    for (int k = 0; k < n; k++)
-        if (hipMemsetAsync(cnt[k], 0, sizeof(uint32_t), (hipStream_t)st) != hipSuccess) {
-            lpa_set_error("lpa_step: memset of the overflow counter failed");
-            return LPA_ERR_HIP;
-        }
     const lpa_step_species *first = &d->species[idx[0]];
     if (first->ev_start && hipEventRecord((hipEvent_t)first->ev_start, (hipStream_t)st) != hipSuccess) {
         lpa_set_error("lpa_step: hipEventRecord failed");
@@ -74,9 +104,33 @@ static int step_push_fused_3d(const lpa_step_desc *d, void *st, bool *done) {
     return LPA_OK;
 }
 
+// every per-step device counter in ONE launch: the overflow-list counters of the tiled pushes and, on slab ranks, the
+// count headers of the particle messages (send side; receive side of a face without a neighbour: nothing arrives)
+static int step_zero_counters(const lpa_step_desc *d, void *st, bool overflow = true) {
+    uint32_t *w[6 * 64];
+    int n = 0;
+    const lpa_step_slab *sl = d->slab;
+    int32_t info[6] = {0, 0, 1, -1, -1, 0};
+    if (sl && sl->comm)
+        if (int e = lpa_comm_info(sl->comm, info)) return e;
+    for (int s = 0; s < d->nspecies && s < 64; s++) {
+        const lpa_step_species *sp = &d->species[s];
+        if (overflow && sp->p.n > 0 && sp->t && sp->n_sorted > 0 && sp->overflow_count) w[n++] = sp->overflow_count;
+        if (sl && sl->comm) {
+            uint32_t *h[4] = {(uint32_t *)sp->mig.s_lo, (uint32_t *)sp->mig.s_hi,
+                              info[3] < 0 ? (uint32_t *)sp->mig.r_lo : nullptr, info[4] < 0 ? (uint32_t *)sp->mig.r_hi : nullptr};
+            for (int k = 0; k < 4; k++)
+                if (h[k]) { w[n++] = h[k]; w[n++] = h[k] + 1; }      // (the header is a 64-bit count)
+        }
+    }
+    return n ? lpai_zero_words(w, n, st) : LPA_OK;
+}
+
 static int step_push(const lpa_step_desc *d, void *st) {
     const lpa_grid *g = &d->grid;
     bool done[64] = {false};
+    LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
+    if (int e = step_zero_counters(d, st)) return e;
     if (d->dim == 3 && d->fuse_species && d->nspecies <= 64)
         if (int e = step_push_fused_3d(d, st, done)) return e;
     for (int s = 0; s < d->nspecies; s++) {
@@ -86,10 +140,6 @@ static int step_push(const lpa_step_desc *d, void *st) {
         lpa_push_params pp = species_params(d, sp);
         int e;
         if (sp->t && sp->n_sorted > 0) {
-            if (hipMemsetAsync(sp->overflow_count, 0, sizeof(uint32_t), (hipStream_t)st) != hipSuccess) {
-                lpa_set_error("lpa_step: memset of the overflow counter failed");
-                return LPA_ERR_HIP;
-            }
             if (sp->ev_start && hipEventRecord((hipEvent_t)sp->ev_start, (hipStream_t)st) != hipSuccess) {
                 lpa_set_error("lpa_step: hipEventRecord failed");
                 return LPA_ERR_HIP;
@@ -119,6 +169,62 @@ static int step_push(const lpa_step_desc *d, void *st) {
     return LPA_OK;
 }
 
+// slab ranks, LPA_STAGE_FOLD: leavers of every species into their face messages, ONE exchange for the J / rho guard
+// planes and all particle messages (sync_currents + sync_particles back to back, simulation.py:1043-1080), the planes
+// folded in, the periodic fold along the local axes, the arrivals seated
+static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
+    const lpa_step_slab *sl = d->slab;
+    if (!headers_zeroed)      // (LPA_STAGE_PUSH of this call did it otherwise)
+        if (int e = step_zero_counters(d, st, false)) return e;
+    const lpa_grid *g = &d->grid;
+    int32_t info[6];
+    if (int e = lpa_comm_info(sl->comm, info)) return e;
+    const bool has_left = info[3] >= 0, has_right = info[4] >= 0;
+    LPA_REQUIRE(sl->cur_r_lo && sl->cur_r_hi && sl->migrate_capacity > 0 && sl->xlo < sl->xhi, "lpa_step: bad slab descriptor");
+    const long plane = plane_of(g), n = (long)g->ng * plane;
+    const long nmig = 1 + (long)LPA_MIG_NATTR * sl->migrate_capacity;
+    lpa_face_msg m[4 + 64];
+    double *f[4] = {g->jx, g->jy, g->jz, g->rho};
+    for (int c = 0; c < 4; c++) {
+        m[c].send_lo = f[c];                                   // my low guard planes -> the left neighbour's interior edge
+        m[c].send_hi = f[c] + (long)(g->nx + g->ng) * plane;
+        m[c].recv_lo = sl->cur_r_lo + (long)c * n;
+        m[c].recv_hi = sl->cur_r_hi + (long)c * n;
+        m[c].n_send_lo = m[c].n_send_hi = m[c].n_recv_lo = m[c].n_recv_hi = n;
+    }
+    int nm = 4;
+    for (int s = 0; s < d->nspecies; s++) {
+        const lpa_step_species *sp = &d->species[s];
+        const lpa_step_migrate *mg = &sp->mig;
+        LPA_REQUIRE(mg->s_lo && mg->s_hi && mg->r_lo && mg->r_hi && mg->cursor, "lpa_step: species without migration buffers");
+        LPA_REQUIRE(sp->t && sp->n_sorted >= 0, "lpa_step: a slab rank needs tile-ordered stores (arrival area)");
+        if (int e = lpai_migrate_pack(&sp->p, sp->t, mg->edge_cols, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity,
+                                      mg->edge_cols > 0 ? mg->fs : nullptr, mg->surplus, 0, st)) return e;
+        m[nm].send_lo = mg->s_lo; m[nm].send_hi = mg->s_hi; m[nm].recv_lo = mg->r_lo; m[nm].recv_hi = mg->r_hi;
+        m[nm].n_send_lo = m[nm].n_send_hi = m[nm].n_recv_lo = m[nm].n_recv_hi = nmig;
+        nm++;
+    }
+    if (int e = lpa_comm_exchange(sl->comm, m, nm, st)) return e;
+    if (int e = lpai_fold_faces(g, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr, st)) return e;
+    if (int e = lpa_current_fold(g, d->local_axes, st)) return e;
+    for (int s = 0; s < d->nspecies; s++) {
+        const lpa_step_species *sp = &d->species[s];
+        const lpa_step_migrate *mg = &sp->mig;
+        if (int e = lpai_migrate_unpack2(&sp->p, g, sp->t, mg->edge_cols > 0 ? mg->fs : nullptr, sp->n_sorted, mg->area_capacity,
+                                         mg->cursor, mg->r_lo, mg->r_hi, sl->migrate_capacity, sl->shift_lo, sl->shift_hi, st))
+            return e;
+    }
+    return LPA_OK;
+}
+
+static int slab_rho(const lpa_step_desc *d, void *st) {
+    const lpa_step_slab *sl = d->slab;
+    int32_t info[6];
+    if (int e = lpa_comm_info(sl->comm, info)) return e;
+    const int split = (info[3] >= 0 ? 1 : 0) | (info[4] >= 0 ? 2 : 0);
+    return lpa_rho_continuity(&d->grid, d->dt, d->local_axes, split, info[3] >= 0 ? sl->jx_left_plane : nullptr, st);
+}
+
 extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage, void *stream) {
     LPA_REQUIRE(d && (d->dim == 2 || d->dim == 3) && d->dt > 0 && d->nspecies >= 0 && (d->nspecies == 0 || d->species),
                 "lpa_step: bad descriptor");
@@ -127,17 +233,25 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     LPA_REQUIRE(!d->continuity || !d->absorbed || (d->absorbed_count && d->absorbed_capacity > 0),
                 "lpa_step: bad absorbed list");
     const lpa_grid *g = &d->grid;
+    // slab rank with a transport of its own: the guard stages move the x faces too
+    const bool slab = d->slab && d->slab->comm;
+    LPA_REQUIRE(!slab || !(d->local_axes & 1), "lpa_step: x is split over slabs, not periodic inside one");
+    LPA_REQUIRE(!slab || !d->slab->rho_exchange || d->slab->jx_left_plane, "lpa_step: jx_left_plane missing");
+    bool headers_zeroed = false;
     for (int stage = first_stage; stage <= last_stage; stage++) {
         int e = LPA_OK;
         switch (stage) {
         case LPA_STAGE_E1:
         case LPA_STAGE_E2:      // update_efield(dt / 2) + sync_guard_fields(E): simulation.py:946-952, 1112-1118
             e = step_fields(d, true, stream);
+            if (stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2_GUARDS)) break;
             if (!e) e = lpa_guard_wrap(g, 1, d->local_axes, stream);
+            if (!e && slab) e = slab_exchange_guards(d, 1, false, stream);
             break;
         case LPA_STAGE_B1:      // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
             e = step_fields(d, false, stream);
             if (!e) e = lpa_guard_wrap(g, 2, d->local_axes, stream);
+            if (!e && slab) e = slab_exchange_guards(d, 2, false, stream);
             break;
         case LPA_STAGE_RESET:   // current_depositor.reset(): :980-981
             if (d->continuity) {
@@ -154,8 +268,15 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             break;
         case LPA_STAGE_PUSH:    // pusher[ispec](dt, unified=True) for every species: :983-990
             e = step_push(d, stream);
+            headers_zeroed = true;
             break;
-        case LPA_STAGE_FOLD:    // sync_currents (one slab: the periodic fold): :1043, 1155-1176
+        case LPA_STAGE_FOLD:    // sync_currents (+ sync_particles between slabs): :1043-1080, 1155-1176
+            if (slab) {
+                e = slab_fold(d, headers_zeroed, stream);
+                // (rho: with rho_exchange the jx plane rides with the B planes of LPA_STAGE_B2_GUARD and rho follows there)
+                if (!e && d->continuity && !d->slab->rho_exchange) e = slab_rho(d, stream);
+                break;
+            }
             e = lpa_current_fold(g, d->local_axes, stream);
             if (!e && d->continuity) e = lpa_rho_continuity(g, d->dt, d->local_axes, 0, nullptr, stream);
             break;
@@ -164,6 +285,10 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             break;
         case LPA_STAGE_B2_GUARD:    // sync_guard_fields(B): :1103-1108
             e = lpa_guard_wrap(g, 2, d->local_axes, stream);
+            if (!e && slab) {
+                e = slab_exchange_guards(d, 2, d->slab->rho_exchange != 0, stream);
+                if (!e && d->continuity && d->slab->rho_exchange) e = slab_rho(d, stream);
+            }
             break;
         }
         if (e) return e;

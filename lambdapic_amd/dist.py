@@ -7,8 +7,16 @@ message per face and exchange, issued as a grouped send/recv pair set through
 ``ncclGroupStart .. ncclSend/ncclRecv .. ncclGroupEnd`` over the xGMI links to the two neighbours.
 The path has no collective: every step is nearest neighbour only (as in the reference, which never
 all-reduces inside the step).  With one rank nothing is sent (the engine wraps locally).
+
+NATIVE TRANSPORT (``SlabComm.attach_rccl`` / ``LoopbackComm``): the face messages travel through the library's own
+communicator (csrc/lpa_comm.hip: ncclSend / ncclRecv groups issued from C on the step's stream) and the engines enqueue a
+whole slab step -- kernels AND exchanges -- with one ``lpa_step`` call; ``torch.distributed`` then only carries the control
+plane (id broadcast, barrier, diagnostics).  Without it (gloo rehearsals, ranks sharing a GPU in the tests) the
+exchanges below run from Python between sub-ranges of the step.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -27,6 +35,8 @@ class SlabComm:
         else:
             self.group, self.rank, self.size = None, 0, 1
         self.p2p_group = p2p_group if p2p_group is not None else self.group
+        self.native = None          # lpa_comm* of the library's own transport (attach_rccl / LoopbackComm)
+        self.native_kind = None
         self.periodic = periodic
         # ring (periodic x) or chain (open / PML x edges: the end ranks have one neighbour)
         self.left = (self.rank - 1) % self.size if (periodic or self.rank > 0) else -1
@@ -37,7 +47,7 @@ class SlabComm:
         `core/mpi/mpi_manager.py:35-46`): a restored communicator binds to the default group of the process that
         loads it; ``rebind`` attaches other groups (e.g. an RCCL group for the face messages)"""
         st = self.__dict__.copy()
-        st["group"] = st["p2p_group"] = None
+        st["group"] = st["p2p_group"] = st["native"] = None
         return st
 
     def __setstate__(self, st):
@@ -77,6 +87,9 @@ class SlabComm:
         With the ``gloo`` backend (CPU rehearsal of the multi-rank path, or several ranks sharing
         one GPU in a test) device tensors are staged through host memory.
         """
+        if self.native is not None:
+            self._native_exchange([(send_lo, send_hi, recv_lo, recv_hi)])
+            return []
         if self.size == 1:
             if self.periodic:
                 recv_lo.copy_(send_hi)   # my own high edge is my low guard's periodic source
@@ -113,6 +126,9 @@ class SlabComm:
         recv_hi), ...].  Every rank lists its sets in the same order; per set the posting order is the one
         of ``exchange`` (sends hi, lo -- receives lo, hi), set after set, so messages between one pair of ranks
         still match in posting order when both neighbours are the same rank (no tags: see ``exchange``)."""
+        if self.native is not None:
+            self._native_exchange(sets)
+            return []
         if self.size == 1:
             for s_ in sets:
                 self.exchange(*s_)
@@ -143,6 +159,66 @@ class SlabComm:
             if self.has_right:
                 recv_hi.copy_(r_hi)
         return reqs
+
+    # ---- the library's own transport --------------------------------------------------------------------------------
+    def attach_rccl(self, librccl=None):
+        """face messages through RCCL calls issued by the library (csrc/lpa_comm.hip): rank 0 makes the 128-byte id, the
+        control group broadcasts it, every rank joins -- collective over ``group``.  The calling thread's current device is
+        the one the communicator binds (``torch.cuda.set_device`` first).  ``librccl``: path of the RCCL library to dlopen
+        (default: the one this process has loaded already -- PyTorch's)."""
+        from ._lib import LPA_COMM_RCCL, check, lib
+        L = lib()
+        path = librccl.encode() if librccl else None
+        idbuf = (C.c_char * 128)()
+        if self.rank == 0:
+            check(L.lpa_comm_unique_id(idbuf, path), "lpa_comm_unique_id")
+        if self.size > 1:
+            t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+            if dist.get_backend(self.group) != "gloo":
+                t = t.cuda()
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            idbuf = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        h = C.c_void_p()
+        check(L.lpa_comm_create_rccl(C.byref(h), idbuf, self.rank, self.size, int(self.periodic), path),
+              "lpa_comm_create_rccl")
+        self.native, self.native_kind = h, LPA_COMM_RCCL
+        return self
+
+    def native_info(self):
+        """(kind, rank, size, left, right, transport library version) of the native communicator"""
+        from ._lib import check, lib
+        info = (C.c_int32 * 6)()
+        check(lib().lpa_comm_info(self.native, info), "lpa_comm_info")
+        return tuple(info)
+
+    def close(self):
+        if self.native is not None:
+            from ._lib import lib
+            lib().lpa_comm_destroy(self.native)
+            self.native = None
+
+    def _native_exchange(self, sets):
+        from ._lib import check, lib, lpa_face_msg
+        arr = (lpa_face_msg * len(sets))()
+        dev = None
+        for k, tensors in enumerate(sets):
+            for t in tensors:
+                if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+                    raise ValueError("native face messages are contiguous float64 device tensors")
+                dev = t.device
+            s_lo, s_hi, r_lo, r_hi = tensors
+            m = arr[k]
+            m.send_lo, m.send_hi, m.recv_lo, m.recv_hi = s_lo.data_ptr(), s_hi.data_ptr(), r_lo.data_ptr(), r_hi.data_ptr()
+            m.n_send_lo, m.n_send_hi, m.n_recv_lo, m.n_recv_hi = s_lo.numel(), s_hi.numel(), r_lo.numel(), r_hi.numel()
+        check(lib().lpa_comm_exchange(self.native, arr, len(sets), torch.cuda.current_stream(dev).cuda_stream),
+              "lpa_comm_exchange")
+
+    def arrival_shift(self, box_length):
+        """what is added to x of the particles arriving through (my low face, my high face): the periodic wrap at the two
+        ends of the box (`core/patch/sync_particles_2d.c:168-182`)"""
+        lo = -box_length if (self.rank == 0 and self.periodic) else 0.0
+        hi = box_length if (self.rank == self.size - 1 and self.periodic) else 0.0
+        return lo, hi
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         """diagnostics only (never inside the step): the reference's scalar reductions (energy, charge, live
@@ -196,6 +272,51 @@ class SlabComm:
     def barrier(self):
         if self.size > 1:
             dist.barrier(group=self.group)
+
+
+class LoopbackComm(SlabComm):
+    """ONE process as rank 0 of a periodic ring of ``size`` (1 or 2) identical slabs: what a neighbour would send through
+    a face is what this slab itself sends through the opposite one (``lpa_comm_create_loopback``; arriving particles are
+    translated by one slab width).  Every kernel of the N > 1 path runs, only the wire is a device copy -- the compute-side
+    cost of the slab decomposition on one GPU (tools/bench_mirror.py), and a test bed in which a slab must reproduce the
+    corresponding half of a single-slab run of the doubled periodic box.  ``rccl=True``: the same ring through RCCL
+    (a communicator of one rank sending to itself): the real ncclSend / ncclRecv path, launch costs included."""
+
+    def __init__(self, slab_width, size=2, rccl=False):
+        super().__init__(None, periodic=True, single=True)
+        from ._lib import LPA_COMM_LOOPBACK, LPA_COMM_RCCL, check, lib
+        L = lib()
+        h = C.c_void_p()
+        if rccl:
+            idbuf = (C.c_char * 128)()
+            check(L.lpa_comm_unique_id(idbuf, None), "lpa_comm_unique_id")
+            check(L.lpa_comm_create_rccl(C.byref(h), idbuf, 0, 1, 1, None), "lpa_comm_create_rccl")
+        else:
+            check(L.lpa_comm_create_loopback(C.byref(h), int(size), 1), "lpa_comm_create_loopback")
+        self.native, self.native_kind = h, (LPA_COMM_RCCL if rccl else LPA_COMM_LOOPBACK)
+        self.size, self.rank = int(size), 0
+        self.left = self.right = (1 if size == 2 else 0)
+        self.slab_width = float(slab_width)
+
+    def arrival_shift(self, box_length):
+        # the neighbour is this slab's copy one slab width further: what left through my high face at xhi + d re-enters
+        # through my low face at xlo + d
+        return -self.slab_width, self.slab_width
+
+    def barrier(self):
+        pass
+
+    def reduce_diagnostics(self, d):
+        return d
+
+    def any(self, flag):
+        return bool(flag)
+
+    def allmin(self, value):
+        return float(value)
+
+    def allreduce_sum(self, t):
+        return t
 
 
 def exchange_faces(comm: SlabComm, pack, unpack, bufs, pack2=None, unpack2=None):

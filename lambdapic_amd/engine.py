@@ -434,6 +434,15 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if self.comm.size > 1:
             h = self._halo_views(3 * bin(which).count("1") * self.ng * self.grid.NY)
             # my low interior edge becomes the LEFT neighbour's high guard and vice versa
+            rho_msg = self._rho_message()      # a deferred rho update: its jx plane rides with these planes (rho.py)
+            if rho_msg is not None:
+                lo, hi = (h["s_lo"] if self.comm.has_left else None), (h["s_hi"] if self.comm.has_right else None)
+                self._faces(_lib.LPA_HALO_PACK_GUARD_SRC, which)(lo, hi)
+                self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"]), rho_msg])
+                self._faces(_lib.LPA_HALO_UNPACK_GUARD, which)(h["r_lo"] if self.comm.has_left else None,
+                                                               h["r_hi"] if self.comm.has_right else None)
+                self._complete_rho()
+                return
             exchange_faces(
                 self.comm,
                 lambda side, b: check(self.L.lpa_halo_pack_guard_src(self._g(), which, side, b.data_ptr(), st),
@@ -787,9 +796,14 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         self._mig_unpack(ispec, m, fs)
 
-    def _mig_pack(self, ispec):
-        """leavers of species ``ispec`` into its two face messages; returns (buffers, free-slot stacks)"""
-        sp = self.species[ispec]
+    def _owner_bounds_x(self):
+        """a particle left of / right of these belongs to the left / right neighbour"""
+        return self.x0 - self.dx / 2, self.x0 + (self.nx - 1) * self.dx + self.dx / 2
+
+    def _slab_species(self, sp, pushed):
+        """migration bookkeeping of one species on a slab rank: face message buffers, arrival cursor, surplus counter,
+        free-slot stacks (or None), arrival-area capacity, tile columns the leaver scan covers (0 = every slot).
+        ``pushed``: this step's push has run already (its age counts)"""
         ws = self._sort_ws(sp)
         cap = self.migrate_capacity
         if ws["mig"] is None:
@@ -797,16 +811,36 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             ws["mig"] = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
         if sp.tiling is None:
             raise _lib.LpaError("sync_particles on a slab decomposition needs a sorted store (arrival area)")
-        m, st = ws["mig"], self.stream
-        pc = sp.cset.cstruct(sp.n)
-        xlo = self.x0 - self.dx / 2
-        xhi = self.x0 + (self.nx - 1) * self.dx + self.dx / 2
         # only the tile columns within drift range of an x face (and the loose particles) can hold leavers
-        cols = self.leaver_columns(sp.steps_since_sort)
+        cols = self.leaver_columns(sp.steps_since_sort + (0 if pushed else 1))
         fs = ws.get("fs") if self.reuse_slots else None
         if fs is not None and (cols == 0 or cols > fs.edge_cols):
             fs = None        # the order is older than the stacks were sized for
-        surplus = ws["counters"][3:4].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
+        return {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
+                "area": ws["area"], "cols": cols}
+
+    def _slab_fill(self, slab):
+        """the slab section of an lpa_step descriptor (step.py); returns what must stay alive until the launches ran"""
+        slab.xlo, slab.xhi = self._owner_bounds_x()
+        slab.shift_lo, slab.shift_hi = self.comm.arrival_shift(self.Lx)
+        slab.migrate_capacity = self.migrate_capacity
+        h = self._halo_views(4 * self.ng * self.grid.NY)
+        slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
+        slab.rho_exchange = int(self.rho_continuity and self._rho_available())
+        if slab.rho_exchange:
+            self._jx_plane_bufs()
+            slab.jx_left_plane = self._jx_plane.data_ptr()
+        return h
+
+    def _mig_pack(self, ispec):
+        """leavers of species ``ispec`` into its two face messages; returns (buffers, free-slot stacks)"""
+        sp = self.species[ispec]
+        mig = self._slab_species(sp, pushed=True)
+        ws, cap, st = self._sort_ws(sp), self.migrate_capacity, self.stream
+        m, cols, fs = mig["bufs"], mig["cols"], mig["fs"]
+        pc = sp.cset.cstruct(sp.n)
+        xlo, xhi = self._owner_bounds_x()
+        surplus = mig["surplus"].data_ptr()          # leavers beyond migrate_capacity (checked at the next sort)
         if cols:
             check(self.L.lpa_migrate_pack_edges_x(C.byref(pc), C.byref(sp.tiling), cols, xlo, xhi,
                                                   m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
@@ -828,8 +862,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         cur = ws["counters"][1:2].data_ptr()
         # arrivals through my low face come from the left neighbour; at the global low edge they
         # crossed the periodic boundary: x > xmax_global -> x - Lx (sync_particles_2d.c:168-182)
-        shift_lo = -self.Lx if (self.comm.rank == 0 and self.periodic_x) else 0.0
-        shift_hi = self.Lx if (self.comm.rank == self.comm.size - 1 and self.periodic_x) else 0.0
+        shift_lo, shift_hi = self.comm.arrival_shift(self.Lx)
         for buf, shift in ((m["r_lo"], shift_lo), (m["r_hi"], shift_hi)):
             if fs is not None:   # arrivals take the slots the leavers of their tile freed, when there are any
                 check(self.L.lpa_migrate_unpack_tiled(C.byref(pc), self._g(), C.byref(sp.tiling), C.byref(fs),
@@ -1009,9 +1042,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
     def sort_due_species(self):
         return [i for i, sp in enumerate(self.species) if self.sort_due(sp)]
 
-    def _species_entries(self, dt):
+    def _species_entries(self, dt, with_mig=False, pushed=False):
         for sp in self.species:
-            if sp.n == 0:
+            if sp.n == 0 and not with_mig:
                 continue
 
             def after(sp=sp):
@@ -1021,17 +1054,23 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
             pp = self._push_params(sp, dt)
             pc = sp.cset.cstruct(sp.n, eb=self.write_part_eb)
-            if sp.tiling is not None and sp.n_sorted > 0:
+            ent = {"pc": pc, "tiling": None, "n_sorted": 0, "pp": pp, "overflow": None, "count": None, "after": after}
+            if sp.tiling is not None and (sp.n_sorted > 0 or with_mig):
                 ws = self._sort_ws(sp)
-                yield pc, sp.tiling, sp.n_sorted, pp, ws["overflow"], ws["counters"][0:1], after
-            else:
-                yield pc, None, 0, pp, None, None, after
+                ent.update(tiling=sp.tiling, n_sorted=sp.n_sorted, overflow=ws["overflow"], count=ws["counters"][0:1])
+            if with_mig:
+                ent["mig"] = self._slab_species(sp, pushed)
+            yield ent
 
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------
-    def step(self, dt, tiled=True):
+    def step(self, dt, tiled=True, defer_e2=False):
+        """``defer_e2``: leave the E guards to the next step (``run_steps``: nothing reads the fields in between)"""
         self._dt_hint = dt
-        if tiled and self.can_fuse():
-            self.step_fused(dt)
+        if tiled and self.one_call_step():
+            self.step_fused(dt, defer_e2=defer_e2)
+            return
+        if tiled and self.can_fuse() and not self.overlap:
+            self._step_segments(dt, defer_e2)
             return
         E, B = ("ex", "ey", "ez"), ("bx", "by", "bz")
         self.update_efield(0.5 * dt)
@@ -1058,7 +1097,46 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self.update_bfield(0.5 * dt)
         self.sync_guard_fields(B)
         self.update_efield(0.5 * dt)
-        self.sync_guard_fields(E)
+        if not defer_e2:
+            self.sync_guard_fields(E)
+
+    def _step_segments(self, dt, defer_e2=False, laser=None):
+        """a slab rank whose faces travel through torch.distributed: the kernels between two exchanges are enqueued by one
+        ``lpa_step`` sub-range each, Python moves the faces in between (E1 | xchg | B1 | xchg | reset + push | J, rho and
+        leavers | B2 | xchg + the jx plane of rho | E2 | xchg) -- four or five message rounds per step"""
+        S, E, B = _lib, ("ex", "ey", "ez"), ("bx", "by", "bz")
+        st = self.stream
+        self.step_stages(dt, S.LPA_STAGE_E1, S.LPA_STAGE_E1)       # (E half step + the local guard wrap)
+        self._exchange_guards(1)
+        self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
+        self._exchange_guards(2)
+        self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)  # (sorts when due, decides the rho mode)
+        self.defer_rho = True
+        try:
+            self.sync_currents_and_particles()
+        finally:
+            self.defer_rho = False
+        self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
+        if laser is not None:
+            laser(self, dt)
+        self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
+        self._exchange_guards(2)                                    # (+ the jx plane; completes rho)
+        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)
+        if not defer_e2:
+            self._exchange_guards(1)
+
+    def _exchange_guards(self, which):
+        """the slab-to-slab half of sync_guard_fields (the local wrap has run): pack, exchange, unpack"""
+        h = self._halo_views(3 * self.ng * self.grid.NY)
+        left, right = self.comm.has_left, self.comm.has_right
+        self._faces(_lib.LPA_HALO_PACK_GUARD_SRC, which)(h["s_lo"] if left else None, h["s_hi"] if right else None)
+        rho_msg = self._rho_message()
+        if rho_msg is not None:
+            self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"]), rho_msg])
+        else:
+            self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
+        self._faces(_lib.LPA_HALO_UNPACK_GUARD, which)(h["r_lo"] if left else None, h["r_hi"] if right else None)
+        self._complete_rho()
 
     def _surplus_message(self, surplus):
         return (f"migration message overflow: {surplus} leaver-steps beyond migrate_capacity={self.migrate_capacity} "

@@ -524,6 +524,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
         if self.comm.size > 1:
             h = self._halo_views(3 * bin(which).count("1"))
+            if self._rho_message() is not None:      # a deferred rho update: its jx plane rides with these planes (rho.py)
+                self._exchange_guards(which, h)
+                return
             exchange_faces(
                 self.comm,
                 lambda side, b: check(self.L.lpa_halo_pack_guard_src(self._g(), which, side, b.data_ptr(), st),
@@ -547,26 +550,46 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         check(self.L.lpa_current_fold(self._g(), self.local_axes, st), "lpa_current_fold")
         self._finish_rho()
 
-    def sync_particles(self, i):
-        """leavers travel to the ring neighbours in one fixed-size message per face (count in band)"""
-        if self.comm.size == 1:
-            return
-        sp = self.species[i]
-        ws, cap, st = self._ws(sp), self.migrate_capacity, self.stream
+    def _owner_bounds_x(self):
+        return self.x0 - self.d[0] / 2, self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
+
+    def _slab_species(self, sp, pushed):
+        """see PicEngine2D._slab_species"""
+        ws, cap = self._ws(sp), self.migrate_capacity
         if ws["mig"] is None:
             mk = lambda: torch.zeros(1 + LPA_MIG_NATTR * cap, dtype=torch.float64, device=self.device)
             ws["mig"] = {"s_lo": mk(), "s_hi": mk(), "r_lo": mk(), "r_hi": mk()}
-        m = ws["mig"]
-        xlo = self.x0 - self.d[0] / 2
-        xhi = self.x0 + (self.n[0] - 1) * self.d[0] + self.d[0] / 2
         ahead = sp.get("sort_ahead_used", 0.0) * constants.C_LIGHT / self.d[0]      # (see PicEngine2D.leaver_columns)
-        cols = int(np.ceil((sp["since"] + 1 + ahead) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
+        age = sp["since"] + (0 if pushed else 1)
+        cols = int(np.ceil((age + 1 + ahead) / _lib.LPA_TILE3_X)) if sp["tiling"] is not None else 0
         if not (cols and 2 * cols <= self.n[0] // _lib.LPA_TILE3_X):
             cols = 0
         fs = ws.get("fs") if (self.reuse_slots and cols) else None
         if fs is not None and cols > fs.edge_cols:
             fs = None
-        surplus = ws["counters"][3:4].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
+        return {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
+                "area": self.arrival_area(), "cols": cols}
+
+    def _slab_fill(self, slab):
+        """the slab section of an lpa_step descriptor (step.py)"""
+        slab.xlo, slab.xhi = self._owner_bounds_x()
+        slab.shift_lo, slab.shift_hi = self.comm.arrival_shift(self.Lbox[0])
+        slab.migrate_capacity = self.migrate_capacity
+        h = self._halo_views(4)
+        slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
+        slab.rho_exchange = int(self.rho_continuity and self._rho_available())
+        if slab.rho_exchange:
+            self._jx_plane_bufs()
+            slab.jx_left_plane = self._jx_plane.data_ptr()
+        return h
+
+    def _mig_pack(self, i):
+        """leavers of species ``i`` into its two face messages (count in band); returns the bookkeeping dict"""
+        sp = self.species[i]
+        mig = self._slab_species(sp, pushed=True)
+        m, cap, st, cols, fs = mig["bufs"], self.migrate_capacity, self.stream, mig["cols"], mig["fs"]
+        xlo, xhi = self._owner_bounds_x()
+        surplus = mig["surplus"].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
         if cols:   # only the edge tile columns + loose particles
             check(self.L.lpa_migrate_pack_edges_x(C.byref(sp["c"]), C.byref(sp["tiling"]), cols, xlo, xhi,
                                                   m["s_lo"].data_ptr(), m["s_hi"].data_ptr(), cap,
@@ -575,15 +598,17 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         else:
             check(self.L.lpa_migrate_pack_x(C.byref(sp["c"]), xlo, xhi, m["s_lo"].data_ptr(), m["s_hi"].data_ptr(),
                                             cap, surplus, st), "lpa_migrate_pack_x")
-        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
-        cur = ws["counters"][1:2].data_ptr()
-        area = self.arrival_area()
+        return mig
+
+    def _mig_unpack(self, i, mig):
+        sp = self.species[i]
+        m, cap, st, fs = mig["bufs"], self.migrate_capacity, self.stream, mig["fs"]
+        cur, area = mig["cursor"].data_ptr(), mig["area"]
         if not self.comm.has_left:
             m["r_lo"][:1].zero_()    # open face: nothing arrives
         if not self.comm.has_right:
             m["r_hi"][:1].zero_()
-        shift_lo = -self.Lbox[0] if (self.comm.rank == 0 and self.periodic[0]) else 0.0
-        shift_hi = self.Lbox[0] if (self.comm.rank == self.comm.size - 1 and self.periodic[0]) else 0.0
+        shift_lo, shift_hi = self.comm.arrival_shift(self.Lbox[0])
         for buf, shift in ((m["r_lo"], shift_lo), (m["r_hi"], shift_hi)):
             if fs is not None:
                 check(self.L.lpa_migrate_unpack_tiled(C.byref(sp["c"]), self._g(), C.byref(sp["tiling"]), C.byref(fs),
@@ -592,6 +617,45 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             else:
                 check(self.L.lpa_migrate_unpack(C.byref(sp["c"]), sp["n_sorted"], area, cur, buf.data_ptr(), cap,
                                                 shift, st), "lpa_migrate_unpack")
+
+    def sync_particles(self, i):
+        """leavers travel to the ring neighbours in one fixed-size message per face (count in band)"""
+        if self.comm.size == 1:
+            return
+        mig = self._mig_pack(i)
+        m = mig["bufs"]
+        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        self._mig_unpack(i, mig)
+
+    def sync_currents_and_particles(self):
+        """the J / rho guard fold and the migration of every species in ONE message round (see PicEngine2D)"""
+        if self.comm.size == 1:
+            self.sync_currents()
+            return
+        h = self._halo_views(4)
+        left, right = self.comm.has_left, self.comm.has_right
+        self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"] if left else None, h["s_hi"] if right else None)
+        packed = [self._mig_pack(i) for i in range(len(self.species))]
+        self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])] +
+                                [tuple(mg["bufs"][k] for k in ("s_lo", "s_hi", "r_lo", "r_hi")) for mg in packed])
+        self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if left else None, h["r_hi"] if right else None)
+        check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
+        self._finish_rho()
+        for i, mg in enumerate(packed):
+            self._mig_unpack(i, mg)
+
+    def _exchange_guards(self, which, h=None):
+        """the slab-to-slab half of sync_guard_fields (the local wrap has run): pack, exchange, unpack"""
+        h = h or self._halo_views(3 * bin(which).count("1"))
+        left, right = self.comm.has_left, self.comm.has_right
+        self._faces(_lib.LPA_HALO_PACK_GUARD_SRC, which)(h["s_lo"] if left else None, h["s_hi"] if right else None)
+        rho_msg = self._rho_message()
+        if rho_msg is not None:
+            self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"]), rho_msg])
+        else:
+            self.comm.exchange(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])
+        self._faces(_lib.LPA_HALO_UNPACK_GUARD, which)(h["r_lo"] if left else None, h["r_hi"] if right else None)
+        self._complete_rho()
 
     # ---- Maxwell with CPML layers (update_e/bfield_cpml_patches_3d, cpml.py:477-530) --------------------
     def update_efield(self, dt):
@@ -911,24 +975,30 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             pp.alo[a], pp.ahi[a] = self.alo[a], self.ahi[a]
         return pp
 
-    def _species_entries(self, dt):
+    def _species_entries(self, dt, with_mig=False, pushed=False):
         for sp in self.species:
             def after(sp=sp):
                 sp["since"] += 1
 
             pp = self._push_params(sp, dt)
+            ent = {"pc": sp["c"], "tiling": None, "n_sorted": 0, "pp": pp, "overflow": None, "count": None, "after": after}
             if self.tiled and sp["tiling"] is not None:
                 ws = sp["ws"]
-                yield sp["c"], sp["tiling"], sp["n_sorted"], pp, ws["overflow"], ws["count"], after
-            else:
-                yield sp["c"], None, 0, pp, None, None, after
+                ent.update(tiling=sp["tiling"], n_sorted=sp["n_sorted"], overflow=ws["overflow"], count=ws["count"])
+            if with_mig:
+                ent["mig"] = self._slab_species(sp, pushed)
+            yield ent
 
-    def step(self, dt, laser=None):
+    def step(self, dt, laser=None, defer_e2=False):
         """``laser``: optional callable ``laser(engine, dt)`` run at the reference's '_laser' stage
-        (between the second B half step and its guard sync, simulation.py:1098-1112)"""
+        (between the second B half step and its guard sync, simulation.py:1098-1112); ``defer_e2``: see
+        PicEngine2D.step"""
         self._dt_hint = dt
-        if self.can_fuse():
-            self.step_fused(dt, laser)
+        if self.one_call_step():
+            self.step_fused(dt, laser, defer_e2)
+            return
+        if self.can_fuse() and self.tiled and not self.overlap:
+            self._step_segments(dt, laser, defer_e2)
             return
         L, st, g = self.L, self.stream, self._g()
         self.update_efield(0.5 * dt)
@@ -947,7 +1017,30 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             laser(self, dt)
         self.sync_guard_fields(2)
         self.update_efield(0.5 * dt)
-        self.sync_guard_fields(1)
+        if not defer_e2:
+            self.sync_guard_fields(1)
+
+    def _step_segments(self, dt, laser=None, defer_e2=False):
+        """see PicEngine2D._step_segments: sub-ranges of lpa_step between the exchanges torch.distributed carries"""
+        S = _lib
+        self.step_stages(dt, S.LPA_STAGE_E1, S.LPA_STAGE_E1)
+        self._exchange_guards(1)
+        self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
+        self._exchange_guards(2)
+        self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)
+        self.defer_rho = True
+        try:
+            self.sync_currents_and_particles()
+        finally:
+            self.defer_rho = False
+        self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
+        if laser is not None:
+            laser(self, dt)
+        self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
+        self._exchange_guards(2)
+        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)
+        if not defer_e2:
+            self._exchange_guards(1)
 
     _surplus_message = PicEngine2D._surplus_message
 

@@ -49,7 +49,7 @@ class RhoContinuityMixin:
         self._jx_plane = None
 
     def _rho_restore(self):             # after unpickling: scratch is rebuilt, the next step re-anchors
-        self._absorbed, self._jx_plane = None, None
+        self._absorbed, self._jx_plane, self._rho_pending = None, None, None
         self._anchor_pending, self._phase, self._prev_phase = True, "idle", "idle"
 
     # ---- hooks the engines provide ------------------------------------------------------------------------------
@@ -210,24 +210,63 @@ class RhoContinuityMixin:
             lst, cnt, cap = self._absorbed_bufs()
             pp.absorbed, pp.absorbed_count, pp.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
 
-    def _finish_rho(self):
-        """after the currents were folded: rho^{n+1} = rho^n - dt div J on a continuity step"""
+    def _end_of_fold(self):
+        """bookkeeping at the end of a step's current fold (nothing is launched): the rho bracket closes and the chain
+        clock ticks -- every sort / phase decision of the step has seen the same clock"""
         phase, self._phase = self._phase, "idle"
-        self._tick_chain_clock()      # (the end of the step: every sort / phase decision of the step has seen the same clock)
-        left = None
-        if self.comm.size > 1 and self.rho_continuity and self._rho_available():
-            # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step.  Sent in
-            # EVERY step, whatever the phase (and whether this rank pushed anything): an exchange that depended on the
-            # phase would hang the chain the day two ranks disagreed about it
-            send = self._rho_last_jx_plane().reshape(-1)
-            if self._jx_plane is None:
-                self._jx_plane = torch.zeros_like(send)
-                self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
-            self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
-            left = self._jx_plane if self.comm.has_left else None
+        self._tick_chain_clock()
+        return phase
+
+    def _jx_plane_bufs(self):
+        """(receive buffer for the left neighbour's folded jx plane, two 1-element dummies for the unused direction)"""
+        send = self._rho_last_jx_plane().reshape(-1)
+        if self._jx_plane is None or self._jx_plane.numel() != send.numel():
+            self._jx_plane = torch.zeros_like(send)
+            self._one = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(2)]
+        return send
+
+    defer_rho = False     # set by the step drivers: the jx plane rides with the B guard planes that follow the fold
+
+    def _finish_rho(self):
+        """after the currents were folded: rho^{n+1} = rho^n - dt div J on a continuity step.  Between slabs the update
+        needs the left neighbour's folded jx plane: one message per step -- sent at once, or (``defer_rho``, the step
+        drivers with no callback between the fold and the B guard exchange that follows it) together with the B guard
+        planes of ``sync_guard_fields``, which then completes the update (``_complete_rho``): one message round less."""
+        phase = self._end_of_fold()
         # dt of the step: from this rank's pushes, or -- a rank that holds no particle (yet) still receives its
         # neighbours' guard-plane currents through the fold and has to advance rho with them -- from the step driver
         dt_step = self._dt_step if self._dt_step > 0.0 else (getattr(self, "_dt_hint", 0.0) if self.comm.size > 1 else 0.0)
+        exchange = self.comm.size > 1 and self.rho_continuity and self._rho_available()
+        if exchange and self.defer_rho:
+            self._rho_pending = (phase, dt_step)
+            return
+        left = None
+        if exchange:
+            # D-x jx at my node 0 needs the left neighbour's folded jx at its node nx - 1: one plane per step.  Sent in
+            # EVERY step, whatever the phase (and whether this rank pushed anything): an exchange that depended on the
+            # phase would hang the chain the day two ranks disagreed about it
+            send = self._jx_plane_bufs()
+            self.comm.exchange(self._one[0], send, self._jx_plane, self._one[1])
+            left = self._jx_plane if self.comm.has_left else None
+        self._apply_continuity(phase, dt_step, left)
+
+    _rho_pending = None
+
+    def _rho_message(self):
+        """the jx-plane message of a deferred rho update as an ``exchange_many`` set, or None"""
+        if self._rho_pending is None:
+            return None
+        send = self._jx_plane_bufs()
+        return (self._one[0], send, self._jx_plane, self._one[1])
+
+    def _complete_rho(self):
+        """after the exchange that carried ``_rho_message``"""
+        if self._rho_pending is None:
+            return
+        (phase, dt_step), self._rho_pending = self._rho_pending, None
+        self._apply_continuity(phase, dt_step, self._jx_plane if self.comm.has_left else None)
+
+    def _apply_continuity(self, phase, dt_step, left):
         if phase != "continuity" or not dt_step > 0.0:        # (single slab, no push ran: J = 0, rho stays)
             return
         split = ((1 if self.comm.has_left else 0) | (2 if self.comm.has_right else 0)) if self.comm.size > 1 else 0

@@ -638,7 +638,8 @@ class Simulation:
         enabled, the whole stage sequence of this step is enqueued by ONE engine call (``lpa_step``, step.py) -- two when a
         '_laser' callback injects in between.  False: the caller walks the stages one facade call at a time."""
         eng = self.engine
-        if not (unified and eng.can_fuse()):
+        segments = eng.can_fuse() and eng.comm.size > 1 and not eng.one_call_step() and not eng.overlap
+        if not (unified and (eng.one_call_step() or segments)):
             return False
         facades = [self.maxwell, *self.pusher, *self.sorter] + \
             ([self.current_depositor] if hasattr(self, "current_depositor") else [])
@@ -648,6 +649,10 @@ class Simulation:
             return False
         from . import _lib
         lasers = bool(self._triggered(table.get("_laser", [])))
+        if segments:      # slab ranks whose faces travel through torch.distributed: sub-ranges between the exchanges
+            eng._step_segments(self.dt, laser=(lambda e, dt: self._run_stage(table, "_laser")) if lasers else None)
+            self.current_synced, self.ispec = True, None
+            return True
         eng.step_stages(self.dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_B2 if lasers else _lib.LPA_STAGE_E2)
         self.current_synced, self.ispec = True, None
         if lasers:

@@ -1,14 +1,22 @@
-"""One host call per step: ``lpa_step`` (csrc/lpa_step.hip) enqueues the no-callback stage sequence of a single-slab
-step -- what the per-stage methods of the engines issue one ctypes call at a time (the reference walks the same stages
-from Python, `simulation/simulation.py:937-1122`).  On launch-bound configs (C3: a 4 M-particle laser-target on 2 M
-cells, ~20 launches of 5-40 us per step) the Python stage loop issues a step no faster than the GPU executes it; through
-``lpa_step`` the host cost per launch is the HIP launch itself.
+"""One host call per step: ``lpa_step`` (csrc/lpa_step.hip) enqueues the no-callback stage sequence of a step -- what the
+per-stage methods of the engines issue one ctypes call at a time (the reference walks the same stages from Python,
+`simulation/simulation.py:937-1122`).  On launch-bound configs (C3: a 4 M-particle laser-target on 2 M cells, ~20 launches
+of 5-40 us per step) the Python stage loop issues a step no faster than the GPU executes it; through ``lpa_step`` the host
+cost per launch is the HIP launch itself.
+
+Slab ranks (``comm.size > 1``):
+
+* with the library's own transport (``SlabComm.attach_rccl``, ``LoopbackComm``) the descriptor carries a slab section and
+  the SAME single call also moves the x faces (ncclSend / ncclRecv groups issued from C on the step's stream): four message
+  rounds per step -- B1 | J + rho + every species' leavers | B2 + the jx plane of the continuity update | E (E2 of this step
+  and E1 of the next when the caller runs steps back to back, ``defer_e2``);
+* without it (gloo rehearsals, ranks sharing a GPU in the tests, torch's own nccl group) the engines call ``step_stages``
+  for the ranges between two exchanges and move the faces from Python (engines: ``_step_segments``).
 
 The descriptor is rebuilt for every call from the engine's CURRENT stores (a few microseconds per species): nothing that
 holds a device address is cached across steps, so a sort, a re-allocation, a window shift or an upload between two steps
-cannot leave a stale pointer behind.  What stays in Python: the sort (it needs the live count on the host), everything
-a callback does, and slab-to-slab exchanges (``torch.distributed``) -- engines with more than one rank keep the
-per-stage path.
+cannot leave a stale pointer behind.  What stays in Python: the sort (it needs the live count on the host) and everything
+a callback does.
 """
 from __future__ import annotations
 
@@ -21,26 +29,40 @@ from ._lib import check
 
 
 class FusedStepMixin:
-    """needs from the engine: ``dim``, ``_grid_struct()``, ``_species_entries()`` (yielding, per species,
-    (lpa_particles, tiling | None, n_sorted, push-params filler, overflow tensor, counter tensor, after-push hook)),
+    """needs from the engine: ``dim``, ``_grid_struct()``, ``_species_entries()`` (yielding, per species, a dict with
+    ``pc`` (lpa_particles), ``tiling`` (or None), ``n_sorted``, ``pp`` (push params), ``overflow`` / ``count`` tensors,
+    ``after`` (hook run after the push) and -- slab ranks -- ``mig`` (see ``_slab_species``)), ``_slab_fill(slab)``,
     ``_cpml_axes``, ``pml``, ``fused_cpml``, ``local_axes``, ``eps0``, ``absorb`` and the rho mixin"""
 
-    fused_step = True          # single-slab steps go through lpa_step (False: the per-stage calls)
+    fused_step = True          # steps go through lpa_step (False: the per-stage calls)
     fuse_species = True        # 3-D: every tile-ordered species in ONE launch (lpa_push_deposit_tiled_multi_3d)
 
     def can_fuse(self):
-        return self.fused_step and self.comm.size == 1 and (self.pml is None or self.fused_cpml)
+        return self.fused_step and (self.pml is None or self.fused_cpml)
 
-    def step_stages(self, dt, first, last):
+    def native_slab(self):
+        """is this a slab rank whose faces travel through the library's own transport?"""
+        return self.comm.size > 1 and self.comm.native is not None
+
+    def one_call_step(self):
+        """can ``lpa_step`` enqueue the whole step (exchanges included)?"""
+        return self.can_fuse() and (self.comm.size == 1 or self.comm.native is not None)
+
+    def step_stages(self, dt, first, last, defer_e2=False):
         """enqueue stages ``first .. last`` (LPA_STAGE_*) of one step in one call.  The stores must be sorted when
         they are due BEFORE LPA_STAGE_RESET is reached (``sort_due_species``); the rho mode of the step is decided
-        when LPA_STAGE_RESET is part of the range and closed when LPA_STAGE_FOLD is."""
+        when LPA_STAGE_RESET is part of the range and closed when LPA_STAGE_FOLD is.  ``defer_e2``: LPA_STAGE_E2 leaves
+        the E guards to the next step's LPA_STAGE_E1 (LPA_STEP_DEFER_E2_GUARDS: the caller runs another step next)."""
         if not self.can_fuse():
-            raise _lib.LpaError("lpa_step drives a single slab (and the fused CPML sweeps)")
+            raise _lib.LpaError("lpa_step drives the fused CPML sweeps")
+        native = self.native_slab()
+        if self.comm.size > 1 and not native and first <= _lib.LPA_STAGE_FOLD <= last:
+            raise _lib.LpaError("slab ranks without a native transport fold their currents from Python (sync_currents)")
         self._dt_hint = dt        # (the first sort of a store sizes its sort interval from the particles' speed)
         d = _lib.lpa_step_desc()
         d.grid = self._grid_struct()
         d.dim, d.local_axes, d.dt, d.eps0 = self.dim, self.local_axes, dt, self.eps0
+        d.flags = _lib.LPA_STEP_DEFER_E2_GUARDS if defer_e2 else 0
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):
@@ -56,17 +78,21 @@ class FusedStepMixin:
         if self.absorb and self.rho_continuity and self._rho_available():
             lst, cnt, cap = self._absorbed_bufs()
             d.absorbed, d.absorbed_count, d.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
-        timed = self.kernel_events is not None and first <= _lib.LPA_STAGE_PUSH <= last
+        push = first <= _lib.LPA_STAGE_PUSH <= last
+        fold = first <= _lib.LPA_STAGE_FOLD <= last
+        timed = self.kernel_events is not None and push
         self.kernel_events_step = False    # (fused species: one launch, one event pair -- on the first tiled species)
-        entries = list(self._species_entries(dt)) if first <= _lib.LPA_STAGE_PUSH <= last else []
+        # the species table is needed by the push and, on slab ranks, by the fold (leavers / arrivals)
+        entries = list(self._species_entries(dt, native and fold, pushed=not push)) if (push or (native and fold)) else []
         arr = (_lib.lpa_step_species * max(len(entries), 1))()
         stream = torch.cuda.current_stream(self.device)
-        for k, (pc, tiling, n_sorted, pp, ovf, cnt_t, _) in enumerate(entries):
+        for k, ent in enumerate(entries):
             e = arr[k]
-            e.p, e.n_sorted, e.pp = pc, n_sorted, pp
+            tiling, n_sorted = ent["tiling"], ent["n_sorted"]
+            e.p, e.n_sorted, e.pp = ent["pc"], n_sorted, ent["pp"]
             e.t = C.pointer(tiling) if tiling is not None else None
-            if ovf is not None:
-                e.overflow, e.overflow_count = ovf.data_ptr(), cnt_t.data_ptr()
+            if ent["overflow"] is not None:
+                e.overflow, e.overflow_count = ent["overflow"].data_ptr(), ent["count"].data_ptr()
             if timed and tiling is not None and n_sorted > 0 and not (d.fuse_species and self.kernel_events_step):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)          # (creates the HIP events; lpa_step records them again around the launch)
@@ -74,22 +100,43 @@ class FusedStepMixin:
                 e.ev_start, e.ev_stop = e0.cuda_event, e1.cuda_event
                 self.kernel_events.append((e0, e1))
                 self.kernel_events_step = True
-            keep.append((pc, tiling, pp, ovf, cnt_t))
+            mig = ent.get("mig")
+            if mig is not None:
+                m = mig["bufs"]
+                e.mig.s_lo, e.mig.s_hi, e.mig.r_lo, e.mig.r_hi = (m[k_].data_ptr() for k_ in ("s_lo", "s_hi", "r_lo", "r_hi"))
+                e.mig.cursor, e.mig.surplus = mig["cursor"].data_ptr(), mig["surplus"].data_ptr()
+                e.mig.fs = C.pointer(mig["fs"]) if mig["fs"] is not None else None
+                e.mig.area_capacity, e.mig.edge_cols = mig["area"], mig["cols"]
+            keep.append(ent)
         d.nspecies, d.species = len(entries), arr
+        if native:
+            slab = _lib.lpa_step_slab()
+            slab.comm = self.comm.native
+            keep.append(self._slab_fill(slab))
+            d.slab = C.pointer(slab)
+            keep.append(slab)
         check(self.L.lpa_step(C.byref(d), first, last, stream.cuda_stream), "lpa_step")
         self._step_keep = (d, arr, keep)      # alive until the next call (the launches copy what they need)
-        if entries:
+        if push:
             self._dt_step = dt
             for ent in entries:
-                ent[6]()
-        if first <= _lib.LPA_STAGE_FOLD <= last:
-            self._phase = "idle"
+                ent["after"]()
+        if fold:
+            self._end_of_fold()
 
-    def step_fused(self, dt, laser=None):
+    def step_fused(self, dt, laser=None, defer_e2=False):
         """one whole step; ``laser``: optional callable(engine, dt) run at the '_laser' stage"""
         if laser is None:
-            self.step_stages(dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_E2)
+            self.step_stages(dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_E2, defer_e2)
             return
         self.step_stages(dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_B2)
         laser(self, dt)
-        self.step_stages(dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2)
+        self.step_stages(dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2, defer_e2)
+
+    def run_steps(self, nsteps, dt, laser=None):
+        """``nsteps`` steps back to back with nothing reading the fields in between: the E guards are brought up to date
+        once per step instead of twice (after E1 of the following step; the last step leaves them current) -- one launch
+        and, between slabs, one message round less per step; the state after the call is that of ``nsteps`` ``step()``s."""
+        for k in range(int(nsteps)):
+            self.step(dt, laser=laser, defer_e2=k < nsteps - 1) if laser is not None else \
+                self.step(dt, defer_e2=k < nsteps - 1)

@@ -52,7 +52,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
     structs = {"lpa_grid": _lib.lpa_grid, "lpa_particles": _lib.lpa_particles, "lpa_tiling": _lib.lpa_tiling,
                "lpa_push_params": _lib.lpa_push_params, "lpa_cpml_axis": _lib.lpa_cpml_axis,
                "lpa_free_slots": _lib.lpa_free_slots, "lpa_step_species": _lib.lpa_step_species,
-               "lpa_step_desc": _lib.lpa_step_desc}
+               "lpa_step_desc": _lib.lpa_step_desc, "lpa_face_msg": _lib.lpa_face_msg,
+               "lpa_step_migrate": _lib.lpa_step_migrate, "lpa_step_slab": _lib.lpa_step_slab}
     lines = []
     for name, cls in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

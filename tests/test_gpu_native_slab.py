@@ -1,0 +1,231 @@
+"""The slab path with the library's OWN transport (csrc/lpa_comm.hip) -- whole steps, exchanges included, enqueued by one
+``lpa_step`` call -- on one GPU: a slab that is rank 0 of a periodic 2-slab ring whose other slab is its translated copy
+(``LoopbackComm``) must reproduce one half of a single-slab run of the doubled periodic box.  Every kernel of the N > 1
+path runs (E / B planes straight from the arrays, J / rho fold, leaver pack, arrival unpack with free slots, arrival area,
+the jx plane of the continuity update riding with the B planes); the wire is a copy kernel (``loopback``), a one-rank RCCL
+communicator sending to itself (``rccl``: real ncclSend / ncclRecv groups) or Python-side copies between ``lpa_step``
+sub-ranges (``python``: the path torch.distributed transports take).  Tolerance 1e-10: summation order only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CL = 299792458.0
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _comm(transport, width, cap):
+    from lambdapic_amd.dist import LoopbackComm
+    if transport == "python":
+        from bench_mirror_comm import MirrorComm
+        return MirrorComm(width, cap)
+    return LoopbackComm(width, 2, rccl=transport == "rccl")
+
+
+# ---- the transport itself ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rccl", [False, True])
+def test_exchange_pairs_high_face_with_low_face(rccl):
+    from lambdapic_amd.dist import LoopbackComm
+    comm = LoopbackComm(1.0, 2, rccl=rccl)
+    kind, rank, size, left, right, version = comm.native_info()
+    assert (rank, left >= 0, right >= 0) == (0, True, True)
+    assert (version > 20000) == rccl
+    dev = torch.device("cuda:0")
+    mk = lambda n, v: torch.full((n,), float(v), dtype=torch.float64, device=dev)
+    # three messages in one round, different sizes per direction (the window shift sends a big block one way only)
+    sets = [(mk(7, 1), mk(5, 2), mk(5, -1), mk(7, -1)), (mk(1000, 3), mk(1000, 4), mk(1000, -1), mk(1000, -1)),
+            (mk(1, 5), mk(33, 6), mk(33, -1), mk(1, -1))]
+    comm.exchange_many(sets)
+    torch.cuda.synchronize()
+    for s_lo, s_hi, r_lo, r_hi in sets:
+        assert torch.equal(r_lo, s_hi) and torch.equal(r_hi, s_lo)
+    a, b, c, d = mk(9, 7), mk(9, 8), mk(9, 0), mk(9, 0)
+    comm.exchange(a, b, c, d)
+    torch.cuda.synchronize()
+    assert torch.equal(c, b) and torch.equal(d, a)
+    with pytest.raises(ValueError):
+        comm.exchange(a.float(), b, c, d)
+    comm.close()
+
+
+def test_loopback_refuses_counts_that_do_not_pair():
+    from lambdapic_amd import _lib
+    from lambdapic_amd.dist import LoopbackComm
+    comm = LoopbackComm(1.0, 2)
+    t = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for n in (4, 5, 6, 4)]
+    with pytest.raises(_lib.LpaError, match="counts differ"):
+        comm.exchange(*t)
+
+
+# ---- 2-D: a mirrored slab == one half of the doubled box -----------------------------------------------------------------
+NX, NY, PPC, NSTEPS = 64, 64, 6, 24
+
+
+def _problem2d():
+    lam = 0.8e-6
+    dx = dy = lam / 20
+    dt = 0.95 / (CL * np.sqrt(dx ** -2 + dy ** -2))
+    rng = np.random.default_rng(5)
+    n = NX * NY * PPC
+    cell = np.arange(n) // PPC
+    x = ((cell // NY) + rng.uniform(-0.5, 0.5, n)) * dx
+    y = ((cell % NY) + rng.uniform(-0.5, 0.5, n)) * dy
+    u = rng.normal(size=(3, n)) * 0.3          # hot: plenty of slab crossings within a few steps
+    w = np.full(n, 1.7e27 * dx * dy / PPC)
+    return dx, dy, dt, x, y, u, w
+
+
+def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True):
+    from lambdapic_amd.engine import PicEngine2D
+    dx, dy, dt, x, y, u, w = _problem2d()
+    eng = PicEngine2D(nx_cells, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
+                      migrate_capacity=4096)
+    eng.rho_continuity = rho
+    n = x.size * copies
+    eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=2 * n + 20000)
+    s = eng.species[0].cset
+    cat = lambda a: np.concatenate([a] * copies)
+    xs = np.concatenate([x + k * NX * dx for k in range(copies)])
+    ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
+    for name, arr in (("x", xs), ("y", cat(y)), ("ux", cat(u[0])), ("uy", cat(u[1])), ("uz", cat(u[2])),
+                      ("inv_gamma", cat(ig)), ("w", cat(w))):
+        s.arr(name)[:n] = torch.from_numpy(arr).cuda()
+    s.id[:n] = torch.arange(n, device="cuda:0")
+    eng.species[0].n = n
+    trace = []
+    if run_steps:
+        for _ in range(NSTEPS // 4):
+            eng.run_steps(4, dt)
+            d = eng.diagnostics()
+            trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+    else:
+        for _ in range(NSTEPS):
+            eng.step(dt)
+            d = eng.diagnostics()
+            trace.append([d["field_energy"], d["charge"], d["kinetic"][0], d["nalive"][0]])
+    g = eng.grid
+    fields = {a: g.view(a)[:, 3:3 + NY].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho", "jx")}
+    return np.array(trace), fields, eng
+
+
+@pytest.fixture(scope="module")
+def doubled2d():
+    tr, f, _ = _engine2d(2 * NX, None, 2)
+    return tr, f
+
+
+def _close(a, b, tol=1e-10):
+    scale = max(np.max(np.abs(b)), 1e-300)
+    return np.max(np.abs(a - b)) / scale < tol
+
+
+@pytest.mark.parametrize("transport", ["loopback", "rccl", "python"])
+def test_mirrored_slab_is_half_of_the_doubled_box_2d(doubled2d, transport):
+    tr2, f2 = doubled2d
+    comm = _comm(transport, NX * _problem2d()[0], 4096)
+    tr, f, eng = _engine2d(NX, comm, 1)
+    assert eng.one_call_step() == (transport != "python")
+    assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])                       # nobody lost, nobody doubled
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
+    for a in f:
+        # interior of the slab + its x guard planes (E / B: the neighbour's edge) == the doubled box's left half
+        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
+    assert eng.rho_steps["continuity"] > eng.rho_steps["anchor"] > 0
+
+
+def test_run_steps_equals_steps_on_a_mirrored_slab(doubled2d):
+    """deferred E2 guards (one message round and one launch less per step): the state after run_steps(n) is the state after
+    n step()s"""
+    comm = _comm("loopback", NX * _problem2d()[0], 4096)
+    tr, f, eng = _engine2d(NX, comm, 1)
+    comm2 = _comm("loopback", NX * _problem2d()[0], 4096)
+    tr_r, f_r, _ = _engine2d(NX, comm2, 1, run_steps=True)
+    # (two runs of the same problem differ in the order of their FP64 atomics: tolerance, not bit equality)
+    assert np.array_equal(tr[3::4, 3], tr_r[:, 3]) and _close(tr[3::4, :3], tr_r[:, :3])
+    for a in f:
+        assert _close(f[a], f_r[a]), a
+
+
+def test_run_steps_equals_steps_single_slab():
+    tr, f, _ = _engine2d(NX, None, 1)
+    tr_r, f_r, _ = _engine2d(NX, None, 1, run_steps=True)
+    assert np.array_equal(tr[3::4, 3], tr_r[:, 3]) and _close(tr[3::4, :3], tr_r[:, :3])
+    for a in f:
+        assert _close(f[a], f_r[a]), a
+
+
+def test_mirrored_slab_with_deposited_rho(doubled2d):
+    """rho deposited in every step (the reference's kernel): no jx plane travels"""
+    tr2, f2 = doubled2d
+    comm = _comm("loopback", NX * _problem2d()[0], 4096)
+    tr, f, eng = _engine2d(NX, comm, 1, rho=False)
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k]), k
+    assert _close(f["rho"][3:3 + NX], f2["rho"][3:3 + NX])
+
+
+# ---- 3-D twin ---------------------------------------------------------------------------------------------------------------
+N3 = (16, 16, 32)
+
+
+def _engine3d(nx_cells, comm, copies, nsteps=12):
+    from lambdapic_amd import constants
+    from lambdapic_amd.engine3d import PicEngine3D
+    lam = 0.8e-6
+    d = (lam / 20, lam / 10, lam / 10)
+    dt = 0.95 / (CL * np.sqrt(sum(v ** -2 for v in d)))
+    ppc = 4
+    rng = np.random.default_rng(11)
+    n = N3[0] * N3[1] * N3[2] * ppc
+    cell = np.arange(n) // ppc
+    pos = [((cell // (N3[1] * N3[2])) + rng.uniform(-0.5, 0.5, n)) * d[0],
+           (((cell // N3[2]) % N3[1]) + rng.uniform(-0.5, 0.5, n)) * d[1],
+           ((cell % N3[2]) + rng.uniform(-0.5, 0.5, n)) * d[2]]
+    u = rng.normal(size=(3, n)) * 0.3
+    eng = PicEngine3D(nx_cells, N3[1], N3[2], *d, 3, sort_interval=5, comm=comm, migrate_capacity=8192)
+    eng.overlap = False
+    ntot = n * copies
+    data = torch.full((8, 2 * ntot + eng.arrival_area() + 1024), float("nan"), dtype=torch.float64, device="cuda:0")
+    cat = lambda a: torch.from_numpy(np.concatenate([a] * copies)).cuda()
+    data[0, :ntot] = torch.from_numpy(np.concatenate([pos[0] + k * N3[0] * d[0] for k in range(copies)])).cuda()
+    data[1, :ntot], data[2, :ntot] = cat(pos[1]), cat(pos[2])
+    for k in range(3):
+        data[3 + k, :ntot] = cat(u[k])
+    data[6, :ntot] = cat(1 / np.sqrt(1 + (u ** 2).sum(0)))
+    data[7, :ntot] = 1.7e27 * d[0] * d[1] * d[2] / ppc
+    eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, ntot)
+    trace = []
+    for _ in range(nsteps):
+        eng.step(dt)
+        dg = eng.diagnostics()
+        trace.append([dg["field_energy"], dg["charge"], dg["kinetic"][0], dg["nalive"][0]])
+    fields = {a: eng.view(a)[:, 3:-3, 3:-3].cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}
+    return np.array(trace), fields, eng, d
+
+
+@pytest.fixture(scope="module")
+def doubled3d():
+    tr, f, _, _ = _engine3d(2 * N3[0], None, 2)
+    return tr, f
+
+
+@pytest.mark.parametrize("transport", ["loopback", "rccl", "python"])
+def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport):
+    tr2, f2 = doubled3d
+    lam = 0.8e-6
+    comm = _comm(transport, N3[0] * lam / 20, 8192)
+    tr, f, eng, _ = _engine3d(N3[0], comm, 1)
+    assert eng.one_call_step() == (transport != "python")
+    assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
+    for a in f:
+        lo, hi = (3, 3 + N3[0]) if a == "rho" else (0, N3[0] + 6)
+        assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)

@@ -21,11 +21,17 @@ ap.add_argument("--ppc", type=int, default=64); ap.add_argument("--steps", type=
 ap.add_argument("--warmup", type=int, default=8); ap.add_argument("--sort-interval", type=int, default=20)
 ap.add_argument("--block-particles", type=int, default=8192)
 ap.add_argument("--overlap", action="store_true", help="edge tiles + J exchange on a second stream beside the interior")
+ap.add_argument("--transport", default="loopback", choices=["loopback", "rccl", "python"],
+                help="loopback: the library's own transport with the wire replaced by one copy kernel per round (whole step = "
+                     "one lpa_step call); rccl: the same through a one-rank RCCL communicator sending to itself (real "
+                     "ncclSend / ncclRecv groups); python: the faces moved from Python between lpa_step sub-ranges")
+ap.add_argument("--run-steps", action="store_true", help="engine.run_steps: E guards once per step (deferred E2 guards)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dx = bench.LAMBDA0 / 20
-comm = MirrorComm(a.nx * dx, 32768)
+from lambdapic_amd.dist import LoopbackComm
+comm = MirrorComm(a.nx * dx, 32768) if a.transport == "python" else LoopbackComm(a.nx * dx, 2, rccl=a.transport == "rccl")
 eng, dt, n = bench.build_engine(a, comm, dev)
 assert eng.migrate_capacity == 32768
 eng.overlap = a.overlap
@@ -33,13 +39,17 @@ for _ in range(a.warmup):
     eng.step(dt)
 eng.kernel_events = []
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(a.steps):
-    eng.step(dt)
+if a.run_steps:
+    eng.run_steps(a.steps, dt)
+else:
+    for _ in range(a.steps):
+        eng.step(dt)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 k_ms = float(np.sum([x.elapsed_time(y) for x, y in eng.kernel_events])) / a.steps
 d = eng.diagnostics()
 w = float(eng.species[0].cset.arr("w")[0].item())
-print(json.dumps({"what": "rank 0 of a mirrored 2-slab ring, no wire", "ms_per_step": 1e3 * el / a.steps,
+print(json.dumps({"what": f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", overlapped" if a.overlap else "") +
+                          (", run_steps" if a.run_steps else ""), "ms_per_step": 1e3 * el / a.steps,
                   "particle_updates_per_s_per_gpu": n * a.steps / el, "k1_edge_plus_interior_ms": k_ms,
                   "alive": d["nalive"][0], "particles": n,
                   "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * w * -1.602176634e-19) - 1)}))

@@ -14,12 +14,16 @@ from lambdapic_amd.engine3d import PicEngine3D
 ap = argparse.ArgumentParser()
 ap.add_argument("--overlap", action="store_true"); ap.add_argument("--single", action="store_true")
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
+ap.add_argument("--transport", default="loopback", choices=["loopback", "rccl", "python"])   # see bench_mirror.py
+ap.add_argument("--run-steps", action="store_true")
 a = ap.parse_args(argv)
 nx, ny, nz, ppc = 64, 256, 256, 8
 lam = 0.8e-6
 dx, dy, dz = lam / 20, lam / 10, lam / 10
 dt = 0.95 / (299792458.0 * np.sqrt(dx ** -2 + dy ** -2 + dz ** -2))
-comm = None if a.single else MirrorComm(nx * dx, 262144)
+from lambdapic_amd.dist import LoopbackComm
+comm = None if a.single else (MirrorComm(nx * dx, 262144) if a.transport == "python" else
+                              LoopbackComm(nx * dx, 2, rccl=a.transport == "rccl"))
 eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, sort_interval=10, comm=comm, migrate_capacity=262144)
 eng.overlap = a.overlap
 n = nx * ny * nz * ppc
@@ -40,11 +44,14 @@ eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
 for _ in range(a.warmup):
     eng.step(dt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(a.steps):
-    eng.step(dt)
+if a.run_steps:
+    eng.run_steps(a.steps, dt)
+else:
+    for _ in range(a.steps):
+        eng.step(dt)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = eng.diagnostics()
-print(json.dumps({"what": "3-D, " + ("single slab" if a.single else "rank 0 of a mirrored 2-slab ring, no wire" +
+print(json.dumps({"what": "3-D, " + ("single slab" if a.single else f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", run_steps" if a.run_steps else "") +
                                       (", overlapped" if a.overlap else ", in line")),
                   "ms_per_step": 1e3 * el / a.steps, "alive": d["nalive"][0], "particles": n,
                   "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * 1.742e27 * dx * dy * dz / ppc * -constants.E_CHARGE) - 1)}))

@@ -10,6 +10,7 @@ class MirrorComm(SlabComm):
         super().__init__(None, periodic=True, single=True)
         self.size, self.rank, self.left, self.right = 2, 0, 1, 1
         self.shift = float(slab_width)
+        self.Lx = 2 * self.shift
         self.mig_numel = 1 + LPA_MIG_NATTR * migrate_capacity
         self.cap = migrate_capacity
 
@@ -25,6 +26,12 @@ class MirrorComm(SlabComm):
         for s_ in sets:
             self.exchange(*s_)
         return []
+
+    def allmin(self, v):
+        return float(v)
+
+    def any(self, flag):
+        return bool(flag)
 
     def barrier(self):
         pass
