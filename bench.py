@@ -671,6 +671,10 @@ def main():
     ap.add_argument("--inv-gamma", default="recomputed", choices=["recomputed", "streamed"],
                     help="1 / gamma of a particle: recomputed from its momenta by the fused kernels (default; two of the "
                          "thirteen attribute streams go) or loaded and stored like the reference's kernel")
+    ap.add_argument("--run-steps", action="store_true",
+                    help="time engine.run_steps(K) instead of K engine.step() calls: the E guard stage after the second E "
+                         "half step is left to the next step's first one (same state after K steps; one launch and, between "
+                         "slabs, one message round less per step).  Default at N > 1.")
     ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
                     help="rho between two sorts: advanced with the discrete continuity equation (default; the fused "
                          "kernel skips its rho atomics, a real deposit re-anchors rho on every sort step) or deposited "
@@ -741,9 +745,13 @@ def main():
     torch.cuda.synchronize(device)
     comm.barrier()
     torch.cuda.synchronize(device)
+    run_steps = args.run_steps or comm.size > 1
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(dt)
+    if run_steps:
+        eng.run_steps(args.steps, dt)
+    else:
+        for _ in range(args.steps):
+            eng.step(dt)
     torch.cuda.synchronize(device)
     comm.barrier()
     torch.cuda.synchronize(device)
@@ -774,6 +782,8 @@ def main():
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
                    "comm": comm_note,
+                   "e_guards": "once per step (engine.run_steps: the guard stage after E2 is the next step's after E1)"
+                               if run_steps else "after both E half steps",
                    "part_eb_writeback": False,
                    # rho between two sorts (lambdapic_amd/rho.py): "continuity" = advanced from the folded currents,
                    # re-anchored by a real deposit on every sort step; "deposited" = the reference's kernel

@@ -36,15 +36,29 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
 }
 
 // ---- internal helpers shared between the translation units (not part of the C ABI; used by lpa_step) --------------
+// one E / B half step with the periodic guard wrap of the axes in `wrap` fused into the sweep (lpa_fields.hip)
+int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
+              void *stream);
+// the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
+// [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
+int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
+                              const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
+                              const int32_t *loose_limit, void *stream);
+int lpai_push_deposit_rest_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
+                              const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
+                              const int32_t *loose_limit, void *stream);
+// jx jy jz (and rho) including guards = 0 and up to 32 device words = 0, one launch (lpa_step: reset + per-step counters)
+int lpai_reset_step(const lpa_grid *g, int with_rho, uint32_t *const *words, int nwords, void *stream);
 // zero up to 32 device words in one launch (the per-step counters: overflow lists, message headers)
 int lpai_zero_words(uint32_t *const *words, int n, void *stream);
-// slab ranks, after the J / rho guard planes of the neighbours arrived in r_lo / r_hi ([4][ng][plane] each, NULL = no
-// neighbour on that face): interior edge += received planes, and the guard planes this rank sent away are zeroed
-int lpai_fold_faces(const lpa_grid *g, const double *r_lo, const double *r_hi, void *stream);
+// the current fold of a step in one launch: periodic fold along `axes` + (slab ranks) the J / rho guard planes received
+// from the neighbours (r_lo / r_hi: [4][ng][plane] each, NULL = no neighbour on that face) added to the interior edge,
+// consumed guards and the guard planes this rank sent away zeroed
+int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, void *stream);
 // lpa_migrate_pack_edges_x / lpa_migrate_pack_x without their header memsets (zero_headers == 0: the caller zeroed them)
 int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
                       double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
-                      int zero_headers, void *stream);
+                      int zero_headers, const int32_t *loose_limit, void *stream);
 // lpa_migrate_unpack(_tiled) of BOTH faces in one launch (fs == NULL: arrival area only)
 int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs,
                          int64_t first_slot, int64_t area_capacity, int32_t *cursor, const double *buf_lo,

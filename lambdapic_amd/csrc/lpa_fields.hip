@@ -17,37 +17,67 @@ void lpa_set_error(const char *fmt, ...) {
 extern "C" const char *lpa_last_error(void) { return g_err; }
 extern "C" int lpa_version(void) { return 100; }
 
+// ---- guard wrap fused into the field updates (lpa_step): an interior cell within ng of a face of an axis in `axes`
+// (the axes that are periodic INSIDE this slab) also stores its new value in the guard cell(s) it is the periodic
+// image source of -- what lpa_guard_wrap would copy in a launch of its own right after the update.  The E sweep reads
+// no E neighbour and the B sweep no B neighbour, so writing the guards inside the sweep races with nothing.
+__device__ __forceinline__ void store3_wrapped(const GridV &g, double *fa, double *fb, double *fc, long c, int i, int j,
+                                               int k, int axes, double va, double vb, double vc) {
+    fa[c] = va; fb[c] = vb; fc[c] = vc;
+    if (!axes) return;
+    const int ng = g.ng;
+    const bool d3 = g.NZ > 1;
+    int ox[3] = {0, ((axes & 1) && i < ng) ? g.nx : 0, ((axes & 1) && i >= g.nx - ng) ? -g.nx : 0};
+    int oy[3] = {0, ((axes & 2) && j < ng) ? g.ny : 0, ((axes & 2) && j >= g.ny - ng) ? -g.ny : 0};
+    int oz[3] = {0, (d3 && (axes & 4) && k < ng) ? g.nz : 0, (d3 && (axes & 4) && k >= g.nz - ng) ? -g.nz : 0};
+    if (!(ox[1] | ox[2] | oy[1] | oy[2] | oz[1] | oz[2])) return;
+    const long sY = g.NZ, sX = (long)g.NY * g.NZ;
+    for (int a = 0; a < 3; a++) {
+        if (a && !ox[a]) continue;
+        for (int b = 0; b < 3; b++) {
+            if (b && !oy[b]) continue;
+            for (int e = 0; e < 3; e++) {
+                if ((e && !oz[e]) || !(a | b | e)) continue;
+                const long t = c + ox[a] * sX + oy[b] * sY + oz[e];
+                fa[t] = va; fb[t] = vb; fc[t] = vc;
+            }
+        }
+    }
+}
+
 // =====================================================================================================
 // FDTD.  Restates update_efield_2d / update_bfield_2d (core/maxwell/cpu.py:9-35) on the conventional
 // layout: interior node (i,j) is at [i+ng][j+ng]; i-1 at i=0 is the low guard, i+1 at nx-1 the high one.
 // AI: E sweep 13 loads + 3 stores per cell (104+24 B, 17 flop) -> HBM bound.
 // =====================================================================================================
-__global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double jfac) {
+__global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double jfac, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xm = c - g.NY, ym = c - 1;
     double bzc = g.bz[c];
-    g.ex[c] += bfac * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c];
-    g.ey[c] += bfac * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
-    g.ez[c] += bfac * ((g.by[c] - g.by[xm]) / g.dx - (g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+    double ex = g.ex[c] + (bfac * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c]);
+    double ey = g.ey[c] + (bfac * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c]);
+    double ez = g.ez[c] + (bfac * ((g.by[c] - g.by[xm]) / g.dx - (g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c]);
+    store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt) {
+__global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xp = c + g.NY, yp = c + 1;
     double ezc = g.ez[c];
-    g.bx[c] -= dt * ((g.ez[yp] - ezc) / g.dy);
-    g.by[c] -= dt * (-(g.ez[xp] - ezc) / g.dx);
-    g.bz[c] -= dt * ((g.ey[xp] - g.ey[c]) / g.dx - (g.ex[yp] - g.ex[c]) / g.dy);
+    double bx = g.bx[c] - dt * ((g.ez[yp] - ezc) / g.dy);
+    double by = g.by[c] - dt * (-(g.ez[xp] - ezc) / g.dx);
+    double bz = g.bz[c] - dt * ((g.ey[xp] - g.ey[c]) / g.dx - (g.ex[yp] - g.ex[c]) / g.dy);
+    store3_wrapped(g, g.bx, g.by, g.bz, c, i, j, 0, wrap, bx, by, bz);
 }
 
 // 3-D (core/maxwell/cpu.py:83-112): grid (ceil(nz/256), ny, nx)
-__global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double jfac) {
+__global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double jfac, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = blockIdx.z;
     if (k >= g.nz) return;
@@ -55,12 +85,13 @@ __global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double 
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
     long xm = c - sx, ym = c - sy, zm = c - 1;
     double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
-    g.ex[c] += bfac * ((bzc - g.bz[ym]) / g.dy - (byc - g.by[zm]) / g.dz) - jfac * g.jx[c];
-    g.ey[c] += bfac * ((bxc - g.bx[zm]) / g.dz - (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
-    g.ez[c] += bfac * ((byc - g.by[xm]) / g.dx - (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+    double ex = g.ex[c] + (bfac * ((bzc - g.bz[ym]) / g.dy - (byc - g.by[zm]) / g.dz) - jfac * g.jx[c]);
+    double ey = g.ey[c] + (bfac * ((bxc - g.bx[zm]) / g.dz - (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c]);
+    double ez = g.ez[c] + (bfac * ((byc - g.by[xm]) / g.dx - (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c]);
+    store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, k, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt) {
+__global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = blockIdx.z;
     if (k >= g.nz) return;
@@ -68,52 +99,57 @@ __global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt) {
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
     long xp = c + sx, yp = c + sy, zp = c + 1;
     double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
-    g.bx[c] -= dt * ((g.ez[yp] - ezc) / g.dy - (g.ey[zp] - eyc) / g.dz);
-    g.by[c] -= dt * ((g.ex[zp] - exc) / g.dz - (g.ez[xp] - ezc) / g.dx);
-    g.bz[c] -= dt * ((g.ey[xp] - eyc) / g.dx - (g.ex[yp] - exc) / g.dy);
+    double bx = g.bx[c] - dt * ((g.ez[yp] - ezc) / g.dy - (g.ey[zp] - eyc) / g.dz);
+    double by = g.by[c] - dt * ((g.ex[zp] - exc) / g.dz - (g.ez[xp] - ezc) / g.dx);
+    double bz = g.bz[c] - dt * ((g.ey[xp] - eyc) / g.dx - (g.ex[yp] - exc) / g.dy);
+    store3_wrapped(g, g.bx, g.by, g.bz, c, i, j, k, wrap, bx, by, bz);
 }
 
-extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *stream) {
+static int fdtd_e_2d(const lpa_grid *g, double dt, double eps0, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 1), "lpa_fdtd_e_2d: bad grid");
     LPA_REQUIRE(eps0 > 0, "lpa_fdtd_e_2d: eps0 must be > 0");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, g->nx);
     hipLaunchKernelGGL(k_fdtd_e_2d, grid, dim3(256), 0, (hipStream_t)stream, v,
-                       dt * (LPA_C * LPA_C), dt / eps0);
+                       dt * (LPA_C * LPA_C), dt / eps0, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_e_2d");
     return LPA_OK;
 }
+extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *stream) { return fdtd_e_2d(g, dt, eps0, 0, stream); }
 
-extern "C" int lpa_fdtd_b_2d(const lpa_grid *g, double dt, void *stream) {
+static int fdtd_b_2d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0), "lpa_fdtd_b_2d: bad grid");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, g->nx);
-    hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt);
+    hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_2d");
     return LPA_OK;
 }
+extern "C" int lpa_fdtd_b_2d(const lpa_grid *g, double dt, void *stream) { return fdtd_b_2d(g, dt, 0, stream); }
 
-extern "C" int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream) {
+static int fdtd_e_3d(const lpa_grid *g, double dt, double eps0, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 1), "lpa_fdtd_e_3d: bad grid");
     LPA_REQUIRE(eps0 > 0, "lpa_fdtd_e_3d: eps0 must be > 0");
     LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_e_3d: nx, ny must be <= 65535");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
     hipLaunchKernelGGL(k_fdtd_e_3d, grid, dim3(256), 0, (hipStream_t)stream, v,
-                       dt * (LPA_C * LPA_C), dt / eps0);
+                       dt * (LPA_C * LPA_C), dt / eps0, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_e_3d");
     return LPA_OK;
 }
+extern "C" int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream) { return fdtd_e_3d(g, dt, eps0, 0, stream); }
 
-extern "C" int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream) {
+static int fdtd_b_3d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0), "lpa_fdtd_b_3d: bad grid");
     LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_3d: nx, ny must be <= 65535");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
-    hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt);
+    hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_3d");
     return LPA_OK;
 }
+extern "C" int lpa_fdtd_b_3d(const lpa_grid *g, double dt, void *stream) { return fdtd_b_3d(g, dt, 0, stream); }
 
 // =====================================================================================================
 // CPML absorbing layers (core/boundary/cpml.py).  The reference attaches PML objects to edge patches and
@@ -268,7 +304,7 @@ __device__ __forceinline__ int cpml_layer(const CpmlAxisV &a, int pos, int &l, i
 }
 
 __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bfac, double jfac, double fac,
-                                                              CpmlAxisV ax, CpmlAxisV ay) {
+                                                              CpmlAxisV ax, CpmlAxisV ay, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= g.ny) return;
@@ -300,10 +336,10 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bf
         pa_[ps] = pa; pb_[ps] = pb;
         ex += fac * pa; ez -= fac * pb;
     }
-    g.ex[c] = ex; g.ey[c] = ey; g.ez[c] = ez;
+    store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay) {
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= g.ny) return;
@@ -335,31 +371,39 @@ __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt
         pa_[ps] = pa; pb_[ps] = pb;
         bx -= dt * pa; bz += dt * pb;
     }
-    g.bx[c] = bx; g.by[c] = by; g.bz[c] = bz;
+    store3_wrapped(g, g.bx, g.by, g.bz, c, i, j, 0, wrap, bx, by, bz);
 }
 
-extern "C" int lpa_fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
-                                        const lpa_cpml_axis *ay, void *stream) {
+static int fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                                const lpa_cpml_axis *ay, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 1) && eps0 > 0 && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
                 "lpa_fdtd_e_cpml_fused_2d: bad args");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, g->nx);
     hipLaunchKernelGGL(k_fdtd_e_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
-                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay));
+                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_fused_2d");
     return LPA_OK;
 }
-
-extern "C" int lpa_fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+extern "C" int lpa_fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
                                         const lpa_cpml_axis *ay, void *stream) {
+    return fdtd_e_cpml_fused_2d(g, dt, eps0, ax, ay, 0, stream);
+}
+
+static int fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay, int wrap,
+                                void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
                 "lpa_fdtd_b_cpml_fused_2d: bad args");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, g->nx);
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
-                       make_axisv(ay));
+                       make_axisv(ay), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_2d");
     return LPA_OK;
+}
+extern "C" int lpa_fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, void *stream) {
+    return fdtd_b_cpml_fused_2d(g, dt, ax, ay, 0, stream);
 }
 
 // 3-D fused twins.  psi layouts: axis 0 [layer][ny][nz], axis 1 [nx][layer][nz], axis 2 [nx][ny][layer].
@@ -380,7 +424,7 @@ __device__ __forceinline__ void psi_step(const CpmlAxisV &a, int w, long ps, int
 }
 
 __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bfac, double jfac, double fac,
-                                                              CpmlAxisV ax, CpmlAxisV ay, CpmlAxisV az) {
+                                                              CpmlAxisV ax, CpmlAxisV ay, CpmlAxisV az, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = blockIdx.z;
     if (k >= g.nz) return;
@@ -409,11 +453,11 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bf
         psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dby_z, dbx_z, pa, pb);
         ex -= fac * pa; ey += fac * pb;
     }
-    g.ex[c] = ex; g.ey[c] = ey; g.ez[c] = ez;
+    store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, k, wrap, ex, ey, ez);
 }
 
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay,
-                                                              CpmlAxisV az) {
+                                                              CpmlAxisV az, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = blockIdx.z;
     if (k >= g.nz) return;
@@ -442,33 +486,56 @@ __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt
         psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dey_z, dex_z, pa, pb);
         bx += dt * pa; by -= dt * pb;
     }
-    g.bx[c] = bx; g.by[c] = by; g.bz[c] = bz;
+    store3_wrapped(g, g.bx, g.by, g.bz, c, i, j, k, wrap, bx, by, bz);
 }
 
-extern "C" int lpa_fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
-                                        const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream) {
+static int fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
+                                const lpa_cpml_axis *ay, const lpa_cpml_axis *az, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 1) && eps0 > 0 && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny) &&
                     cpml_axis_ok(az, g->nz) && g->ny <= 65535 && g->nx <= 65535,
                 "lpa_fdtd_e_cpml_fused_3d: bad args");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
     hipLaunchKernelGGL(k_fdtd_e_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt * (LPA_C * LPA_C),
-                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay), make_axisv(az));
+                       dt / eps0, dt * (LPA_C * LPA_C), make_axisv(ax), make_axisv(ay), make_axisv(az), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_e_cpml_fused_3d");
     return LPA_OK;
 }
-
-extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+extern "C" int lpa_fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps0, const lpa_cpml_axis *ax,
                                         const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream) {
+    return fdtd_e_cpml_fused_3d(g, dt, eps0, ax, ay, az, 0, stream);
+}
+
+static int fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay,
+                                const lpa_cpml_axis *az, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny) && cpml_axis_ok(az, g->nz) &&
                     g->ny <= 65535 && g->nx <= 65535,
                 "lpa_fdtd_b_cpml_fused_3d: bad args");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
-                       make_axisv(ay), make_axisv(az));
+                       make_axisv(ay), make_axisv(az), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_3d");
     return LPA_OK;
+}
+extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax,
+                                        const lpa_cpml_axis *ay, const lpa_cpml_axis *az, void *stream) {
+    return fdtd_b_cpml_fused_3d(g, dt, ax, ay, az, 0, stream);
+}
+
+// one half step of E or B over the slab with the guard wrap of the axes in `wrap` fused in (lpa_step); ax[]: the fused
+// CPML descriptors, all NULL = the plain Yee update
+int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
+              void *stream) {
+    LPA_REQUIRE(g && g->nx >= g->ng && g->ny >= g->ng && (dim == 2 || g->nz >= g->ng), "lpai_fdtd: slab thinner than the guard");
+    const bool cpml = ax && ax[0];
+    if (dim == 2) {
+        if (efield) return cpml ? fdtd_e_cpml_fused_2d(g, dt, eps0, ax[0], ax[1], wrap, stream) : fdtd_e_2d(g, dt, eps0, wrap, stream);
+        return cpml ? fdtd_b_cpml_fused_2d(g, dt, ax[0], ax[1], wrap, stream) : fdtd_b_2d(g, dt, wrap, stream);
+    }
+    if (efield)
+        return cpml ? fdtd_e_cpml_fused_3d(g, dt, eps0, ax[0], ax[1], ax[2], wrap, stream) : fdtd_e_3d(g, dt, eps0, wrap, stream);
+    return cpml ? fdtd_b_cpml_fused_3d(g, dt, ax[0], ax[1], ax[2], wrap, stream) : fdtd_b_3d(g, dt, wrap, stream);
 }
 
 // ---- 3-D CPML (cpml.py:431-475 kappa-scaled update, :609-729 psi recursions) ---------------------------
@@ -1022,6 +1089,33 @@ __global__ void k_zero_words(Words32 a, int n) {
     if ((int)threadIdx.x < n) *a.w[threadIdx.x] = 0u;
 }
 
+// current reset of a step (lpa_reset_current / lpa_reset_j) with the per-step counters zeroed by the same launch
+__global__ void __launch_bounds__(256) k_reset_step(double *a, long n, double *b, long nb, Words32 w, int nw) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) a[t] = 0.0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nb; t += stride) b[t] = 0.0;
+    if (blockIdx.x == 0 && (int)threadIdx.x < nw) *w.w[threadIdx.x] = 0u;
+}
+
+int lpai_reset_step(const lpa_grid *g, int with_rho, uint32_t *const *words, int nwords, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && nwords >= 0 && nwords <= 32, "lpai_reset_step: bad args");
+    const long cnt = (long)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) * (g->nz > 1 ? (long)(g->nz + 2 * g->ng) : 1);
+    Words32 w;
+    for (int i = 0; i < nwords; i++) w.w[i] = words[i];
+    const bool contiguous = g->jy == g->jx + cnt && g->jz == g->jy + cnt && (!with_rho || g->rho == g->jz + cnt);
+    if (!contiguous) {      // separate allocations: the plain entry points, then the counters
+        if (int e = with_rho ? lpa_reset_current(g, stream) : lpa_reset_j(g, stream)) return e;
+        return nwords ? lpai_zero_words(words, nwords, stream) : LPA_OK;
+    }
+    const long n = (with_rho ? 4 : 3) * cnt;
+    long nb = (n + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_reset_step, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g->jx, n, (double *)nullptr, 0L, w,
+                       nwords);
+    LPA_CHECK_LAUNCH("lpai_reset_step");
+    return LPA_OK;
+}
+
 int lpai_zero_words(uint32_t *const *words, int n, void *stream) {
     for (int done = 0; done < n; done += 32) {
         Words32 a;
@@ -1033,31 +1127,91 @@ int lpai_zero_words(uint32_t *const *words, int n, void *stream) {
     return LPA_OK;
 }
 
-// blockIdx.z = face; the received planes are added to the interior edge (fill of sync_currents,
-// core/mpi/sync_fields2d.c:76-102) and the guard planes that travelled to that neighbour are zeroed (:44-74)
-__global__ void __launch_bounds__(256) k_fold_faces(Ptr6 f, const double *r_lo, const double *r_hi, long plane, long nx,
-                                                    int ng) {
-    const long n = (long)ng * plane;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const double *r = blockIdx.z == 0 ? r_lo : r_hi;
-    if (!r) return;
-    double *a = f.p[blockIdx.y];
-    const long edge = (blockIdx.z == 0 ? (long)ng : nx) * plane + t;      // interior edge planes
-    const long guard = (blockIdx.z == 0 ? 0L : nx + ng) * plane + t;      // my guard planes on that face
-    a[edge] += r[(long)blockIdx.y * n + t];
-    a[guard] = 0.0;
+// The whole current fold of a step in ONE launch (lpa_step): what k_fold_faces-style face addition, k_current_fold and
+// k_current_zero_guard do in three.  One thread per padded cell:
+//   * an interior cell adds up its periodic images along the local axes in the reference's order (x, y, z, xy, xz, yz,
+//     xyz: core/patch/sync_fields2d.c:43-148) and zeroes each image after reading it -- every consumed guard cell is the
+//     image of exactly one interior cell (n >= 2 ng), so nobody else reads or writes it;
+//   * on a slab rank the planes received from a neighbour (r_lo / r_hi: [4][ng][plane], NULL = no neighbour) are added
+//     on the fly, to the cell and to its y / z images alike: (f + r) per cell first, then the fold -- the sums the
+//     separate launches form (fill of sync_currents, core/mpi/sync_fields2d.c:76-102);
+//   * a cell of an x guard plane that was sent to a neighbour is zeroed (:44-74).
+__global__ void __launch_bounds__(256) k_fold_all(GridV g, int axes, const double *__restrict__ r_lo,
+                                                  const double *__restrict__ r_hi) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool d3 = g.NZ > 1;
+    const int NF = d3 ? g.NZ : g.NY;
+    if (z >= NF) return;
+    const int cx = d3 ? blockIdx.z : blockIdx.y, cy = d3 ? blockIdx.y : z, cz = d3 ? z : 0;
+    const int ng = g.ng;
+    const long sY = g.NZ, sX = (long)g.NY * g.NZ;
+    const long c = (long)cx * sX + (long)cy * sY + cz;
+    double *arr[4] = {g.jx, g.jy, g.jz, g.rho};
+    const int i = cx - ng, j = cy - ng, k = d3 ? cz - ng : 0;
+    if (i < 0 || i >= g.nx) {                       // x guard plane: sent to a neighbour -> zero
+        if ((i < 0 && r_lo) || (i >= g.nx && r_hi)) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) arr[a][c] = 0.0;
+        }
+        return;
+    }
+    // received planes cover the interior edge rows i < ng (low face) / i >= nx - ng (high face), whole planes
+    const double *r = (r_lo && i < ng) ? r_lo : ((r_hi && i >= g.nx - ng) ? r_hi : nullptr);
+    const long n = (long)ng * sX;                                        // doubles per component in a face message
+    const long rbase = r ? (long)(r == r_lo ? i : i - (g.nx - ng)) * sX + (long)cy * sY + cz : 0;
+    const bool gy = j < 0 || j >= g.ny, gz = d3 && (k < 0 || k >= g.nz);
+    if (gy || gz) {
+        // a y / z guard cell that the fold consumes is handled by its interior owner (read with its received share,
+        // then zeroed); one at an open face keeps what was deposited there and takes the neighbour's share here
+        const bool consumed = !((gy && !(axes & 2)) || (gz && !(axes & 4)));
+        if (!consumed && r) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) arr[a][c] += r[(long)a * n + rbase];
+        }
+        return;
+    }
+    const int ox = (axes & 1) ? (i < ng ? g.nx : (i >= g.nx - ng ? -g.nx : 0)) : 0;
+    const int oy = (axes & 2) ? (j < ng ? g.ny : (j >= g.ny - ng ? -g.ny : 0)) : 0;
+    const int oz = (d3 && (axes & 4)) ? (k < ng ? g.nz : (k >= g.nz - ng ? -g.nz : 0)) : 0;
+    if (!(ox | oy | oz) && !r) return;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        double *f = arr[a];
+        const double *ra = r ? r + (long)a * n + rbase : nullptr;
+        auto take = [&](long off) {                 // value of the image at c + off (with its received share), then zero it
+            double v = f[c + off];
+            if (ra) v += ra[off];
+            f[c + off] = 0.0;
+            return v;
+        };
+        double v = f[c];
+        if (ra) v += ra[0];
+        if (ox) v += take(ox * sX);
+        if (oy) v += take(oy * sY);
+        if (oz) v += take(oz);
+        if (ox && oy) v += take(ox * sX + oy * sY);
+        if (ox && oz) v += take(ox * sX + oz);
+        if (oy && oz) v += take(oy * sY + oz);
+        if (ox && oy && oz) v += take(ox * sX + oy * sY + oz);
+        f[c] = v;
+    }
 }
 
-int lpai_fold_faces(const lpa_grid *g, const double *r_lo, const double *r_hi, void *stream) {
-    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx >= g->ng, "lpai_fold_faces: bad grid");
-    if (!r_lo && !r_hi) return LPA_OK;
-    const long plane = (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1);
-    const long n = (long)g->ng * plane;
-    dim3 grid((unsigned)((n + 255) / 256), 4, 2);
-    hipLaunchKernelGGL(k_fold_faces, grid, dim3(256), 0, (hipStream_t)stream, cur_ptrs(g), r_lo, r_hi, plane,
-                       (long)g->nx, g->ng);
-    LPA_CHECK_LAUNCH("lpai_fold_faces");
+int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx > 0 && g->ny > 0 && g->ng > 0, "lpai_fold_all: bad grid");
+    const int dim = g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(g->nx >= 2 * g->ng && g->ny >= 2 * g->ng && (dim == 2 || g->nz >= 2 * g->ng),
+                "lpai_fold_all: slab thinner than 2*ng");
+    LPA_REQUIRE(!((r_lo || r_hi) && (axes & 1)), "lpai_fold_all: x is either folded locally or split over slabs");
+    if (axes == 0 && !r_lo && !r_hi) return LPA_OK;
+    GridV v;
+    memset(&v, 0, sizeof v);
+    v.nx = g->nx; v.ny = g->ny; v.nz = dim == 3 ? g->nz : 1; v.ng = g->ng;
+    v.NX = g->nx + 2 * g->ng; v.NY = g->ny + 2 * g->ng; v.NZ = dim == 3 ? g->nz + 2 * g->ng : 1;
+    v.jx = g->jx; v.jy = g->jy; v.jz = g->jz; v.rho = g->rho;
+    dim3 gp = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
+    hipLaunchKernelGGL(k_fold_all, gp, dim3(256), 0, (hipStream_t)stream, v, axes, r_lo, r_hi);
+    LPA_CHECK_LAUNCH("lpai_fold_all");
     return LPA_OK;
 }
 

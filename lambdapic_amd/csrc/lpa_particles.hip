@@ -194,6 +194,23 @@ __global__ void __launch_bounds__(256) k_push_deposit_list_2d(GridV g, PartV p, 
         update_global_2d(g, p, k, list[t]);
 }
 
+// what the tiled kernel leaves to the global-memory path, in ONE launch (lpa_step): the overflow list (particles outside
+// their tile's staged region) and the loose range behind the tile-ordered part -- on a slab rank the arrival area, of which
+// only the first *loose_limit slots have ever been handed out (the unpack kernels' cursor); the rest is NaN from the sort
+__global__ void __launch_bounds__(256) k_push_deposit_rest_2d(GridV g, PartV p, PushK k,
+                                                              const uint32_t *__restrict__ list,
+                                                              const uint32_t *__restrict__ list_count, long loose_first,
+                                                              long loose_count, const int32_t *__restrict__ loose_limit) {
+    const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (list) {
+        const long n = *list_count;
+        for (long t = t0; t < n; t += stride) update_global_2d(g, p, k, list[t]);
+    }
+    long m = loose_count;
+    if (loose_limit && (long)*loose_limit < m) m = *loose_limit;
+    for (long t = t0; t < m; t += stride) update_global_2d(g, p, k, loose_first + t);
+}
+
 // =====================================================================================================
 // K1-tiled
 // =====================================================================================================
@@ -984,6 +1001,22 @@ extern "C" int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *
     hipLaunchKernelGGL(k_push_deposit_list_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
                        make_gridv(g, 2), make_partv(p), make_pushk(pp, g), list, list_count);
     LPA_CHECK_LAUNCH("lpa_push_deposit_list_2d");
+    return LPA_OK;
+}
+
+int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
+                              const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
+                              const int32_t *loose_limit, void *stream) {
+    if (int e = check_push(g, p, pp, "lpai_push_deposit_rest_2d")) return e;
+    LPA_REQUIRE((!list || list_count) && max_count >= 0 && loose_first >= 0 && loose_count >= 0 &&
+                    loose_first + loose_count <= p->n, "lpai_push_deposit_rest_2d: bad list / range");
+    const long work = (list ? max_count : 0) > loose_count ? (long)max_count : (long)loose_count;
+    if (work == 0 || p->n == 0) return LPA_OK;
+    long nb = (work + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_push_deposit_rest_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, make_gridv(g, 2),
+                       make_partv(p), make_pushk(pp, g), list, list_count, (long)loose_first, (long)loose_count, loose_limit);
+    LPA_CHECK_LAUNCH("lpai_push_deposit_rest_2d");
     return LPA_OK;
 }
 

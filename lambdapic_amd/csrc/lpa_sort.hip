@@ -852,11 +852,11 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
                                                  const FreeSlots &fs = FreeSlots{nullptr, nullptr, 0, 0},
                                                  const int32_t *tile_off = nullptr, int ntiles = 0,
                                                  long n_sorted = 0, bool active = true,
-                                                 int32_t *surplus = nullptr) {
+                                                 int32_t *surplus = nullptr, bool have_x = false, double x_in = 0.0) {
     // called by every lane of the wave (`active` = this lane has a particle): the message slots are taken
     // with ONE atomic per wave and face -- tens of thousands of leavers bumping a single counter one by one
     // took 0.14 ms of the 3-D scan
-    double x = active ? p.x[ip] : 0.0;
+    double x = have_x ? x_in : (active ? p.x[ip] : 0.0);      // (have_x: the caller loaded a batch of positions up front)
     const bool live = active && !((p.dead && p.dead[ip]) || isnan(x));
     const int side = !live ? -1 : (x < xlo ? 0 : (x > xhi ? 1 : -1));
     const int lane = (int)(threadIdx.x & 63u);
@@ -929,17 +929,32 @@ __global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int
                                                               int ntiles, int edge_tiles, long n_sorted,
                                                               double xlo, double xhi, double *buf_lo,
                                                               double *buf_hi, long cap, FreeSlots fs,
-                                                              int32_t *surplus) {
+                                                              int32_t *surplus, const int32_t *loose_limit = nullptr) {
     const long a1 = tile_off[edge_tiles], b0 = tile_off[ntiles - edge_tiles], b1 = tile_off[ntiles];
-    const long nb = b1 - b0, nl = p.n > n_sorted ? p.n - n_sorted : 0;
+    long nl = p.n > n_sorted ? p.n - n_sorted : 0;
+    // (arrival area: only the slots the unpack kernels have handed out since the sort can hold a particle)
+    if (loose_limit && (long)*loose_limit < nl) nl = *loose_limit;
+    const long nb = b1 - b0;
     const long total = a1 + nb + nl;
-    // wave-uniform trip count (the slot allocation is a wave-wide operation)
-    const long lane = threadIdx.x & 63u;
-    for (long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; t0 < total; t0 += (long)gridDim.x * blockDim.x) {
-        const long t = t0 + lane;
-        const bool active = t < total;
-        long ip = !active ? 0 : (t < a1 ? t : (t < a1 + nb ? b0 + (t - a1) : n_sorted + (t - a1 - nb)));
-        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active, surplus);
+    // wave-uniform trip count (the slot allocation is a wave-wide operation); four positions per thread are loaded before
+    // any is looked at: one load per wave and trip left the scan latency bound (27 us for 5 M positions)
+    const long lane = threadIdx.x & 63u, stride = (long)gridDim.x * blockDim.x;
+    for (long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; t0 < total; t0 += 4 * stride) {
+        long ip[4];
+        double xv[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long t = t0 + u * stride + lane;
+            act[u] = t < total;
+            ip[u] = !act[u] ? 0 : (t < a1 ? t : (t < a1 + nb ? b0 + (t - a1) : n_sorted + (t - a1 - nb)));
+            xv[u] = act[u] ? p.x[ip[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t0 + u * stride >= total) break;      // (wave-uniform)
+            migrate_pack_one(p, ip[u], xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, act[u], surplus, true, xv[u]);
+        }
     }
 }
 
@@ -1081,8 +1096,8 @@ extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling
     const int ntiles = t->tiles_x * per_col;
     // grid-stride over a range only known on the device: enough workgroups to keep the loads of a large
     // edge region in flight (1024 of them made the 3-D scan latency bound: 0.17 ms for 12 M positions)
-    long nblk = (p->n + 255) / 256;
-    if (nblk > 16384) nblk = 16384;
+    long nblk = (p->n + 1023) / 1024;      // (four positions per thread)
+    if (nblk > 8192) nblk = 8192;
     hipLaunchKernelGGL(k_migrate_pack_edges_x, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), t->tile_off, ntiles,
                        edge_cols * per_col, (long)t->n_sorted, xlo, xhi, buf_lo, buf_hi, (long)capacity,
                        make_free_slots(fs, t), surplus);
@@ -1135,7 +1150,7 @@ extern "C" int lpa_migrate_unpack_tiled(const lpa_particles *p, const lpa_grid *
 // =====================================================================================================
 int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
                       double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
-                      int zero_headers, void *stream) {
+                      int zero_headers, const int32_t *loose_limit, void *stream) {
     if (zero_headers)
         return edge_cols > 0 ? lpa_migrate_pack_edges_x(p, t, edge_cols, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, stream)
                              : lpa_migrate_pack_x(p, xlo, xhi, buf_lo, buf_hi, capacity, surplus, stream);
@@ -1153,11 +1168,11 @@ int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_
                     2 * edge_cols <= t->tiles_x, "lpai_migrate_pack: bad tiling / edge_cols");
     const int per_col = t->tiles_y * (t->tiles_z > 0 ? t->tiles_z : 1);
     const int ntiles = t->tiles_x * per_col;
-    long nblk = (p->n + 255) / 256;
-    if (nblk > 16384) nblk = 16384;
+    long nblk = (p->n + 1023) / 1024;
+    if (nblk > 8192) nblk = 8192;
     hipLaunchKernelGGL(k_migrate_pack_edges_x, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), t->tile_off, ntiles,
                        edge_cols * per_col, (long)t->n_sorted, xlo, xhi, buf_lo, buf_hi, (long)capacity,
-                       make_free_slots(fs, t), surplus);
+                       make_free_slots(fs, t), surplus, loose_limit);
     LPA_CHECK_LAUNCH("lpai_migrate_pack");
     return LPA_OK;
 }

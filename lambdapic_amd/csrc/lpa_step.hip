@@ -42,18 +42,8 @@ static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx,
     return lpa_comm_exchange(sl->comm, m, nm, st);
 }
 
-static int step_fields(const lpa_step_desc *d, bool efield, void *st) {
-    const lpa_grid *g = &d->grid;
-    const double h = 0.5 * d->dt;
-    const lpa_cpml_axis *const *ax = efield ? d->e_axes : d->b_axes;
-    const bool cpml = ax[0] != nullptr;
-    if (d->dim == 2) {
-        if (efield) return cpml ? lpa_fdtd_e_cpml_fused_2d(g, h, d->eps0, ax[0], ax[1], st) : lpa_fdtd_e_2d(g, h, d->eps0, st);
-        return cpml ? lpa_fdtd_b_cpml_fused_2d(g, h, ax[0], ax[1], st) : lpa_fdtd_b_2d(g, h, st);
-    }
-    if (efield)
-        return cpml ? lpa_fdtd_e_cpml_fused_3d(g, h, d->eps0, ax[0], ax[1], ax[2], st) : lpa_fdtd_e_3d(g, h, d->eps0, st);
-    return cpml ? lpa_fdtd_b_cpml_fused_3d(g, h, ax[0], ax[1], ax[2], st) : lpa_fdtd_b_3d(g, h, st);
+static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st) {
+    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, st);
 }
 
 static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
@@ -95,24 +85,21 @@ static int step_push_fused_3d(const lpa_step_desc *d, void *st, bool *done) {
     }
     for (int k = 0; k < n; k++) {
         const lpa_step_species *sp = &d->species[idx[k]];
-        if (int e = lpa_push_deposit_list_3d(g, &sp->p, &pp[k], sp->overflow, sp->overflow_count, sp->n_sorted, st)) return e;
-        const int64_t loose = sp->p.n - sp->n_sorted;
-        if (loose > 0)
-            if (int e = lpa_push_deposit_3d(g, &sp->p, &pp[k], sp->n_sorted, loose, st)) return e;
+        if (int e = lpai_push_deposit_rest_3d(g, &sp->p, &pp[k], sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
+                                              sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st)) return e;
         done[idx[k]] = true;
     }
     return LPA_OK;
 }
 
-// every per-step device counter in ONE launch: the overflow-list counters of the tiled pushes and, on slab ranks, the
-// count headers of the particle messages (send side; receive side of a face without a neighbour: nothing arrives)
-static int step_zero_counters(const lpa_step_desc *d, void *st, bool overflow = true) {
-    uint32_t *w[6 * 64];
+// every per-step device counter: the overflow-list counters of the tiled pushes and, on slab ranks, the count headers of
+// the particle messages (send side; receive side of a face without a neighbour: nothing arrives).  Zeroed by ONE launch --
+// the current reset's when LPA_STAGE_RESET runs in the same call, else one of their own
+static int step_counters(const lpa_step_desc *d, uint32_t **w, bool overflow) {
     int n = 0;
     const lpa_step_slab *sl = d->slab;
     int32_t info[6] = {0, 0, 1, -1, -1, 0};
-    if (sl && sl->comm)
-        if (int e = lpa_comm_info(sl->comm, info)) return e;
+    if (sl && sl->comm && lpa_comm_info(sl->comm, info)) return -1;
     for (int s = 0; s < d->nspecies && s < 64; s++) {
         const lpa_step_species *sp = &d->species[s];
         if (overflow && sp->p.n > 0 && sp->t && sp->n_sorted > 0 && sp->overflow_count) w[n++] = sp->overflow_count;
@@ -123,14 +110,22 @@ static int step_zero_counters(const lpa_step_desc *d, void *st, bool overflow = 
                 if (h[k]) { w[n++] = h[k]; w[n++] = h[k] + 1; }      // (the header is a 64-bit count)
         }
     }
+    return n;
+}
+
+static int step_zero_counters(const lpa_step_desc *d, void *st, bool overflow = true) {
+    uint32_t *w[9 * 64];
+    const int n = step_counters(d, w, overflow);
+    if (n < 0) return LPA_ERR_ARG;
     return n ? lpai_zero_words(w, n, st) : LPA_OK;
 }
 
-static int step_push(const lpa_step_desc *d, void *st) {
+static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
     const lpa_grid *g = &d->grid;
     bool done[64] = {false};
     LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
-    if (int e = step_zero_counters(d, st)) return e;
+    if (!counters_zeroed)
+        if (int e = step_zero_counters(d, st)) return e;
     if (d->dim == 3 && d->fuse_species && d->nspecies <= 64)
         if (int e = step_push_fused_3d(d, st, done)) return e;
     for (int s = 0; s < d->nspecies; s++) {
@@ -151,15 +146,16 @@ static int step_push(const lpa_step_desc *d, void *st) {
                 lpa_set_error("lpa_step: hipEventRecord failed");
                 return LPA_ERR_HIP;
             }
-            e = d->dim == 2 ? lpa_push_deposit_list_2d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, st)
-                            : lpa_push_deposit_list_3d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, st);
+            // the overflow list and the loose particles (appended / arrived since the sort) in one launch
+            e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
+                                                        sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st)
+                            : lpai_push_deposit_rest_3d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
+                                                        sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st);
             if (e) return e;
-            const int64_t loose = sp->p.n - sp->n_sorted;     // appended / arrived since the sort
-            if (loose > 0) {
-                e = d->dim == 2 ? lpa_push_deposit_2d(g, &sp->p, &pp, sp->n_sorted, loose, st)
-                                : lpa_push_deposit_3d(g, &sp->p, &pp, sp->n_sorted, loose, st);
-                if (e) return e;
-            }
+        } else if (sp->t && sp->mig.cursor) {     // a slab rank's store without a tile-ordered particle: its arrival area
+            e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, &pp, nullptr, nullptr, 0, 0, sp->p.n, (const int32_t *)sp->mig.cursor, st)
+                            : lpai_push_deposit_rest_3d(g, &sp->p, &pp, nullptr, nullptr, 0, 0, sp->p.n, (const int32_t *)sp->mig.cursor, st);
+            if (e) return e;
         } else {
             e = d->dim == 2 ? lpa_push_deposit_2d(g, &sp->p, &pp, 0, sp->p.n, st)
                             : lpa_push_deposit_3d(g, &sp->p, &pp, 0, sp->p.n, st);
@@ -199,14 +195,13 @@ static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
         LPA_REQUIRE(mg->s_lo && mg->s_hi && mg->r_lo && mg->r_hi && mg->cursor, "lpa_step: species without migration buffers");
         LPA_REQUIRE(sp->t && sp->n_sorted >= 0, "lpa_step: a slab rank needs tile-ordered stores (arrival area)");
         if (int e = lpai_migrate_pack(&sp->p, sp->t, mg->edge_cols, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity,
-                                      mg->edge_cols > 0 ? mg->fs : nullptr, mg->surplus, 0, st)) return e;
+                                      mg->edge_cols > 0 ? mg->fs : nullptr, mg->surplus, 0, mg->cursor, st)) return e;
         m[nm].send_lo = mg->s_lo; m[nm].send_hi = mg->s_hi; m[nm].recv_lo = mg->r_lo; m[nm].recv_hi = mg->r_hi;
         m[nm].n_send_lo = m[nm].n_send_hi = m[nm].n_recv_lo = m[nm].n_recv_hi = nmig;
         nm++;
     }
     if (int e = lpa_comm_exchange(sl->comm, m, nm, st)) return e;
-    if (int e = lpai_fold_faces(g, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr, st)) return e;
-    if (int e = lpa_current_fold(g, d->local_axes, st)) return e;
+    if (int e = lpai_fold_all(g, d->local_axes, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr, st)) return e;
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
         const lpa_step_migrate *mg = &sp->mig;
@@ -237,37 +232,43 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     const bool slab = d->slab && d->slab->comm;
     LPA_REQUIRE(!slab || !(d->local_axes & 1), "lpa_step: x is split over slabs, not periodic inside one");
     LPA_REQUIRE(!slab || !d->slab->rho_exchange || d->slab->jx_left_plane, "lpa_step: jx_left_plane missing");
-    bool headers_zeroed = false;
+    bool headers_zeroed = false, counters_zeroed = false;
     for (int stage = first_stage; stage <= last_stage; stage++) {
         int e = LPA_OK;
         switch (stage) {
         case LPA_STAGE_E1:
-        case LPA_STAGE_E2:      // update_efield(dt / 2) + sync_guard_fields(E): simulation.py:946-952, 1112-1118
-            e = step_fields(d, true, stream);
-            if (stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2_GUARDS)) break;
-            if (!e) e = lpa_guard_wrap(g, 1, d->local_axes, stream);
-            if (!e && slab) e = slab_exchange_guards(d, 1, false, stream);
+        case LPA_STAGE_E2: {    // update_efield(dt / 2) + sync_guard_fields(E): simulation.py:946-952, 1112-1118
+            const bool defer = stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2_GUARDS);
+            e = step_fields(d, true, defer ? 0 : d->local_axes, stream);      // (the periodic guard wrap rides in the sweep)
+            if (!e && slab && !defer) e = slab_exchange_guards(d, 1, false, stream);
             break;
+        }
         case LPA_STAGE_B1:      // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
-            e = step_fields(d, false, stream);
-            if (!e) e = lpa_guard_wrap(g, 2, d->local_axes, stream);
+            e = step_fields(d, false, d->local_axes, stream);
             if (!e && slab) e = slab_exchange_guards(d, 2, false, stream);
             break;
-        case LPA_STAGE_RESET:   // current_depositor.reset(): :980-981
+        case LPA_STAGE_RESET: { // current_depositor.reset(): :980-981
+            // (+ the per-step counters of the push that follows in the same call: one launch for both)
+            uint32_t *w[9 * 64 + 1];
+            int ns = 0;
+            if (last_stage >= LPA_STAGE_PUSH) {
+                ns = step_counters(d, w, true);
+                if (ns < 0) return LPA_ERR_ARG;
+                if (ns > 31) ns = 0;        // (many species: LPA_STAGE_PUSH zeroes them with launches of its own)
+            }
+            int nw = ns;
             if (d->continuity) {
                 if (d->absorbed) e = lpa_rho_absorbed(g, d->absorbed, d->absorbed_count, d->absorbed_capacity, stream);
-                if (!e) e = lpa_reset_j(g, stream);
+                if (!e) e = lpai_reset_step(g, 0, w, nw, stream);
             } else {
-                e = lpa_reset_current(g, stream);
-                if (!e && d->absorbed_count &&
-                    hipMemsetAsync(d->absorbed_count, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
-                    lpa_set_error("lpa_step: memset of the absorbed counter failed");
-                    e = LPA_ERR_HIP;
-                }
+                if (d->absorbed_count) w[nw++] = d->absorbed_count;
+                e = lpai_reset_step(g, 1, w, nw, stream);
             }
+            counters_zeroed = !e && ns > 0;
             break;
+        }
         case LPA_STAGE_PUSH:    // pusher[ispec](dt, unified=True) for every species: :983-990
-            e = step_push(d, stream);
+            e = step_push(d, counters_zeroed, stream);
             headers_zeroed = true;
             break;
         case LPA_STAGE_FOLD:    // sync_currents (+ sync_particles between slabs): :1043-1080, 1155-1176
@@ -277,14 +278,15 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
                 if (!e && d->continuity && !d->slab->rho_exchange) e = slab_rho(d, stream);
                 break;
             }
-            e = lpa_current_fold(g, d->local_axes, stream);
+            e = lpai_fold_all(g, d->local_axes, nullptr, nullptr, stream);
             if (!e && d->continuity) e = lpa_rho_continuity(g, d->dt, d->local_axes, 0, nullptr, stream);
             break;
         case LPA_STAGE_B2:      // update_bfield(dt / 2): :1098 (the '_laser' stage follows: :1101)
-            e = step_fields(d, false, stream);
+            // a call that runs on through LPA_STAGE_B2_GUARD has no injection in between: the wrap rides in the sweep
+            e = step_fields(d, false, last_stage >= LPA_STAGE_B2_GUARD ? d->local_axes : 0, stream);
             break;
         case LPA_STAGE_B2_GUARD:    // sync_guard_fields(B): :1103-1108
-            e = lpa_guard_wrap(g, 2, d->local_axes, stream);
+            if (first_stage > LPA_STAGE_B2) e = lpa_guard_wrap(g, 2, d->local_axes, stream);
             if (!e && slab) {
                 e = slab_exchange_guards(d, 2, d->slab->rho_exchange != 0, stream);
                 if (!e && d->continuity && d->slab->rho_exchange) e = slab_rho(d, stream);

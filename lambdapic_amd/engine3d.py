@@ -1033,10 +1033,12 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             self.sync_currents_and_particles()
         finally:
             self.defer_rho = False
-        self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
-        if laser is not None:
+        if laser is None:
+            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2_GUARD)
+        else:
+            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
             laser(self, dt)
-        self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
+            self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
         self._exchange_guards(2)
         self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)
         if not defer_e2:

@@ -83,7 +83,10 @@ class FusedStepMixin:
         timed = self.kernel_events is not None and push
         self.kernel_events_step = False    # (fused species: one launch, one event pair -- on the first tiled species)
         # the species table is needed by the push and, on slab ranks, by the fold (leavers / arrivals)
-        entries = list(self._species_entries(dt, native and fold, pushed=not push)) if (push or (native and fold)) else []
+        # (slab ranks: with the migration bookkeeping -- the fold's leavers / arrivals, and the arrival cursor that bounds
+        # the loose range of the push)
+        slab_rank = self.comm.size > 1
+        entries = list(self._species_entries(dt, slab_rank, pushed=not push)) if (push or (native and fold)) else []
         arr = (_lib.lpa_step_species * max(len(entries), 1))()
         stream = torch.cuda.current_stream(self.device)
         for k, ent in enumerate(entries):
