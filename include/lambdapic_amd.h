@@ -305,6 +305,15 @@ typedef struct {
     double *absorbed;
     uint32_t *absorbed_count;
     int64_t absorbed_capacity;
+    /* optional (NULL = off; slab ranks): the slot of every particle whose advanced x lies outside [leave_lo, leave_hi]
+     * -- it now belongs to a neighbour slab -- is appended to `leavers` (uint32 slots; leaver_count = device uint32
+     * the caller zeroes before the step's pushes; entries beyond leaver_capacity are dropped and only counted: such a
+     * particle is reported again by the next step's push).  The migration pack then visits the listed slots instead of
+     * scanning the edge tile columns for them (lpa_migrate_pack_list). */
+    uint32_t *leavers;
+    uint32_t *leaver_count;
+    int64_t leaver_capacity;
+    double leave_lo, leave_hi;
 } lpa_push_params;
 #define LPA_ABSORB_X 16
 /* LPA_PUSH_NO_RHO: the fused kernels deposit jx jy jz only.  Esirkepov's deposit satisfies the discrete continuity
@@ -470,6 +479,12 @@ int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *b
 int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo,
                              double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
                              const lpa_free_slots *fs, int32_t *surplus, void *stream);
+/* the same pack over a list of slots (lpa_push_params.leavers, written by the push kernels of this step): visits
+ * min(*list_count, list_capacity) slots; a listed slot whose particle is not (or no longer) outside [xlo, xhi] is left
+ * alone.  `t` / `fs` as for lpa_migrate_pack_edges_x (both may be NULL: no free-slot bookkeeping). */
+int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+                          int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi,
+                          int64_t capacity, const lpa_free_slots *fs, int32_t *surplus, void *stream);
 /* unpack for a tile-ordered store with free-slot stacks: an arrival whose tile (from its position on grid
  * `g`) has a recorded free slot takes it and is pushed by the tiled kernel from the next step on; the others are
  * appended to the arrival area exactly like lpa_migrate_unpack. */

@@ -68,8 +68,9 @@ class lpa_push_params(C.Structure):
     _fields_ = [("dt", C.c_double), ("q", C.c_double), ("m", C.c_double), ("wrap", C.c_int32), ("flags", C.c_int32),
                 ("lo", C.c_double * 3), ("hi", C.c_double * 3),
                 ("alo", C.c_double * 3), ("ahi", C.c_double * 3),
-                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64)]
-
+                ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64),
+                ("leavers", C.c_void_p), ("leaver_count", C.c_void_p), ("leaver_capacity", C.c_int64),
+                ("leave_lo", C.c_double), ("leave_hi", C.c_double)]
 
 
 
@@ -182,6 +183,7 @@ SIGNATURES = {
     "lpa_sort_overflow": (_vp, [_vp]),
     "lpa_migrate_pack_x": (_i, [_P, _d, _d, _vp, _vp, _i64, _vp, _vp]),
     "lpa_migrate_pack_edges_x": (_i, [_P, _T, C.c_int32, _d, _d, _vp, _vp, _i64, _FS, _vp, _vp]),
+    "lpa_migrate_pack_list": (_i, [_P, _T, _vp, _vp, _i64, _d, _d, _vp, _vp, _i64, _FS, _vp, _vp]),
     "lpa_migrate_unpack_tiled": (_i, [_P, _G, _T, _FS, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_migrate_unpack": (_i, [_P, _i64, _i64, _vp, _vp, _i64, _d, _vp]),
     "lpa_sync_guard_fields_2d": (_i, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),

@@ -59,6 +59,10 @@ int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double 
 int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
                       double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
                       int zero_headers, const int32_t *loose_limit, void *stream);
+// lpa_migrate_pack_list without its header memsets
+int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+                           int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
+                           const lpa_free_slots *fs, int32_t *surplus, void *stream);
 // lpa_migrate_unpack(_tiled) of BOTH faces in one launch (fs == NULL: arrival area only)
 int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs,
                          int64_t first_slot, int64_t area_capacity, int32_t *cursor, const double *buf_lo,
@@ -154,6 +158,19 @@ __device__ __forceinline__ double rcp_nr(double a) {
     y = fma(y, e, y);
     e = fma(-a, y, 1.0);
     return fma(y, e, y);
+}
+
+// a particle whose advanced position left the slab along x: its slot goes on the leaver list (lpa_push_params.leavers;
+// rare: one atomic each).  K = PushK / PushK3.
+template <class K>
+__device__ __forceinline__ void report_leaver(const K &k, double xs, long ip) {
+#ifdef LPA_NO_LEAVERS      // A/B build: what the check costs the tiled kernels
+    return;
+#endif
+    if (k.leavers && (xs < k.leave_lo || xs > k.leave_hi)) {      // (NaN -- dead, absorbed -- compares false)
+        const uint32_t slot = atomicAdd(k.leaver_count, 1u);
+        if ((long)slot < k.leaver_cap) k.leavers[slot] = (uint32_t)ip;
+    }
 }
 
 // relativistic Boris rotation, core/pusher/unified/unified_pusher_2d.c:15-51

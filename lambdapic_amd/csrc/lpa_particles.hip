@@ -32,6 +32,10 @@ struct PushK {
     double *absorbed;
     uint32_t *absorbed_count;
     long absorbed_cap;
+    // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
+    uint32_t *leavers, *leaver_count;
+    long leaver_cap;
+    double leave_lo, leave_hi;
 };
 
 #ifndef LPA_K1_VARIANTS
@@ -48,6 +52,8 @@ __device__ __forceinline__ void report_absorbed_2d(const PushK &k, double o1x, d
 
 static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
     PushK k;
+    k.leavers = pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
+    k.leave_lo = pp->leave_lo; k.leave_hi = pp->leave_hi;
     k.dep.c_rho = k.dep.c_jx = k.dep.c_jy = 0.0;
     if (g) {   // current/current_deposit.h:238-241: (q / (dx dy)) w, (q / (dy dt)) w, (q / (dx dt)) w
         k.dep.c_rho = pp->q / (g->dx * g->dy);
@@ -174,6 +180,7 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     if (finish_position_2d(x, y, k) && k.absorbed)     // deposit end point = r + v dt / 2, v = u c / gamma
         report_absorbed_2d(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
                            (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy), k.dep.c_rho * w);
+    report_leaver(k, x, ip);
     p.x[ip] = x; p.y[ip] = y;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if (!noig) p.ig[ip] = ig;
@@ -607,6 +614,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (finish_position_2d(xs, ys, k) && k.absorbed)    // rare: a particle reached an open face
                 report_absorbed_2d(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                    k.dep.c_rho * w);
+            report_leaver(k, xs, ip);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
             // diagnostic builds (wrong physics; profiles/r03_k1_streams.txt): what the attribute stores cost
@@ -862,6 +870,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 const uint32_t od = (uint32_t)(dst - rb) * 8u;
                 double x = m[0], y = m[1];
                 finish_position_2d(x, y, k);
+                report_leaver(k, x, dst);
                 st(p.x, od, x); st(p.y, od, y);
                 st(p.ux, od, m[2]); st(p.uy, od, m[3]); st(p.uz, od, m[4]); st(p.ig, od, m[5]); st(p.w, od, m[6]);
                 if (p.id) p.id[dst] = mid;
@@ -975,6 +984,8 @@ static int check_push(const lpa_grid *g, const lpa_particles *p, const lpa_push_
     LPA_REQUIRE(!(pp->flags & LPA_PUSH_NO_RHO) || !(pp->wrap & (3 * LPA_ABSORB_X)) || pp->absorbed,
                 "%s: LPA_PUSH_NO_RHO with absorbing faces needs the absorbed list", name);
     LPA_REQUIRE(!pp->absorbed || (pp->absorbed_count && pp->absorbed_capacity > 0), "%s: bad absorbed list", name);
+    LPA_REQUIRE(!pp->leavers || (pp->leaver_count && pp->leaver_capacity > 0 && pp->leave_lo < pp->leave_hi),
+                "%s: bad leaver list", name);
     return LPA_OK;
 }
 

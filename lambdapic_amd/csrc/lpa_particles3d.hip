@@ -22,6 +22,10 @@ struct PushK3 {
     double *absorbed;
     uint32_t *absorbed_count;
     long absorbed_cap;
+    // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
+    uint32_t *leavers, *leaver_count;
+    long leaver_cap;
+    double leave_lo, leave_hi;
 };
 
 // the deposit end point (cells from node 0) and charge density factor of a particle that was just absorbed
@@ -267,6 +271,7 @@ __device__ __forceinline__ void update_global_3d(const GridV &g, const PartV &p,
                         (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy),
                         (ze + uz * LPA_C * ig * 0.5 * k.dt - g.z0) * (1.0 / g.dz), (k.q / (g.dx * g.dy * g.dz)) * w);
     }
+    report_leaver(k, x, ip);
     p.x[ip] = x; p.y[ip] = y; p.z[ip] = z;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz; p.ig[ip] = ig;
 }
@@ -694,6 +699,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
             if (finish_position_3d(xs, ys, zs, k) && k.absorbed)    // rare: a particle reached an open face
                 report_absorbed(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                 (z + vz * 0.5 * k.dt - g.z0) * inv_dz, k.c_rho * w);
+            report_leaver(k, xs, ip);
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
             stp(p.x, o, xs); stp(p.y, o, ys); stp(p.z, o, zs);
             stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); stp(p.ig, o, ig);
@@ -878,6 +884,8 @@ static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr
     k.wrap = pp->wrap;
     k.flags = pp->flags;
     k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
+    k.leavers = pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
+    k.leave_lo = pp->leave_lo; k.leave_hi = pp->leave_hi;
     for (int a = 0; a < 3; a++) {
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
         k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
@@ -914,6 +922,8 @@ static int check_push3(const lpa_grid *g, const lpa_particles *p, const lpa_push
     LPA_REQUIRE(!(pp->flags & LPA_PUSH_NO_RHO) || !(pp->wrap & (7 * LPA_ABSORB_X)) || pp->absorbed,
                 "%s: LPA_PUSH_NO_RHO with absorbing faces needs the absorbed list", name);
     LPA_REQUIRE(!pp->absorbed || (pp->absorbed_count && pp->absorbed_capacity > 0), "%s: bad absorbed list", name);
+    LPA_REQUIRE(!pp->leavers || (pp->leaver_count && pp->leaver_capacity > 0 && pp->leave_lo < pp->leave_hi),
+                "%s: bad leaver list", name);
     return LPA_OK;
 }
 

@@ -958,6 +958,23 @@ __global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int
     }
 }
 
+// the same over the slots the push kernels of this step reported (lpa_push_params.leavers): no scan at all
+__global__ void __launch_bounds__(256) k_migrate_pack_list(PartV p, const uint32_t *__restrict__ list,
+                                                           const uint32_t *__restrict__ list_count, long list_cap,
+                                                           const int32_t *__restrict__ tile_off, int ntiles, long n_sorted,
+                                                           double xlo, double xhi, double *buf_lo, double *buf_hi,
+                                                           long cap, FreeSlots fs, int32_t *surplus) {
+    long total = *list_count;
+    if (total > list_cap) total = list_cap;
+    const long lane = threadIdx.x & 63u;
+    for (long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; t0 < total; t0 += (long)gridDim.x * blockDim.x) {
+        const long t = t0 + lane;
+        const bool active = t < total;
+        long ip = active ? (long)list[t] : 0;
+        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active && ip < p.n, surplus);
+    }
+}
+
 // one atomic per wave for the lanes that need an arrival-area slot; -1 for the others
 __device__ __forceinline__ long area_slot_wave(bool need, int32_t *cursor) {
     const unsigned long long m = __ballot(need);
@@ -1103,6 +1120,45 @@ extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling
                        make_free_slots(fs, t), surplus);
     LPA_CHECK_LAUNCH("lpa_migrate_pack_edges_x");
     return LPA_OK;
+}
+
+static int migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+                             int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
+                             const lpa_free_slots *fs, int32_t *surplus, int zero_headers, void *stream) {
+    LPA_REQUIRE(lpa_part_ok(p, 2) && list && list_count && list_capacity > 0 && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
+                "lpa_migrate_pack_list: bad args");
+    LPA_REQUIRE(!fs || (t && t->tile_off && free_slots_ok(fs, t) && t->n_sorted >= 0 && t->n_sorted <= p->n),
+                "lpa_migrate_pack_list: bad tiling / free-slot stacks");
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_headers && (hipMemsetAsync(buf_lo, 0, sizeof(double), st) != hipSuccess ||
+                         hipMemsetAsync(buf_hi, 0, sizeof(double), st) != hipSuccess)) {
+        lpa_set_error("lpa_migrate_pack_list: memset failed");
+        return LPA_ERR_HIP;
+    }
+    if (p->n == 0) return LPA_OK;
+    int ntiles = 0;
+    if (fs) ntiles = t->tiles_x * t->tiles_y * (t->tiles_z > 0 ? t->tiles_z : 1);
+    // the list is short (what crosses a face in one step): a fixed small grid, grid-stride over the device-side count
+    long nblk = (list_capacity + 255) / 256;
+    if (nblk > 64) nblk = 64;
+    hipLaunchKernelGGL(k_migrate_pack_list, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), list, list_count,
+                       (long)list_capacity, fs ? t->tile_off : nullptr, ntiles, fs ? (long)t->n_sorted : 0L, xlo, xhi, buf_lo,
+                       buf_hi, (long)capacity, make_free_slots(fs, t), surplus);
+    LPA_CHECK_LAUNCH("lpa_migrate_pack_list");
+    return LPA_OK;
+}
+
+extern "C" int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list,
+                                     const uint32_t *list_count, int64_t list_capacity, double xlo, double xhi,
+                                     double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs,
+                                     int32_t *surplus, void *stream) {
+    return migrate_pack_list(p, t, list, list_count, list_capacity, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, 1, stream);
+}
+
+int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+                           int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
+                           const lpa_free_slots *fs, int32_t *surplus, void *stream) {
+    return migrate_pack_list(p, t, list, list_count, list_capacity, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, 0, stream);
 }
 
 extern "C" int lpa_migrate_unpack(const lpa_particles *p, int64_t first_slot, int64_t area_capacity,

@@ -103,6 +103,7 @@ static int step_counters(const lpa_step_desc *d, uint32_t **w, bool overflow) {
     for (int s = 0; s < d->nspecies && s < 64; s++) {
         const lpa_step_species *sp = &d->species[s];
         if (overflow && sp->p.n > 0 && sp->t && sp->n_sorted > 0 && sp->overflow_count) w[n++] = sp->overflow_count;
+        if (overflow && sp->pp.leaver_count) w[n++] = sp->pp.leaver_count;
         if (sl && sl->comm) {
             uint32_t *h[4] = {(uint32_t *)sp->mig.s_lo, (uint32_t *)sp->mig.s_hi,
                               info[3] < 0 ? (uint32_t *)sp->mig.r_lo : nullptr, info[4] < 0 ? (uint32_t *)sp->mig.r_hi : nullptr};
@@ -194,8 +195,11 @@ static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
         const lpa_step_migrate *mg = &sp->mig;
         LPA_REQUIRE(mg->s_lo && mg->s_hi && mg->r_lo && mg->r_hi && mg->cursor, "lpa_step: species without migration buffers");
         LPA_REQUIRE(sp->t && sp->n_sorted >= 0, "lpa_step: a slab rank needs tile-ordered stores (arrival area)");
-        if (int e = lpai_migrate_pack(&sp->p, sp->t, mg->edge_cols, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity,
-                                      mg->edge_cols > 0 ? mg->fs : nullptr, mg->surplus, 0, mg->cursor, st)) return e;
+        if (sp->pp.leavers) {       // this step's pushes listed the leavers: no scan
+            if (int e = lpai_migrate_pack_list(&sp->p, sp->t, sp->pp.leavers, sp->pp.leaver_count, sp->pp.leaver_capacity, sl->xlo,
+                                               sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity, mg->fs, mg->surplus, st)) return e;
+        } else if (int e = lpai_migrate_pack(&sp->p, sp->t, mg->edge_cols, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity,
+                                             mg->edge_cols > 0 ? mg->fs : nullptr, mg->surplus, 0, mg->cursor, st)) return e;
         m[nm].send_lo = mg->s_lo; m[nm].send_hi = mg->s_hi; m[nm].recv_lo = mg->r_lo; m[nm].recv_hi = mg->r_hi;
         m[nm].n_send_lo = m[nm].n_send_hi = m[nm].n_recv_lo = m[nm].n_recv_hi = nmig;
         nm++;
@@ -205,7 +209,7 @@ static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
         const lpa_step_migrate *mg = &sp->mig;
-        if (int e = lpai_migrate_unpack2(&sp->p, g, sp->t, mg->edge_cols > 0 ? mg->fs : nullptr, sp->n_sorted, mg->area_capacity,
+        if (int e = lpai_migrate_unpack2(&sp->p, g, sp->t, (mg->edge_cols > 0 || sp->pp.leavers) ? mg->fs : nullptr, sp->n_sorted, mg->area_capacity,
                                          mg->cursor, mg->r_lo, mg->r_hi, sl->migrate_capacity, sl->shift_lo, sl->shift_hi, st))
             return e;
     }

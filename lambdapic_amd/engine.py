@@ -483,7 +483,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                 "sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
                 "overflow": torch.empty(sp.capacity, dtype=torch.int32, device=self.device),
                 # 0: overflow list, 1: arrival cursor, 2: overflow list of the edge part, 3: leavers that did not fit
-                "counters": torch.zeros(4, dtype=torch.int32, device=self.device),
+                # (4: this step's leaver list, lpa_push_params.leavers)
+                "counters": torch.zeros(8, dtype=torch.int32, device=self.device),
                 "area": area,
                 "tiling": _lib.lpa_tiling(),
                 "mig": None,
@@ -816,8 +817,17 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         fs = ws.get("fs") if self.reuse_slots else None
         if fs is not None and (cols == 0 or cols > fs.edge_cols):
             fs = None        # the order is older than the stacks were sized for
-        return {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
-                "area": ws["area"], "cols": cols}
+        out = {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
+               "area": ws["area"], "cols": cols}
+        if self.leaver_lists and self.native_slab():
+            # the push kernels list the slots that left the slab (exact: no scan of the edge tile columns, and the free-slot
+            # stacks stay usable however old the order is)
+            if ws.get("leavers") is None:
+                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+            out.update(leavers=ws["leavers"], leaver_count=ws["counters"][4:5], fs=ws.get("fs") if self.reuse_slots else None)
+        return out
+
+    leaver_lists = True      # native slab steps: the push kernels report the leavers (lpa_push_params.leavers)
 
     def _slab_fill(self, slab):
         """the slab section of an lpa_step descriptor (step.py); returns what must stay alive until the launches ran"""
@@ -1059,7 +1069,11 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                 ws = self._sort_ws(sp)
                 ent.update(tiling=sp.tiling, n_sorted=sp.n_sorted, overflow=ws["overflow"], count=ws["counters"][0:1])
             if with_mig:
-                ent["mig"] = self._slab_species(sp, pushed)
+                ent["mig"] = mig = self._slab_species(sp, pushed)
+                if "leavers" in mig and not pushed:
+                    pp.leavers, pp.leaver_count = mig["leavers"].data_ptr(), mig["leaver_count"].data_ptr()
+                    pp.leaver_capacity = mig["leavers"].numel()
+                    pp.leave_lo, pp.leave_hi = self._owner_bounds_x()
             yield ent
 
     # ---- one full step in the reference's stage order (simulation/simulation.py:946-1118) ----------

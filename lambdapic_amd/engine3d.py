@@ -395,7 +395,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             if sp.get("alt") is None or sp["alt"].shape != sp["data"].shape:
                 sp["alt"] = torch.empty_like(sp["data"])
             nbytes = self.L.lpa_sort_workspace_bytes_ranks(self._g(), cap, sp.get("stripe_ranks", 0))
-            cnt = torch.zeros(4, dtype=torch.int32, device=self.device)   # 0: overflow, 1: arrivals
+            cnt = torch.zeros(8, dtype=torch.int32, device=self.device)   # 0: overflow, 1: arrivals, 2: edge overflow, 3: surplus, 4: leavers
             sp["ws"] = {"sort": torch.zeros(nbytes, dtype=torch.uint8, device=self.device),
                         "overflow": torch.empty(max(cap, 1), dtype=torch.int32, device=self.device),
                         "counters": cnt, "count": cnt[0:1], "tiling": _lib.lpa_tiling(), "mig": None}
@@ -567,8 +567,15 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         fs = ws.get("fs") if (self.reuse_slots and cols) else None
         if fs is not None and cols > fs.edge_cols:
             fs = None
-        return {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
-                "area": self.arrival_area(), "cols": cols}
+        out = {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
+               "area": self.arrival_area(), "cols": cols}
+        if self.leaver_lists and self.native_slab() and sp["tiling"] is not None:      # (see PicEngine2D._slab_species)
+            if ws.get("leavers") is None:
+                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+            out.update(leavers=ws["leavers"], leaver_count=ws["counters"][4:5], fs=ws.get("fs") if self.reuse_slots else None)
+        return out
+
+    leaver_lists = True
 
     def _slab_fill(self, slab):
         """the slab section of an lpa_step descriptor (step.py)"""
@@ -986,7 +993,11 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                 ws = sp["ws"]
                 ent.update(tiling=sp["tiling"], n_sorted=sp["n_sorted"], overflow=ws["overflow"], count=ws["count"])
             if with_mig:
-                ent["mig"] = self._slab_species(sp, pushed)
+                ent["mig"] = mig = self._slab_species(sp, pushed)
+                if "leavers" in mig and not pushed:
+                    pp.leavers, pp.leaver_count = mig["leavers"].data_ptr(), mig["leaver_count"].data_ptr()
+                    pp.leaver_capacity = mig["leavers"].numel()
+                    pp.leave_lo, pp.leave_hi = self._owner_bounds_x()
             yield ent
 
     def step(self, dt, laser=None, defer_e2=False):

@@ -46,6 +46,10 @@ else:
         eng.step(dt)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 k_ms = float(np.sum([x.elapsed_time(y) for x, y in eng.kernel_events])) / a.steps
+sp0 = eng.species[0]
+ws0 = eng._sort_ws(sp0)
+print("counters [overflow, arrival cursor, overflow edge, surplus, leavers]:", ws0["counters"].tolist()[:5], "steps since sort", sp0.steps_since_sort,
+      "fs" , None if ws0.get("fs") is None else (ws0["fs"].edge_cols, int(ws0["fs_count"].sum().item()), int(ws0["fs_count"].max().item())), file=sys.stderr)
 d = eng.diagnostics()
 w = float(eng.species[0].cset.arr("w")[0].item())
 print(json.dumps({"what": f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", overlapped" if a.overlap else "") +
