@@ -425,13 +425,16 @@ def _gather(v):
     return out
 
 
-def _timed(comm, device, step, nsteps):
-    """EXACTLY ``nsteps`` calls of ``step`` between barrier + synchronize on both sides; max over the ranks"""
+def _timed(comm, device, step, nsteps, batch=None):
+    """EXACTLY ``nsteps`` steps -- ``nsteps`` calls of ``step()``, or one call of ``batch(nsteps)`` -- between barrier +
+    synchronize on both sides; max over the ranks"""
     torch.cuda.synchronize(device)
     comm.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for _ in range(nsteps):
+    if batch is not None:
+        batch(nsteps)
+    for _ in range(nsteps if batch is None else 0):
         step()
     torch.cuda.synchronize(device)
     comm.barrier()
@@ -506,7 +509,7 @@ def leg_c2_strong(args, comm, device, steps, warm):
     for _ in range(warm):
         eng.step(dt)
     eng.kernel_events = []
-    el = _timed(comm, device, lambda: eng.step(dt), steps)
+    el = _timed(comm, device, None, steps, batch=lambda n: eng.run_steps(n, dt))
     d = eng.diagnostics(reduce=True)
     w = float(eng.species[0].cset.arr("w")[0].item())
     n_tot = n_local * comm.size
@@ -517,14 +520,15 @@ def leg_c2_strong(args, comm, device, steps, warm):
                        f"of {nx_loc}x1024 (fixed problem size)",
            "scaling": "strong", "value": n_tot * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
            "steps": steps, "alive_per_rank": _gather(eng.diagnostics()["nalive"][0]), "charge_rel_err": charge_err,
-           "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+           "rho": eng.rho_mode(), "overlap": bool(eng.overlap) and not eng.one_call_step(),
+           "one_call_step": eng.one_call_step(), "e_guards": "once per step (engine.run_steps)",
            "roofline": _k1_roofline(eng, steps, BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * nx_loc * 1024,
                                     "k_push_deposit_tiled_2d")}
     del eng
     return out
 
 
-def leg_c4(args, comm, device, steps, warm, p2p):
+def leg_c4(args, comm, device, steps, warm, make_comm):
     """BASELINE config C4 (2-D LWFA, `example/lwfa.py:30-76`): 4096 x 512 cells, 16 ppc, ne = 0.01 nc for x > 1 um with
     1 um vacuum margins in y, CPML on all sides, SimpleLaser2D a0 = 2, moving window at c with injection -- as N slabs
     of (4096 / N) x 512 through the Simulation stage loop (chain: the end ranks own the x layers)"""
@@ -538,7 +542,7 @@ def leg_c4(args, comm, device, steps, warm, p2p):
     if nxl * comm.size != nx or nxl % 64:
         return {"workload": "C4", "value": None, "error": f"4096 cells do not split into {comm.size} slabs of 64-cell patches"}
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
-    chain = SlabComm(None, periodic=False, p2p_group=p2p)
+    chain = make_comm(periodic=False)
     sim = Simulation(nx, ny, dx, dy, npatch_x=nxl // 64, npatch_y=ny // 64, random_seed=1, sort_interval=20, comm=chain,
                      device=str(device))
     Ly = ny * dy
@@ -562,6 +566,8 @@ def leg_c4(args, comm, device, steps, warm, p2p):
 
     eng.shift_window, eng.append_particles_device = shift_window, append_particles_device
     cbs = [SimpleLaser2D(a0=2.0, w0=5e-6, ctau=5e-6, l0=LAMBDA0), MovingWindow(velocity=C_LIGHT, start_time=0.03 * sim.Lx / C_LIGHT)]
+    if getattr(args, "stall_rank", -1) == comm.rank:      # rehearsal of the watchdog: this rank never joins the next exchange
+        time.sleep(1e6)
     sim.run(5, callbacks=cbs)          # the cells loaded inside the x-max layer are absorbed by the first step
     n_init = _allsum([_live_2d(eng)[2]])[0]
     ledger.update(dropped=0, injected=0)
@@ -589,11 +595,11 @@ def leg_c4(args, comm, device, steps, warm, p2p):
             "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_2d(eng)[2]), "window_shifts": shifts[0],
             "ledger": {"initial": int(n_init), "dropped": int(dropped), "injected": int(injected), "final": int(n_end)},
-            "charge_rel_err": err, "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
-            "roofline": roof}
+            "charge_rel_err": err, "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(),
+            "overlap": bool(eng.overlap) and not eng.one_call_step(), "one_call_step": eng.one_call_step(), "roofline": roof}
 
 
-def leg_c5(args, comm, device, steps, warm, p2p):
+def leg_c5(args, comm, device, steps, warm, make_comm):
     """BASELINE config C5 (3-D laser-target, `example/laser-target-3d.py:26-60`): 512 x 256 x 256 cells, e- + p at 8 ppc
     each for x > 1 um, CPML on six faces, GaussianLaser3D a0 = 10 -- as N slabs of (512 / N) x 256 x 256 through the
     Simulation3D stage loop, the J / rho guard planes travelling behind the interior tiles (overlap on)"""
@@ -607,7 +613,7 @@ def leg_c5(args, comm, device, steps, warm, p2p):
     if nxl * comm.size != nx or nxl % 32:
         return {"workload": "C5", "value": None, "error": f"512 cells do not split into {comm.size} slabs of 32-cell patches"}
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C_LIGHT / LAMBDA0) ** 2 / constants.E_CHARGE ** 2
-    chain = SlabComm(None, periodic=False, p2p_group=p2p)
+    chain = make_comm(periodic=False)
     sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=nxl // 32, npatch_y=ny // 64, npatch_z=nz // 64, random_seed=1,
                        sort_interval=10, comm=chain, device=str(device))
     dens = lambda x, y, z: np.where(x > 1e-6, nc, 0.0)
@@ -633,10 +639,90 @@ def leg_c5(args, comm, device, steps, warm, p2p):
                         f"x-slabs of {nxl}x256x256 (Simulation3D stage loop)",
             "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_3d(eng)[2]), "charge_rel_err": err,
-            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap), "roofline": roof}
+            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap) and not eng.one_call_step(),
+            "one_call_step": eng.one_call_step(), "roofline": roof}
+
+
+class Watchdog:
+    """bounded waits for the multi-rank run: a collective (or a first contact with RCCL) that hangs cannot be cancelled from
+    inside the process, so when a section overruns its budget every rank that notices says so on stderr, rank 0 prints the
+    JSON line it has so far (the headline survives a hanging leg; the leg is reported as {"error": "timeout"}) and the
+    process exits non-zero -- the launcher then takes the other ranks down.  Never a re-exec."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.deadline, self.label, self.partial = rank, None, "", None
+        self._lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, label, seconds):
+        with self._lock:
+            self.label, self.deadline = label, time.monotonic() + seconds
+
+    def disarm(self):
+        with self._lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                label = self.label
+            if late:
+                print(f"[bench] rank {self.rank}: '{label}' exceeded its time budget -- giving up", file=sys.stderr, flush=True)
+                if self.rank == 0 and self.partial is not None:
+                    out = dict(self.partial)
+                    out.setdefault("extra", []).append({"workload": label, "value": None, "error": "timeout"})
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
+
+
+def preflight_native():
+    """child process of one rank (``bench.py --preflight``): can the library's own RCCL transport serve this job?  Creates the
+    communicator and runs one ring exchange, nothing else; the parent waits with a timeout, so a first contact that hangs
+    costs a fallback, not the run.  Exit code 0 = yes."""
+    import torch.distributed as dist
+    from lambdapic_amd.dist import SlabComm
+    local_rank = 0 if os.environ.get("LPA_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    dist.init_process_group("gloo")
+    comm = SlabComm(None).attach_rccl()
+    t = [torch.full((1024,), float(comm.rank), dtype=torch.float64, device=device) for _ in range(4)]
+    for _ in range(3):
+        comm.exchange(t[0], t[1], t[2], t[3])
+    torch.cuda.synchronize(device)
+    ok = t[2][0].item() == comm.left and t[3][0].item() == comm.right
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 5)
+
+
+def native_preflight_ok(timeout=150):
+    """run ``preflight_native`` in a child of THIS rank, on a rendezvous of its own (MASTER_PORT + 1); True when it exited 0
+    in time.  Called before this process touches the GPU."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--preflight"], env=env, timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            tail = r.stderr.decode(errors="replace").strip().splitlines()[-3:]
+            print(f"[bench] rank {os.environ.get('RANK')}: native RCCL pre-flight failed (exit {r.returncode}): {' | '.join(tail)}",
+                  file=sys.stderr, flush=True)
+        return r.returncode == 0
+    except subprocess.TimeoutExpired:
+        print(f"[bench] rank {os.environ.get('RANK')}: native RCCL pre-flight timed out", file=sys.stderr, flush=True)
+        return False
 
 
 def main():
+    if "--preflight" in sys.argv:
+        preflight_native()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -658,6 +744,13 @@ def main():
                     help="gloo = rehearsal of the multi-rank path with ranks sharing GPUs (buffers staged "
                          "through the host); the driver's runs use nccl (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--transport", default="auto", choices=["auto", "native", "torch"],
+                    help="N > 1 with --backend nccl: 'native' = the library's own RCCL communicator (whole steps, exchanges "
+                         "included, in one lpa_step call); 'torch' = torch.distributed's nccl group, faces moved from Python "
+                         "between lpa_step sub-ranges; 'auto' = native when its pre-flight (a child process, bounded wait) "
+                         "succeeds on every rank, else torch, else host-staged gloo")
+    ap.add_argument("--stall-rank", type=int, default=-1, help="rehearsal of the watchdog: this rank stops inside the C4 leg")
+    ap.add_argument("--leg-timeout", type=float, default=420.0, help="time budget of one N > 1 leg in seconds")
     ap.add_argument("--no-defer", action="store_true", help="A/B: deposit cell-crossers' tail cells inline")
     ap.add_argument("--order", default="striped", choices=["striped", "padded"],
                     help="padded = LPA_ORDER_PADDED store + cooperative deposit")
@@ -688,17 +781,33 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: lambdapic_amd has no CPU path")
+    # first contact with the library's own RCCL transport happens in a CHILD process with a bounded wait, before this
+    # process touches the GPU: a hang there costs the fallback, not the run
+    native_ok = False
+    if world > 1 and args.backend == "nccl" and args.transport in ("auto", "native"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_gpu:
+            os.environ["LPA_BENCH_SHARE_GPU"] = "1"       # (rehearsal: RCCL refuses two ranks on one GPU -> the fallback runs)
+        native_ok = native_preflight_ok()
     device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    p2p, comm_note = None, "single rank"
+    rank = int(os.environ.get("RANK", "0"))
+    dog = Watchdog(rank)
+    p2p, comm_note, native = None, "single rank", False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane (barrier, max of the elapsed time) on gloo; the halo / migration messages of the
-        # step travel device-to-device on an RCCL group.  A pre-flight ring exchange checks that group; if
-        # RCCL cannot serve it the faces are staged through the host on gloo instead and the line says so.
+        # control plane (barrier, max of the elapsed time) on gloo; the halo / migration messages of the step travel
+        # device-to-device: through the library's own RCCL communicator (native), else through torch's nccl group, else
+        # staged through the host on gloo -- the line says which
+        dog.arm("process group", 300)
         dist.init_process_group("gloo")
+        flag = torch.tensor([1 if native_ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native = int(flag.item()) == 1
         comm_note = "gloo (host-staged faces)"
-        if args.backend == "nccl":
+        if native:
+            comm_note = "native rccl (lpa_comm: ncclSend / ncclRecv groups inside lpa_step), gloo control"
+        elif args.backend == "nccl" and args.transport != "native":
             ok = 1
             try:
                 import datetime
@@ -721,10 +830,23 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                comm_note = "rccl p2p (batch_isend_irecv), gloo control"
+                comm_note = "rccl p2p (torch batch_isend_irecv between lpa_step sub-ranges), gloo control"
             else:
                 p2p = None
-    comm = SlabComm(None, p2p_group=p2p)
+        dog.disarm()
+
+    def make_comm(periodic=True):
+        """the communicator of one engine: ring (periodic) or chain; with the native transport every communicator is an RCCL
+        communicator of its own (rank 0 makes the id, gloo broadcasts it)"""
+        c = SlabComm(None, periodic=periodic, p2p_group=p2p)
+        if native and c.size > 1:
+            c.attach_rccl()
+        return c
+
+    dog.arm("communicator", 300)
+    comm = make_comm()
+    dog.disarm()
+    rccl_version = comm.native_info()[5] if comm.native is not None else None
     assert comm.size == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     if args.order == "padded" or args.reseat:
@@ -738,6 +860,7 @@ def main():
     eng.reseat = args.reseat
     eng.rho_continuity = args.rho == "continuity"
     eng.lazy_inv_gamma = args.inv_gamma == "recomputed"
+    dog.arm("headline (weak-scaled C2)", 600)
     for _ in range(args.warmup):
         eng.step(dt)
     # timed region: EXACTLY --steps steps between barrier + synchronize on both sides
@@ -781,7 +904,7 @@ def main():
                                f"+guards, tile sort every {args.sort_interval} steps",
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
-                   "comm": comm_note,
+                   "comm": comm_note, "world": world, "rccl_version": rccl_version,
                    "e_guards": "once per step (engine.run_steps: the guard stage after E2 is the next step's after E1)"
                                if run_steps else "after both E half steps",
                    "part_eb_writeback": False,
@@ -803,6 +926,11 @@ def main():
                      "counted_traffic_over_plain_stream_6070GBps":
                          (traffic / (k_ms * 1e-3) / 1e9 / 6070.0) if (traffic and ev) else None},
     }
+    dog.disarm()
+    if comm.rank == 0 and comm.size > 1:
+        # the headline, at once: a leg that hangs below cannot take it along (the full line follows at the end)
+        print(json.dumps(out), flush=True)
+        dog.partial = out
     if comm.size > 1 and not args.no_extra:
         # the configs BASELINE.json defines on several GPUs are FIXED-size problems: C2's 1024^2 box (north_star quotes
         # ">= 6x at 8 GPUs" on it), C4 (4096 x 512 LWFA with window) and C5 (512 x 256 x 256 laser-target) cut into N
@@ -813,17 +941,21 @@ def main():
         legs = []
         want = set(args.legs.split(","))
         todo = [("c2s", lambda: leg_c2_strong(args, comm, device, args.leg_steps or 200, 10)),
-                ("c4", lambda: leg_c4(args, comm, device, args.leg_steps or 200, 40, p2p)),
-                ("c5", lambda: leg_c5(args, comm, device, args.leg_steps or 20, 12, p2p))]
+                ("c4", lambda: leg_c4(args, comm, device, args.leg_steps or 200, 40, make_comm)),
+                ("c5", lambda: leg_c5(args, comm, device, args.leg_steps or 20, 12, make_comm))]
         for name, leg in todo:
             if name not in want:
                 continue
+            dog.arm(f"leg {name}", args.leg_timeout)       # (a stuck rank: rank 0 prints what it has and everybody exits != 0)
             try:
                 r = leg()
             except Exception as e:   # noqa: BLE001 -- reported; the other ranks run the same code and fail alike
                 r = {"workload": name, "value": None, "error": repr(e)}
+            dog.disarm()
             r.setdefault("comm", comm_note)
             legs.append(r)
+            if comm.rank == 0:
+                dog.partial = dict(out, extra=list(legs))
             torch.cuda.empty_cache()
         out["extra"] = legs
     if comm.rank == 0 and comm.size == 1 and not args.no_extra:
