@@ -247,6 +247,10 @@ int lpa_reset_j(const lpa_grid *g, void *stream);
 int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axes, int split_x, const double *jx_left_plane,
                        void *stream);
 int lpa_rho_absorbed(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity, void *stream);
+/* the same with the spill array of lpa_push_params.absorbed_spill: when count[0] exceeded `capacity` the array is
+ * subtracted from rho (and zeroed) as well -- nothing is lost, count[1] stays 0 */
+int lpa_rho_absorbed_spill(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity, double *spill,
+                           void *stream);
 
 /* ---- periodic guard handling inside one slab (replaces sync_guard_fields_2d and
  *      sync_currents_2d with a self-neighbour table, core/patch/sync_fields2d.c:150-255,43-148).
@@ -314,6 +318,11 @@ typedef struct {
     uint32_t *leaver_count;
     int64_t leaver_capacity;
     double leave_lo, leave_hi;
+    /* optional companion of `absorbed` (NULL = entries beyond absorbed_capacity are only counted): a device array shaped
+     * like rho into which the kernel adds, node by node, what an absorbed particle that found the list full had
+     * deposited -- lpa_rho_absorbed_spill takes it out of rho together with the listed entries, so the list cannot lose
+     * a particle however many are absorbed in one step */
+    double *absorbed_spill;
 } lpa_push_params;
 #define LPA_ABSORB_X 16
 /* LPA_PUSH_NO_RHO: the fused kernels deposit jx jy jz only.  Esirkepov's deposit satisfies the discrete continuity
@@ -680,6 +689,7 @@ typedef struct {
     uint32_t *absorbed_count;
     int64_t absorbed_capacity;
     const lpa_step_slab *slab;  /* NULL: single slab */
+    double *absorbed_spill;     /* see lpa_push_params.absorbed_spill (may be NULL) */
 } lpa_step_desc;
 
 /* LPA_STEP_DEFER_E2_GUARDS: LPA_STAGE_E2 leaves the E guard cells stale (no wrap, no exchange).  For a caller that runs

@@ -70,7 +70,7 @@ class lpa_push_params(C.Structure):
                 ("alo", C.c_double * 3), ("ahi", C.c_double * 3),
                 ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64),
                 ("leavers", C.c_void_p), ("leaver_count", C.c_void_p), ("leaver_capacity", C.c_int64),
-                ("leave_lo", C.c_double), ("leave_hi", C.c_double)]
+                ("leave_lo", C.c_double), ("leave_hi", C.c_double), ("absorbed_spill", C.c_void_p)]
 
 
 
@@ -108,7 +108,7 @@ class lpa_step_desc(C.Structure):
                 ("nspecies", C.c_int32), ("continuity", C.c_int32), ("fuse_species", C.c_int32), ("flags", C.c_int32),
                 ("species", C.POINTER(lpa_step_species)),
                 ("absorbed", C.c_void_p), ("absorbed_count", C.c_void_p), ("absorbed_capacity", C.c_int64),
-                ("slab", C.POINTER(lpa_step_slab))]
+                ("slab", C.POINTER(lpa_step_slab)), ("absorbed_spill", C.c_void_p)]
 
 
 LPA_COMM_RCCL, LPA_COMM_LOOPBACK = 1, 2
@@ -146,6 +146,7 @@ SIGNATURES = {
     "lpa_reset_j": (_i, [_G, _vp]),
     "lpa_rho_continuity": (_i, [_G, _d, _i, _i, _vp, _vp]),
     "lpa_rho_absorbed": (_i, [_G, _vp, _vp, _i64, _vp]),
+    "lpa_rho_absorbed_spill": (_i, [_G, _vp, _vp, _i64, _vp, _vp]),
     "lpa_guard_wrap": (_i, [_G, _i, _i, _vp]),
     "lpa_current_fold": (_i, [_G, _i, _vp]),
     "lpa_halo_pack_guard_src": (_i, [_G, _i, _i, _vp, _vp]),

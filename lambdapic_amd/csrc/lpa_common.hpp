@@ -48,7 +48,8 @@ int lpai_push_deposit_rest_3d(const lpa_grid *g, const lpa_particles *p, const l
                               const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
                               const int32_t *loose_limit, void *stream);
 // jx jy jz (and rho) including guards = 0 and up to 32 device words = 0, one launch (lpa_step: reset + per-step counters)
-int lpai_reset_step(const lpa_grid *g, int with_rho, uint32_t *const *words, int nwords, void *stream);
+// (`also`: one more array shaped like rho to zero, or NULL)
+int lpai_reset_step(const lpa_grid *g, int with_rho, double *also, uint32_t *const *words, int nwords, void *stream);
 // zero up to 32 device words in one launch (the per-step counters: overflow lists, message headers)
 int lpai_zero_words(uint32_t *const *words, int n, void *stream);
 // the current fold of a step in one launch: periodic fold along `axes` + (slab ranks) the J / rho guard planes received
@@ -158,6 +159,35 @@ __device__ __forceinline__ double rcp_nr(double a) {
     y = fma(y, e, y);
     e = fma(-a, y, 1.0);
     return fma(y, e, y);
+}
+
+// the TSC shape of a deposit end point (e0, e1, e2: cells from node 0) times `v`, added to `dst` (an array shaped like rho)
+// on the torus of the padded array: what an absorbed particle had deposited into rho (current_deposit.h:7-35, S1)
+__device__ __forceinline__ void spread_tsc(const GridV &g, double *dst, double e0, double e1, double e2, double v) {
+    const bool d3 = g.NZ > 1;
+    const double e[3] = {e0, e1, e2};
+    int i1[3];
+    double s[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        i1[a] = ifloor(e[a] + 0.5);
+        tsc3(i1[a] - e[a], s[a]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const long r = (long)torus(i1[0] - 1 + i + g.ng, g.NX) * g.NY;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const long rc = (r + torus(i1[1] - 1 + j + g.ng, g.NY)) * g.NZ;
+            if (!d3) {
+                atomicAdd(&dst[rc], v * s[0][i] * s[1][j]);
+                continue;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++)
+                atomicAdd(&dst[rc + torus(i1[2] - 1 + kk + g.ng, g.NZ)], v * s[0][i] * s[1][j] * s[2][kk]);
+        }
+    }
 }
 
 // a particle whose advanced position left the slab along x: its slot goes on the leaver list (lpa_push_params.leavers;

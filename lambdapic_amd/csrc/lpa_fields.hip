@@ -1097,7 +1097,7 @@ __global__ void __launch_bounds__(256) k_reset_step(double *a, long n, double *b
     if (blockIdx.x == 0 && (int)threadIdx.x < nw) *w.w[threadIdx.x] = 0u;
 }
 
-int lpai_reset_step(const lpa_grid *g, int with_rho, uint32_t *const *words, int nwords, void *stream) {
+int lpai_reset_step(const lpa_grid *g, int with_rho, double *also, uint32_t *const *words, int nwords, void *stream) {
     LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && nwords >= 0 && nwords <= 32, "lpai_reset_step: bad args");
     const long cnt = (long)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) * (g->nz > 1 ? (long)(g->nz + 2 * g->ng) : 1);
     Words32 w;
@@ -1105,12 +1105,16 @@ int lpai_reset_step(const lpa_grid *g, int with_rho, uint32_t *const *words, int
     const bool contiguous = g->jy == g->jx + cnt && g->jz == g->jy + cnt && (!with_rho || g->rho == g->jz + cnt);
     if (!contiguous) {      // separate allocations: the plain entry points, then the counters
         if (int e = with_rho ? lpa_reset_current(g, stream) : lpa_reset_j(g, stream)) return e;
+        if (also && hipMemsetAsync(also, 0, cnt * sizeof(double), (hipStream_t)stream) != hipSuccess) {
+            lpa_set_error("lpai_reset_step: memset failed");
+            return LPA_ERR_HIP;
+        }
         return nwords ? lpai_zero_words(words, nwords, stream) : LPA_OK;
     }
     const long n = (with_rho ? 4 : 3) * cnt;
     long nb = (n + 1023) / 1024;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_reset_step, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g->jx, n, (double *)nullptr, 0L, w,
+    hipLaunchKernelGGL(k_reset_step, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g->jx, n, also, also ? cnt : 0L, w,
                        nwords);
     LPA_CHECK_LAUNCH("lpai_reset_step");
     return LPA_OK;

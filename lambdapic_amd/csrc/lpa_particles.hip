@@ -32,6 +32,7 @@ struct PushK {
     double *absorbed;
     uint32_t *absorbed_count;
     long absorbed_cap;
+    double *absorbed_spill;
     // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
     uint32_t *leavers, *leaver_count;
     long leaver_cap;
@@ -42,11 +43,13 @@ struct PushK {
 #define LPA_K1_VARIANTS 0
 #endif
 
-__device__ __forceinline__ void report_absorbed_2d(const PushK &k, double o1x, double o1y, double cd) {
+__device__ __forceinline__ void report_absorbed_2d(const GridV &g, const PushK &k, double o1x, double o1y, double cd) {
     const uint32_t slot = atomicAdd(k.absorbed_count, 1u);
     if ((long)slot < k.absorbed_cap) {
         double *e = k.absorbed + 4 * (long)slot;
         e[0] = o1x; e[1] = o1y; e[2] = 0.0; e[3] = cd;
+    } else if (k.absorbed_spill) {      // the list is full: what the particle had deposited goes to the spill array, node by node
+        spread_tsc(g, k.absorbed_spill, o1x, o1y, 0.0, cd);
     }
 }
 
@@ -67,6 +70,7 @@ static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) 
     k.wrap = pp->wrap;
     k.flags = pp->flags;
     k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
+    k.absorbed_spill = pp->absorbed_spill;
     for (int a = 0; a < 3; a++) {
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];
         k.alo[a] = pp->alo[a]; k.ahi[a] = pp->ahi[a];
@@ -178,7 +182,7 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     deposit_global_2d<true>(g, x, y, ux, uy, uz, ig, w, k.q, k.dt, &k.dep, !(k.flags & LPA_PUSH_NO_RHO));
     const double xe = x, ye = y;
     if (finish_position_2d(x, y, k) && k.absorbed)     // deposit end point = r + v dt / 2, v = u c / gamma
-        report_absorbed_2d(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
+        report_absorbed_2d(g, k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
                            (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy), k.dep.c_rho * w);
     report_leaver(k, x, ip);
     p.x[ip] = x; p.y[ip] = y;
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             b0 = bx * RSJ + by;
             double xs = x, ys = y;
             if (finish_position_2d(xs, ys, k) && k.absorbed)    // rare: a particle reached an open face
-                report_absorbed_2d(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
+                report_absorbed_2d(g, k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                    k.dep.c_rho * w);
             report_leaver(k, xs, ip);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole

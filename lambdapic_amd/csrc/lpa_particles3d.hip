@@ -22,6 +22,7 @@ struct PushK3 {
     double *absorbed;
     uint32_t *absorbed_count;
     long absorbed_cap;
+    double *absorbed_spill;
     // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
     uint32_t *leavers, *leaver_count;
     long leaver_cap;
@@ -29,11 +30,13 @@ struct PushK3 {
 };
 
 // the deposit end point (cells from node 0) and charge density factor of a particle that was just absorbed
-__device__ __forceinline__ void report_absorbed(const PushK3 &k, double o1x, double o1y, double o1z, double cd) {
+__device__ __forceinline__ void report_absorbed(const GridV &g, const PushK3 &k, double o1x, double o1y, double o1z, double cd) {
     const uint32_t slot = atomicAdd(k.absorbed_count, 1u);
     if ((long)slot < k.absorbed_cap) {
         double *e = k.absorbed + 4 * (long)slot;
         e[0] = o1x; e[1] = o1y; e[2] = o1z; e[3] = cd;
+    } else if (k.absorbed_spill) {      // the list is full: see report_absorbed_2d
+        spread_tsc(g, k.absorbed_spill, o1x, o1y, o1z, cd);
     }
 }
 
@@ -267,7 +270,7 @@ __device__ __forceinline__ void update_global_3d(const GridV &g, const PartV &p,
     const double xe = x, ye = y, ze = z;
     if (finish_position_3d(x, y, z, k) && k.absorbed) {
         // deposit_global_3d: end point = r + v dt / 2 with v = u c / gamma
-        report_absorbed(k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
+        report_absorbed(g, k, (xe + ux * LPA_C * ig * 0.5 * k.dt - g.x0) * (1.0 / g.dx),
                         (ye + uy * LPA_C * ig * 0.5 * k.dt - g.y0) * (1.0 / g.dy),
                         (ze + uz * LPA_C * ig * 0.5 * k.dt - g.z0) * (1.0 / g.dz), (k.q / (g.dx * g.dy * g.dz)) * w);
     }
@@ -697,7 +700,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
         {
             double xs = x, ys = y, zs = z;
             if (finish_position_3d(xs, ys, zs, k) && k.absorbed)    // rare: a particle reached an open face
-                report_absorbed(k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
+                report_absorbed(g, k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                 (z + vz * 0.5 * k.dt - g.z0) * inv_dz, k.c_rho * w);
             report_leaver(k, xs, ip);
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
@@ -884,6 +887,7 @@ static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr
     k.wrap = pp->wrap;
     k.flags = pp->flags;
     k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
+    k.absorbed_spill = pp->absorbed_spill;
     k.leavers = pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
     k.leave_lo = pp->leave_lo; k.leave_hi = pp->leave_hi;
     for (int a = 0; a < 3; a++) {

@@ -85,53 +85,45 @@ extern "C" int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axe
 }
 
 // ---- the charge of absorbed particles leaves rho -----------------------------------------------------------------
+// listed entries: minus their TSC shape; entries that found the list full were spread into `spill` by the push kernels
+// (lpa_push_params.absorbed_spill): subtracted node by node and zeroed here
 __global__ void __launch_bounds__(256) k_rho_absorbed(GridV g, const double *__restrict__ list,
-                                                      const uint32_t *__restrict__ count, long capacity) {
-    const long n = min((long)count[0], capacity);
-    const bool d3 = g.NZ > 1;
+                                                      const uint32_t *__restrict__ count, long capacity, double *spill) {
+    const long total = count[0];
+    const long n = min(total, capacity);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const double *e = list + 4 * t;
-        const double cd = e[3];
-        int i1[3];
-        double s[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            i1[a] = ifloor(e[a] + 0.5);
-            tsc3(i1[a] - e[a], s[a]);     // the new shape S1 of the deposit (current_deposit.h:7-35)
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const long r = (long)torus(i1[0] - 1 + i + g.ng, g.NX) * g.NY;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const long rc = (r + torus(i1[1] - 1 + j + g.ng, g.NY)) * g.NZ;
-                if (!d3) {
-                    atomicAdd(&g.rho[rc], -(cd * s[0][i] * s[1][j]));
-                    continue;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++)
-                    atomicAdd(&g.rho[rc + torus(i1[2] - 1 + kk + g.ng, g.NZ)], -(cd * s[0][i] * s[1][j] * s[2][kk]));
-            }
+        spread_tsc(g, g.rho, e[0], e[1], e[2], -e[3]);
+    }
+    if (spill && total > capacity) {        // (uniform; rare: more absorptions in one step than the list holds)
+        const long cells = (long)g.NX * g.NY * g.NZ;
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x * blockDim.x) {
+            const double v = spill[c];
+            if (v != 0.0) { atomicAdd(&g.rho[c], -v); spill[c] = 0.0; }
         }
     }
 }
 
-__global__ void k_rho_absorbed_done(uint32_t *count, long capacity) {
+__global__ void k_rho_absorbed_done(uint32_t *count, long capacity, int spilled) {
     const uint32_t n = count[0];
-    if ((long)n > capacity) count[1] += (uint32_t)((long)n - capacity);
+    if (!spilled && (long)n > capacity) count[1] += (uint32_t)((long)n - capacity);
     count[0] = 0;
 }
 
-extern "C" int lpa_rho_absorbed(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity,
-                                void *stream) {
+extern "C" int lpa_rho_absorbed_spill(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity,
+                                      double *spill, void *stream) {
     const int dim = g && g->nz > 1 ? 3 : 2;
     LPA_REQUIRE(lpa_grid_ok(g, dim, 1) && list && count && capacity > 0, "lpa_rho_absorbed: bad args");
     // absorptions are rare (particles reaching an open face): a small fixed grid walks whatever the list holds
     hipLaunchKernelGGL(k_rho_absorbed, dim3(64), dim3(256), 0, (hipStream_t)stream, make_gridv(g, dim), list, count,
-                       (long)capacity);
+                       (long)capacity, spill);
     LPA_CHECK_LAUNCH("lpa_rho_absorbed");
-    hipLaunchKernelGGL(k_rho_absorbed_done, dim3(1), dim3(1), 0, (hipStream_t)stream, count, (long)capacity);
+    hipLaunchKernelGGL(k_rho_absorbed_done, dim3(1), dim3(1), 0, (hipStream_t)stream, count, (long)capacity, spill ? 1 : 0);
     LPA_CHECK_LAUNCH("lpa_rho_absorbed_done");
     return LPA_OK;
+}
+
+extern "C" int lpa_rho_absorbed(const lpa_grid *g, const double *list, uint32_t *count, int64_t capacity,
+                                void *stream) {
+    return lpa_rho_absorbed_spill(g, list, count, capacity, nullptr, stream);
 }

@@ -51,6 +51,7 @@ static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_spe
     pp.dt = d->dt;
     pp.flags = (sp->pp.flags & ~LPA_PUSH_NO_RHO) | (d->continuity ? LPA_PUSH_NO_RHO : 0);   // (LPA_PUSH_NO_IG: per species)
     pp.absorbed = d->absorbed; pp.absorbed_count = d->absorbed_count; pp.absorbed_capacity = d->absorbed_capacity;
+    pp.absorbed_spill = d->absorbed ? d->absorbed_spill : nullptr;
     return pp;
 }
 
@@ -262,11 +263,12 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             }
             int nw = ns;
             if (d->continuity) {
-                if (d->absorbed) e = lpa_rho_absorbed(g, d->absorbed, d->absorbed_count, d->absorbed_capacity, stream);
-                if (!e) e = lpai_reset_step(g, 0, w, nw, stream);
-            } else {
+                if (d->absorbed)
+                    e = lpa_rho_absorbed_spill(g, d->absorbed, d->absorbed_count, d->absorbed_capacity, d->absorbed_spill, stream);
+                if (!e) e = lpai_reset_step(g, 0, nullptr, w, nw, stream);
+            } else {        // a real deposit contains no absorbed particle: the list and the spill array start empty
                 if (d->absorbed_count) w[nw++] = d->absorbed_count;
-                e = lpai_reset_step(g, 1, w, nw, stream);
+                e = lpai_reset_step(g, 1, d->absorbed ? d->absorbed_spill : nullptr, w, nw, stream);
             }
             counters_zeroed = !e && ns > 0;
             break;

@@ -271,6 +271,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
     def _rho_last_jx_plane(self):
         return self.grid.view("jx")[self.ng + self.nx - 1]
 
+    def _rho_array(self):
+        return self.grid.view("rho")
+
     # ---- restart (RestartDump, `callback/restart.py:88-107`: the reference pickles the whole Simulation) ----
     _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed", "_jx_plane",
                   "_one", "_step_keep")

@@ -259,6 +259,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def _rho_last_jx_plane(self):
         return self.view("jx")[self.ng + self.n[0] - 1]
 
+    def _rho_array(self):
+        return self.view("rho")
+
     # ---- restart (RestartDump, `callback/restart.py:88-107`) ------------------------------------------------
     _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed",
                   "_jx_plane", "_one", "_step_keep")

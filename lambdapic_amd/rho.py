@@ -12,12 +12,11 @@ LDS array is what bounds those kernels).  Rules (VERDICT r2
   which a callback reads per-species rho between the species' deposits, and while the split pusher path deposits with
   the standalone kernel);
 * particles the kernels absorb at open faces are reported on the device (``lpa_push_params.absorbed``) in every step and
-  their charge leaves rho at the start of the next continuity step (``lpa_rho_absorbed``) -- exactly when the
-  reference's next deposit no longer contains them.  The list holds 1/32 of the particle slots (at least 65 536
-  entries); the step after a real deposit reads its fill level (one 8-byte read, the sort of that step synchronised the
-  host anyway) and deposits for real again when it did not suffice -- the first step of a run absorbs whatever was
-  loaded inside the layers, millions of particles at C5's size.  An overflow inside a run of continuity steps is
-  reported at the next sort (rho, not the fields, was off until that re-anchoring step) and the list grows;
+  their charge leaves rho at the start of the next continuity step (``lpa_rho_absorbed_spill``) -- exactly when the
+  reference's next deposit no longer contains them.  The list holds 1/32 of the particle slots (at least 65 536 entries);
+  a particle that finds it full -- the first step of a run absorbs whatever was loaded inside the layers, millions at C5's
+  size -- adds what it had deposited to a spill array shaped like rho instead (``absorbed_spill``), which is subtracted
+  with the list.  Nothing is lost whatever the burst, no host read, no vote between slabs;
 * between slabs the backward difference of jx at a slab's node 0 needs the left neighbour's folded jx at its last node:
   one plane per step travels to the right.
 
@@ -62,6 +61,9 @@ class RhoContinuityMixin:
     def _rho_last_jx_plane(self) -> torch.Tensor:
         raise NotImplementedError
 
+    def _rho_array(self) -> torch.Tensor:
+        raise NotImplementedError
+
     def _rho_particle_slots(self) -> int:
         raise NotImplementedError
 
@@ -75,34 +77,17 @@ class RhoContinuityMixin:
 
     def _absorbed_bufs(self):
         """device list of the particles the kernels absorbed in the current step: [capacity][4] doubles + uint32
-        {entries, entries lost}"""
-        want = max(self.ABSORBED_MIN_CAPACITY, self._rho_particle_slots() // 32)
+        {entries, (unused)}; ``_absorbed[3]`` = the spill array (what the entries beyond the capacity had deposited)"""
         if self._absorbed is None:
-            self._new_absorbed(want)
-        elif self._absorbed[2] < want and self._phase == "idle" and (self.comm.size == 1 or self._rho_sort_due()):
-            # (never swapped inside a step; on a slab chain only in the steps every rank re-deposits rho anyway)
-            self._new_absorbed(max(want, 2 * self._absorbed[2]))
-            self._anchor_pending = True      # the fresh list knows nothing of the last step's absorptions
-        return self._absorbed
+            cap = max(self.ABSORBED_MIN_CAPACITY, self._rho_particle_slots() // 32)
+            self._absorbed = (torch.zeros(4 * cap, dtype=torch.float64, device=self.device),
+                              torch.zeros(2, dtype=torch.int32, device=self.device), int(cap),
+                              torch.zeros_like(self._rho_array()))
+            self._anchor_pending = True      # (a fresh list knows nothing of the last step's absorptions)
+        return self._absorbed[:3]
 
-    def _new_absorbed(self, cap):
-        self._absorbed = (torch.zeros(4 * cap, dtype=torch.float64, device=self.device),
-                          torch.zeros(2, dtype=torch.int32, device=self.device), int(cap))
-
-    def _check_absorbed(self):
-        """(at a sort: the host is synchronised anyway) absorbed particles that did not fit the list kept their
-        charge in rho until this re-anchoring step"""
-        if self._absorbed is not None:
-            lost = int(self._absorbed[1][1].item())
-            if lost:
-                import warnings
-                cap = self._absorbed[2]
-                self.ABSORBED_MIN_CAPACITY = 4 * cap
-                self._new_absorbed(4 * cap)
-                self._anchor_pending = True
-                warnings.warn(f"{lost} absorbed particles exceeded the device list of {cap} per step: rho (not the "
-                              f"fields) missed their removal since the last sort; this step re-deposits rho and the "
-                              f"list grows to {4 * cap}", RuntimeWarning, stacklevel=3)
+    def _absorbed_spill(self):
+        return self._absorbed[3]
 
     def _absorbing_chain(self):
         """does ANY slab of the chain absorb particles?  (the same answer on every rank)"""
@@ -146,7 +131,6 @@ class RhoContinuityMixin:
         (``forced``: the store had no valid order -- first sort, upload, append, window shift)"""
         if self._phase == "idle" and (forced or not self._relaxed() or self._steps_since_anchor + 1 >= self.sort_interval):
             self._anchor_pending = True
-        self._check_absorbed()
 
     def _rho_forced_sort_due(self):
         """is a sort due that brings particles rho does not know (engines)"""
@@ -161,23 +145,15 @@ class RhoContinuityMixin:
             sort_anchor = self._rho_sort_due() if not self._relaxed() else \
                 (self._rho_forced_sort_due() or self._steps_since_anchor + 1 >= self.sort_interval)
             anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending or sort_anchor
-            if not anchor and self._prev_phase == "anchor" and self.absorb:
-                # the step after a real deposit: did its absorptions fit the list?  (at most once per sort interval)
-                anchor = int(self._absorbed[1][0].item()) > self._absorbed[2]
             self._anchor_pending = False
         else:
             # Slab chain: neighbouring slabs must be in the SAME phase -- a slab that re-deposits rho puts its share of
             # the face nodes into guard planes which the fold adds to a neighbour that carries that charge already.  So
-            # the decision uses only what every rank knows (the chain's clock: sort_due; forced re-sorts; the
-            # configuration), and what one rank alone knows -- its absorbed-particle list overflowed, its list was
-            # swapped -- is put to the vote in the one step per interval in which all ranks ask (the step after a real
-            # deposit); until then a local wish waits.
-            anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._rho_sort_due()
-            if not anchor and self._prev_phase == "anchor" and self._absorbing_chain():
-                over = self._absorbed is not None and int(self._absorbed[1][0].item()) > self._absorbed[2]
-                anchor = self.comm.any(over or self._anchor_pending)
-            if anchor:
-                self._anchor_pending = False
+            # the decision uses only what every rank knows: the chain's clock (sort_due), the sorts that ran in this step
+            # (``_rho_sorted``: on the common clock, or forced on every rank at once -- window shifts, appends and uploads
+            # are collective by contract) and the configuration
+            anchor = force_anchor or not enabled or self.rho_continuity_blocked or self._anchor_pending or self._rho_sort_due()
+            self._anchor_pending = False
         self._phase = self._prev_phase = "anchor" if anchor else "continuity"
         self._steps_since_anchor = 0 if anchor else self._steps_since_anchor + 1
         self.rho_steps[self._phase] += 1
@@ -192,12 +168,14 @@ class RhoContinuityMixin:
             check(self.L.lpa_reset_current(g, st), "lpa_reset_current")
             if self._absorbed is not None:
                 self._absorbed[1][:1].zero_()       # the real deposit does not contain them anyway
+                self._absorbed[3].zero_()
         else:
             if self.absorb:
-                lst, cnt, cap = self._absorbed
+                lst, cnt, cap, spill = self._absorbed
                 # the particles last step's kernels absorbed: their charge leaves rho now (it travels through this
                 # step's fold like any deposit)
-                check(self.L.lpa_rho_absorbed(g, lst.data_ptr(), cnt.data_ptr(), cap, st), "lpa_rho_absorbed")
+                check(self.L.lpa_rho_absorbed_spill(g, lst.data_ptr(), cnt.data_ptr(), cap, spill.data_ptr(), st),
+                      "lpa_rho_absorbed_spill")
             check(self.L.lpa_reset_j(g, st), "lpa_reset_j")
 
     def _push_flags(self, pp, dt, absorbing):
@@ -209,6 +187,7 @@ class RhoContinuityMixin:
             # absorbed particles are reported in every step: the next one may carry this step's rho over
             lst, cnt, cap = self._absorbed_bufs()
             pp.absorbed, pp.absorbed_count, pp.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
+            pp.absorbed_spill = self._absorbed_spill().data_ptr()
 
     def _end_of_fold(self):
         """bookkeeping at the end of a step's current fold (nothing is launched): the rho bracket closes and the chain

@@ -78,6 +78,7 @@ class FusedStepMixin:
         if self.absorb and self.rho_continuity and self._rho_available():
             lst, cnt, cap = self._absorbed_bufs()
             d.absorbed, d.absorbed_count, d.absorbed_capacity = lst.data_ptr(), cnt.data_ptr(), cap
+            d.absorbed_spill = self._absorbed_spill().data_ptr()
         push = first <= _lib.LPA_STAGE_PUSH <= last
         fold = first <= _lib.LPA_STAGE_FOLD <= last
         timed = self.kernel_events is not None and push

@@ -41,7 +41,7 @@ def test_struct_layout_matches_header():
     # field counts / sizes of the POD structs (x86-64 SysV, natural alignment)
     assert ctypes.sizeof(_lib.lpa_grid) == 4 * 4 + 6 * 8 + 10 * 8
     assert ctypes.sizeof(_lib.lpa_particles) == 8 + 8 * 8 + 6 * 8 + 8 + 8
-    assert ctypes.sizeof(_lib.lpa_push_params) == 3 * 8 + 8 + 12 * 8 + 3 * 8 + 5 * 8      # wrap + flags share 8 bytes
+    assert ctypes.sizeof(_lib.lpa_push_params) == 3 * 8 + 8 + 12 * 8 + 3 * 8 + 5 * 8 + 8      # wrap + flags share 8 bytes
     # 2 i32, i64, 2 i32, 5 pointers, 2 i32, 8 pointers, 5 pointers, 2 i32
     assert ctypes.sizeof(_lib.lpa_tiling) == 8 + 8 + 8 + 5 * 8 + 8 + 8 * 8 + 5 * 8 + 8
 

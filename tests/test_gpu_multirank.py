@@ -507,16 +507,11 @@ def _run_3d_open(rank, world, port, q, stress=False):
     u = rng.normal(size=(3, n)) * (0.5 if stress else 0.05)
     if stress:
         # a hot slab next to the x-min layer, all of it on rank 0 (rank 1 of 2 starts empty), and an absorbed-particle
-        # list of EIGHT entries: rank 0 overflows it in the step after every real deposit, rank 1 never does -- the
-        # chain has to decide together that the next step re-deposits rho (rho.py: comm.any), and the list's growth at
-        # the sorts must not take one rank out of phase
-        import warnings
-        warnings.simplefilter("ignore", RuntimeWarning)
+        # list of EIGHT entries: rank 0 overflows it step after step, rank 1 never does.  What does not fit the list goes to
+        # the spill array (lpa_push_params.absorbed_spill) and leaves rho with the listed entries: rho is exact in every
+        # step, the ranks need no vote, and the single slab and the chain may sort (and re-deposit) in different steps
         eng.ABSORBED_MIN_CAPACITY = 8
         eng._rho_particle_slots = lambda: 0
-        # (an undersized list is exact again from the next real deposit on, rho.py `_check_absorbed`: the single slab runs
-        # the chain's fixed sort clock here, so that both runs re-deposit in the same steps while the list grows)
-        eng.overflow_sort_fraction = 0
     ig = 1 / np.sqrt(1 + (u ** 2).sum(0))
     w = np.full(n, 3e27 * dx * dy * dz / ppc)
     lo, hi = (rank * nx - 0.5) * dx, ((rank + 1) * nx - 0.5) * dx
