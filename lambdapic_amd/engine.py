@@ -929,71 +929,90 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self.ahi[0] = self.x0_global + (self.nx * self.comm.size - 1) * self.dx + self.dx / 2
 
     def shift_window(self, ncells):
-        """move every slab ``ncells`` to the right: what relabelling the leftmost patch column to the
-        right end does (callback/utils.py:594-620,576-585).  Surviving cells keep their values (the
-        new low guard holds the cells that just left, like the reference's stale guard); on a slab
-        chain the columns (and y-layer psi rows) that leave through a low face travel to the left
-        neighbour, whose tail and high guard they become (a rotation of the neighbour ring
-        by one patch width); the last rank's new columns start from zero fields and zero psi.
-        Particles left of the new lower bound follow their columns; on rank 0 they are dropped."""
-        n, g = int(ncells), self.grid
+        """move every slab ``ncells`` to the right (``ncells`` < 0: to the left): what relabelling the leftmost
+        (rightmost) patch column to the other end does (callback/utils.py:594-620 / :622-648, :576-585).  Surviving
+        cells keep their values (the guard behind the window holds the cells that just left, like the reference's stale
+        guard); on a slab chain the columns (and y-layer psi rows) that leave through a slab's trailing face travel to
+        the neighbour behind it, whose leading columns and guard they become (a rotation of the neighbour ring
+        by one patch width); the leading rank's new columns start from zero fields and zero psi.  Particles behind the new
+        bound follow their columns; on the trailing rank they are dropped."""
+        fwd = ncells > 0
+        n, g = abs(int(ncells)), self.grid
         if not 0 < n <= g.nx - g.ng:
             raise _lib.LpaError("window shift must be between 1 and nx - n_guard cells")
-        keep = g.ng + g.nx - n
+        ng, nx, NX = g.ng, g.nx, g.nx + 2 * g.ng
+        keep = ng + nx - n
         ylayers = [l for l in self.pml.layers if l["axis"] == 1] if self.pml is not None else []
-        # ---- what leaves through the low face: interior columns [0, n + ng) and psi rows [0, n)
-        parts = [g.buf[:, g.ng:g.ng + n + g.ng].reshape(-1)]
+        one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+
+        def to_trailing(send, recv):
+            """``send`` to the slab behind me (left when the window moves right), ``recv`` from the one ahead"""
+            if self.comm.size > 1:
+                if fwd:
+                    self.comm.exchange(send, one(), one(), recv)
+                else:
+                    self.comm.exchange(one(), send, recv, one())
+
+        # ---- what leaves through the trailing face: n + ng interior columns next to it and n psi rows
+        cols = slice(ng, ng + n + ng) if fwd else slice(nx - n, nx + ng)
+        rows = slice(0, n) if fwd else slice(nx - n, nx)
+        parts = [g.buf[:, cols].reshape(-1)]
         for l in ylayers:
             nl = l["stop"] - l["start"]
             for k in ("psi_a", "psi_b"):
-                parts.append(l[k].view(self.nx, nl)[:n].reshape(-1))
+                parts.append(l[k].view(nx, nl)[rows].reshape(-1))
         send = torch.cat(parts)
-        recv = torch.zeros_like(send)          # stays zero on the last rank: fresh columns
-        if self.comm.size > 1:
-            one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
-            self.comm.exchange(send, one(), one(), recv)
-        nf = 10 * (n + g.ng) * g.NY
-        g.buf[:, :keep] = g.buf[:, n:n + keep].clone()
-        g.buf[:, keep:] = recv[:nf].view(10, n + g.ng, g.NY)
+        recv = torch.zeros_like(send)          # stays zero on the leading rank: fresh columns
+        to_trailing(send, recv)
+        nf = 10 * (n + ng) * g.NY
+        if fwd:
+            g.buf[:, :keep] = g.buf[:, n:n + keep].clone()
+            g.buf[:, keep:] = recv[:nf].view(10, n + ng, g.NY)
+        else:
+            g.buf[:, NX - keep:] = g.buf[:, NX - keep - n:NX - n].clone()
+            g.buf[:, :n + ng] = recv[:nf].view(10, n + ng, g.NY)
         off = nf
         for l in ylayers:
             nl = l["stop"] - l["start"]
             for k in ("psi_a", "psi_b"):
-                v = l[k].view(self.nx, nl)
-                v[: self.nx - n] = v[n:].clone()
-                v[self.nx - n:] = recv[off:off + n * nl].view(n, nl)
+                v = l[k].view(nx, nl)
+                if fwd:
+                    v[: nx - n] = v[n:].clone()
+                    v[nx - n:] = recv[off:off + n * nl].view(n, nl)
+                else:
+                    v[n:] = v[: nx - n].clone()
+                    v[:n] = recv[off:off + n * nl].view(n, nl)
                 off += n * nl
-        shift = n * self.dx
+        shift = (n if fwd else -n) * self.dx
         self.x0_global += shift
         self.x0 += shift
         g.x0 += shift
         g.c.x0 = g.x0
         self.alo[0] += shift
         self.ahi[0] += shift
-        # ---- particles that are now left of the slab
-        xlo = self.x0 - self.dx / 2
+        # ---- particles that are now behind the slab
+        xlo, xhi = self._owner_bounds_x()
+        from_ahead = self.comm.has_right if fwd else self.comm.has_left
         for sp in self.species:
             st = sp.cset
             x = st.arr("x")[: sp.n]
+            gone = (x < xlo) if fwd else (x > xhi)
             if self.comm.size == 1:
-                x[x < xlo] = float("nan")
+                x[gone] = float("nan")
                 continue
-            idx = (x < xlo).nonzero().squeeze(1)          # host sync: a window shift is a rare event
+            idx = gone.nonzero().squeeze(1)          # host sync: a window shift is a rare event
             cnt = torch.tensor([float(idx.numel())], dtype=torch.float64, device=self.device)
             got = torch.zeros_like(cnt)
-            self.comm.exchange(cnt, torch.zeros_like(cnt), torch.zeros_like(cnt), got)
-            rows = len(st.core) + 1                       # core attributes + id (bit pattern); the next push rewrites ex_part ...
-            out = torch.empty((rows, idx.numel()), dtype=torch.float64, device=self.device)
+            to_trailing(cnt, got)
+            rows_ = len(st.core) + 1                      # core attributes + id (bit pattern); the next push rewrites ex_part ...
+            out = torch.empty((rows_, idx.numel()), dtype=torch.float64, device=self.device)
             out[:-1] = st.data[:, idx]
             out[-1] = st.id[idx].view(torch.float64)
             x[idx] = float("nan")
-            k = int(got.item()) if self.comm.has_right else 0
-            inc = torch.empty((rows, k), dtype=torch.float64, device=self.device)
-            dummy = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
+            k = int(got.item()) if from_ahead else 0
+            inc = torch.empty((rows_, k), dtype=torch.float64, device=self.device)
             # zero-length messages are legal but pointless: pad to one column
-            s_ = out.reshape(-1) if out.numel() else dummy()
-            r_ = inc.reshape(-1) if inc.numel() else dummy()
-            self.comm.exchange(s_, dummy(), dummy(), r_)
+            to_trailing(out.reshape(-1) if out.numel() else one(), inc.reshape(-1) if inc.numel() else one())
             if k:
                 self._append_device(sp, inc[:-1], inc[-1].view(torch.int64))
         # the tiling (and the age every edge / leaver-column estimate is derived from) refers to the grid origin of

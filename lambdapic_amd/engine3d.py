@@ -784,61 +784,79 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self.ahi[0] = xg + (ntot - 1) * self.d[0] + self.d[0] / 2
 
     def shift_window(self, ncells):
-        """move every slab ``ncells`` to the right (see PicEngine2D.shift_window): field columns and the
-        psi rows of the y / z layers that leave through a low face travel to the left neighbour; the last
-        rank's new columns start from zero; particles left of the new lower bound follow or are dropped"""
-        n, ng, nx = int(ncells), self.ng, self.n[0]
+        """move every slab ``ncells`` to the right, or to the left when negative (see PicEngine2D.shift_window): field
+        columns and the psi rows of the y / z layers that leave through a slab's trailing face travel to the neighbour
+        behind it; the leading rank's new columns start from zero; particles behind the new bound follow or are dropped"""
+        fwd = ncells > 0
+        n, ng, nx = abs(int(ncells)), self.ng, self.n[0]
         if not 0 < n <= nx - ng:
             raise _lib.LpaError("window shift must be between 1 and nx - n_guard cells")
+        NX = nx + 2 * ng
         keep = ng + nx - n
         lay = [l for l in self.pml.layers if l["axis"] != 0] if self.pml is not None else []
+        one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
 
         def rows(l, k):          # psi array of a y / z layer as [nx][...]
             return l[k].view(nx, -1)
 
-        parts = [self.buf[:, ng:ng + n + ng].reshape(-1)]
+        def to_trailing(send, recv):
+            if self.comm.size > 1:
+                if fwd:
+                    self.comm.exchange(send, one(), one(), recv)
+                else:
+                    self.comm.exchange(one(), send, recv, one())
+
+        cols = slice(ng, ng + n + ng) if fwd else slice(nx - n, nx + ng)
+        prow = slice(0, n) if fwd else slice(nx - n, nx)
+        parts = [self.buf[:, cols].reshape(-1)]
         for l in lay:
             for k in ("psi_a", "psi_b"):
-                parts.append(rows(l, k)[:n].reshape(-1))
+                parts.append(rows(l, k)[prow].reshape(-1))
         send = torch.cat(parts)
         recv = torch.zeros_like(send)
-        if self.comm.size > 1:
-            one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
-            self.comm.exchange(send, one(), one(), recv)
+        to_trailing(send, recv)
         plane = self.N[1] * self.N[2]
         nf = 10 * (n + ng) * plane
-        self.buf[:, :keep] = self.buf[:, n:n + keep].clone()
-        self.buf[:, keep:] = recv[:nf].view(10, n + ng, self.N[1], self.N[2])
+        if fwd:
+            self.buf[:, :keep] = self.buf[:, n:n + keep].clone()
+            self.buf[:, keep:] = recv[:nf].view(10, n + ng, self.N[1], self.N[2])
+        else:
+            self.buf[:, NX - keep:] = self.buf[:, NX - keep - n:NX - n].clone()
+            self.buf[:, :n + ng] = recv[:nf].view(10, n + ng, self.N[1], self.N[2])
         off = nf
         for l in lay:
             for k in ("psi_a", "psi_b"):
                 v = rows(l, k)
                 w = v.shape[1]
-                v[: nx - n] = v[n:].clone()
-                v[nx - n:] = recv[off:off + n * w].view(n, w)
+                if fwd:
+                    v[: nx - n] = v[n:].clone()
+                    v[nx - n:] = recv[off:off + n * w].view(n, w)
+                else:
+                    v[n:] = v[: nx - n].clone()
+                    v[:n] = recv[off:off + n * w].view(n, w)
                 off += n * w
-        shift = n * self.d[0]
+        shift = (n if fwd else -n) * self.d[0]
         self.x0 += shift
         self.c.x0 = self.x0
         self.alo[0] += shift
         self.ahi[0] += shift
-        xlo = self.x0 - self.d[0] / 2
+        xlo, xhi = self._owner_bounds_x()
+        from_ahead = self.comm.has_right if fwd else self.comm.has_left
         for sp in self.species:
             x = sp["data"][0, : sp["n"]]
+            gone = (x < xlo) if fwd else (x > xhi)
             if self.comm.size == 1:
-                x[x < xlo] = float("nan")
+                x[gone] = float("nan")
                 continue
-            idx = (x < xlo).nonzero().squeeze(1)          # host sync: a window shift is a rare event
+            idx = gone.nonzero().squeeze(1)          # host sync: a window shift is a rare event
             cnt = torch.tensor([float(idx.numel())], dtype=torch.float64, device=self.device)
             got = torch.zeros_like(cnt)
-            self.comm.exchange(cnt, torch.zeros_like(cnt), torch.zeros_like(cnt), got)
+            to_trailing(cnt, got)
             out = sp["data"][:, idx].contiguous()
             x[idx] = float("nan")
-            k = int(got.item()) if self.comm.has_right else 0
+            k = int(got.item()) if from_ahead else 0
             inc = torch.empty((NROWS3, k), dtype=torch.float64, device=self.device)
-            dummy = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
-            self.comm.exchange(out.reshape(-1) if out.numel() else dummy(), dummy(), dummy(),
-                               inc.reshape(-1) if inc.numel() else dummy())
+            to_trailing(out.reshape(-1) if out.numel() else one(), inc.reshape(-1) if inc.numel() else one())
             if k:
                 self.append_device(self.species.index(sp), inc)
         # the tiling (and the age every edge / leaver-column estimate is derived from) refers to the grid origin of

@@ -407,7 +407,8 @@ class MovingWindow:
     ``start``; once ``sim.time >= start_time`` (default Lx / c) the x layers are removed and the
     window advances by ``velocity * dt`` per step; every time a whole patch width has accumulated
     the leftmost patch column is recycled to the right end (fields and psi zeroed, its particles
-    replaced by a fresh loading of the species' density profiles)."""
+    replaced by a fresh loading of the species' density profiles); a negative velocity moves the window
+    backwards -- the rightmost column is recycled to the left end (`callback/utils.py:570-573,622-648`)."""
     stage = "start"
     interval = 1
     device_native = True
@@ -432,13 +433,13 @@ class MovingWindow:
         self.total_shift += v * sim.dt
         self.patch_this_shift += v * sim.dt
         self.num_shifts += 1
-        if self.patch_this_shift <= -patch_Lx:
-            raise NotImplementedError("backward moving window")
-        if self.patch_this_shift < patch_Lx:
-            return
-        self.patch_this_shift -= patch_Lx
-        sim.shift_window_right(self.inject_particles and
-                               (self.stop_inject_time is None or sim.time < self.stop_inject_time))
+        inject = self.inject_particles and (self.stop_inject_time is None or sim.time < self.stop_inject_time)
+        if self.patch_this_shift >= patch_Lx:            # callback/utils.py:567-572
+            self.patch_this_shift -= patch_Lx
+            sim.shift_window_right(inject)
+        elif self.patch_this_shift <= -patch_Lx:         # a window moving backwards: the rightmost column is recycled
+            self.patch_this_shift += patch_Lx
+            sim.shift_window_left(inject)
 
 
 class Simulation:
@@ -545,21 +546,25 @@ class Simulation:
         return None if self.random_seed is None else \
             [self.random_seed, s.ispec, int(round(x0 / self.dx)), int(round(y0 / self.dy))]
 
-    def shift_window_right(self, inject):
+    def shift_window_left(self, inject):
+        """recycle the rightmost patch column (`callback/utils.py:622-648`): the window moves one patch width to -x"""
+        self.shift_window_right(inject, direction=-1)
+
+    def shift_window_right(self, inject, direction=1):
         """recycle the leftmost patch column (`callback/utils.py:594-620`) on the device slab"""
         eng, n = self.engine, self.nx_per_patch
-        eng.shift_window(n)
+        eng.shift_window(direction * n)
         self.window_shifts = getattr(self, "window_shifts", 0) + 1
         for p in self.patches:              # the mirrors follow the window
-            p.x0 += n * self.dx
+            p.x0 += direction * n * self.dx
             p.fields.x0 = p.x0
-            p.fields.xaxis += n * self.dx
-            p.xaxis = p.xaxis + n * self.dx
-        self.patches._m.xmin_global += n * self.dx
-        self.patches._m.xmax_global += n * self.dx
-        if not inject or self.comm.rank != self.comm.size - 1:
-            return                      # only the last slab's tail is new ground
-        x_new = eng.x0 + (eng.nx - n) * self.dx
+            p.fields.xaxis += direction * n * self.dx
+            p.xaxis = p.xaxis + direction * n * self.dx
+        self.patches._m.xmin_global += direction * n * self.dx
+        self.patches._m.xmax_global += direction * n * self.dx
+        if not inject or self.comm.rank != (self.comm.size - 1 if direction > 0 else 0):
+            return                      # only the leading slab's new columns are new ground
+        x_new = eng.x0 + (eng.nx - n) * self.dx if direction > 0 else eng.x0
         for s in self.species:
             for j in range(self.npatch_y):
                 # same seed rule as initialize(): the loading of a column is a function of its origin,

@@ -192,20 +192,24 @@ class Simulation3D:
     def nz_per_patch(self):
         return self.n_per_patch[2]
 
-    def shift_window_right(self, inject):
+    def shift_window_left(self, inject):
+        """recycle the rightmost patch column (`callback/utils.py:622-648`): the window moves one patch width to -x"""
+        self.shift_window_right(inject, direction=-1)
+
+    def shift_window_right(self, inject, direction=1):
         """recycle the leftmost patch column (`callback/utils.py:594-620`, 3-D relabelling `:705-730`)"""
         eng, n = self.engine, self.n_per_patch[0]
-        eng.shift_window(n)
+        eng.shift_window(direction * n)
         self.window_shifts = getattr(self, "window_shifts", 0) + 1
         for p in self.patches:
-            p.x0 += n * self.dx
+            p.x0 += direction * n * self.dx
             p.fields.x0 = p.x0
-            p.fields.xaxis += n * self.dx
-        if not inject or self.comm.rank != self.comm.size - 1:
+            p.fields.xaxis += direction * n * self.dx
+        if not inject or self.comm.rank != (self.comm.size - 1 if direction > 0 else 0):
             return
         px, py, pz = self.npatch
         npp, d = self.n_per_patch, (self.dx, self.dy, self.dz)
-        x_new = eng.x0 + (eng.n[0] - n) * self.dx
+        x_new = eng.x0 + (eng.n[0] - n) * self.dx if direction > 0 else eng.x0
         for s in self.species:
             for k in range(pz):
                 for j in range(py):

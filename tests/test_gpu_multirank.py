@@ -271,7 +271,7 @@ def test_laser_target_chain_matches_single_rank():
 
 # ---- moving window on a slab chain: the columns that leave a slab's low face become the left
 # ---- neighbour's tail (rotation of the neighbour ring by one patch width) ----------------
-def _run_window(rank, world, port, q, inject=True):
+def _run_window(rank, world, port, q, inject=True, direction=1):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -288,12 +288,15 @@ def _run_window(rank, world, port, q, inject=True):
     sim = Simulation(nx, ny, dx, dy, npatch_x=8 // world, boundary_conditions=bc, cpml_thickness=6, comm=comm,
                      sort_interval=5, random_seed=5)
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
-    dens = lambda x, y: np.where((x > 150 * dx) & (abs(y - ny * dy / 2) < 20 * dy), 0.05 * nc, 0.0)
+    if direction > 0:
+        dens = lambda x, y: np.where((x > 150 * dx) & (abs(y - ny * dy / 2) < 20 * dy), 0.05 * nc, 0.0)
+    else:       # a window moving backwards: the plasma lies at and beyond the low-x end (injected at the shifts)
+        dens = lambda x, y: np.where((x < 60 * dx) & (abs(y - ny * dy / 2) < 20 * dy), 0.05 * nc, 0.0)
     sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=0.01))
     laser = SimpleLaser2D(a0=1.5, w0=1.2e-6, ctau=1.5e-6, l0=lam)
     # inject=False: the last rank gets neither arrivals nor fresh particles at a shift -- its tiling must still
     # be rebuilt for the moved origin (edge / leaver columns, tile margins)
-    mw = MovingWindow(velocity=C, start_time=0.6 * nx * dx / C, inject_particles=inject)
+    mw = MovingWindow(velocity=direction * C, start_time=(0.6 if direction > 0 else 0.2) * nx * dx / C, inject_particles=inject)
     trace = []
     for it in range(520):
         sim.run(1, callbacks=[laser, mw])
@@ -310,11 +313,11 @@ def _run_window(rank, world, port, q, inject=True):
         dist.destroy_process_group()
 
 
-def _launch_window(world, inject=True):
+def _launch_window(world, inject=True, direction=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_window, args=(r, world, port, q, inject)) for r in range(world)]
+    procs = [ctx.Process(target=_run_window, args=(r, world, port, q, inject, direction)) for r in range(world)]
     for p in procs:
         p.daemon = True
         p.start()
@@ -332,12 +335,13 @@ def _launch_window(world, inject=True):
     return trace, fields
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_moving_window_chain_matches_single_rank(world):
-    """(4 ranks: the two left slabs hold no particle until the window has moved the plasma into them)"""
-    t1, f1 = _launch_window(1)
-    t2, f2 = _launch_window(world)
-    assert f1["_x0"][0, 0] >= 4 * 32 and np.array_equal(f1["_x0"][0], f2["_x0"][0])   # both shifted alike
+@pytest.mark.parametrize("world,direction", [(2, 1), (4, 1), (2, -1)])
+def test_moving_window_chain_matches_single_rank(world, direction):
+    """(4 ranks: the two left slabs hold no particle until the window has moved the plasma into them; direction -1:
+    the backward window -- columns and particles travel to the RIGHT neighbour, rank 0 injects)"""
+    t1, f1 = _launch_window(1, direction=direction)
+    t2, f2 = _launch_window(world, direction=direction)
+    assert direction * f1["_x0"][0, 0] >= 4 * 32 and np.array_equal(f1["_x0"][0], f2["_x0"][0])   # both shifted alike
     assert t1[-1, 3] > 1000                                        # plasma was injected and kept
     assert np.array_equal(t2[:, 3], t1[:, 3])
     np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
@@ -585,7 +589,7 @@ def test_3d_laser_target_chain_matches_single_rank(stress):
 
 
 # ---- 3-D moving window on a slab chain -------------------------------------------------------------------
-def _run_window_3d(rank, world, port, q):
+def _run_window_3d(rank, world, port, q, direction=1):
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -602,11 +606,12 @@ def _run_window_3d(rank, world, port, q):
     sim = Simulation3D(nx, ny, nz, dx, dy, dz, npatch_x=6 // world, cpml_thickness=4, random_seed=4, sort_interval=4,
                        block_particles=1024, comm=comm)
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
-    dens = lambda x, y, z: np.where((x > 70 * dx) & (abs(y - sim.Ly / 2) < 4 * dy) & (abs(z - sim.Lz / 2) < 8 * dz),
+    along_x = (lambda x: x > 70 * dx) if direction > 0 else (lambda x: x < 30 * dx)     # (backwards: plasma at and beyond x-min)
+    dens = lambda x, y, z: np.where(along_x(x) & (abs(y - sim.Ly / 2) < 4 * dy) & (abs(z - sim.Lz / 2) < 8 * dz),
                                     0.05 * nc, 0.0)
     sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=2, momentum_sigma=0.01))
     laser = GaussianLaser3D(a0=1.5, l0=lam, w0=0.8e-6, ctau=0.5e-6, x0=1.2e-6)
-    mw = MovingWindow(velocity=C, start_time=0.7 * nx * dx / C)
+    mw = MovingWindow(velocity=direction * C, start_time=(0.7 if direction > 0 else 0.1) * nx * dx / C)
     trace = []
     for it in range(170):
         sim.run(1, callbacks=[laser, mw])
@@ -623,12 +628,13 @@ def _run_window_3d(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_moving_window_3d_chain_matches_single_rank():
+@pytest.mark.parametrize("direction", [1, -1])
+def test_moving_window_3d_chain_matches_single_rank(direction):
     def launch(world):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_run_window_3d, args=(r, world, port, q)) for r in range(world)]
+        procs = [ctx.Process(target=_run_window_3d, args=(r, world, port, q, direction)) for r in range(world)]
         for p in procs:
             p.daemon = True
             p.start()
@@ -645,7 +651,7 @@ def test_moving_window_3d_chain_matches_single_rank():
 
     t1, f1 = launch(1)
     t2, f2 = launch(2)
-    assert f1["_x0"][0, 0, 0] >= 3 * 16 and np.array_equal(f1["_x0"][0], f2["_x0"][0])
+    assert direction * f1["_x0"][0, 0, 0] >= 3 * 16 and np.array_equal(f1["_x0"][0], f2["_x0"][0])
     assert t1[-1, 3] > 200 and np.array_equal(t2[:, 3], t1[:, 3])
     np.testing.assert_allclose(t2[:, 0], t1[:, 0], rtol=1e-9)
     np.testing.assert_allclose(t2[:, 2], t1[:, 2], rtol=1e-9)

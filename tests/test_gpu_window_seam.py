@@ -38,25 +38,26 @@ BC = {"xmin": "pml", "xmax": "pml", "ymin": "periodic", "ymax": "periodic"}
 FIELDS = ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho")
 
 
-def _recycle_left_column(P, sim, species, id_next):
-    """callback/utils.py:594-620,653-690,748-800,576-585 on the host mirrors (see the module docstring)"""
+def _recycle_left_column(P, sim, species, id_next, direction=1):
+    """callback/utils.py:594-620 (``direction`` = -1: _shift_left, :622-648: the rightmost column moves to the left
+    end),653-690,748-800,576-585 on the host mirrors (see the module docstring)"""
     import torch  # noqa: F401
     from lambdapic_amd.simulation import load_block_device
     npx, Lx = sim.npatch_x, sim.npatch_x * sim.nx_per_patch * sim.dx
     new = []
     for p in P:
-        if p.ipatch_x == 0:
-            p.ipatch_x = npx - 1
-            p.x0 += Lx
-            p.xaxis = p.xaxis + Lx
+        if p.ipatch_x == (0 if direction > 0 else npx - 1):
+            p.ipatch_x = npx - 1 if direction > 0 else 0
+            p.x0 += direction * Lx
+            p.xaxis = p.xaxis + direction * Lx
             p.fields.x0 = p.x0
-            p.fields.xaxis = p.fields.xaxis + Lx
+            p.fields.xaxis = p.fields.xaxis + direction * Lx
             new.append(p)
         else:
-            p.ipatch_x -= 1
+            p.ipatch_x -= direction
     P.init_rect_neighbor_index_2d(npx, sim.npatch_y, boundary_conditions=BC)
-    P.xmin_global += sim.nx_per_patch * sim.dx
-    P.xmax_global += sim.nx_per_patch * sim.dx
+    P.xmin_global += direction * sim.nx_per_patch * sim.dx
+    P.xmax_global += direction * sim.nx_per_patch * sim.dx
     for p in new:
         for s in species:
             q = p.particles[s.ispec]
@@ -72,7 +73,8 @@ def _recycle_left_column(P, sim, species, id_next):
             getattr(p.fields, a).fill(0.0)
 
 
-def _pair(thermal, nsteps=150):
+def _pair(thermal, nsteps=150, direction=1):
+    """``direction`` = -1: everything mirrored along x -- the packet travels to -x and the window follows it backwards"""
     import torch
     from lambdapic_amd import constants
     from lambdapic_amd.simulation import MovingWindow, Simulation, Species
@@ -85,20 +87,26 @@ def _pair(thermal, nsteps=150):
     nc = constants.EPSILON_0 * constants.M_E * (2 * np.pi * C / lam) ** 2 / constants.E_CHARGE ** 2
     if thermal:
         dens, sigma = (lambda x, y: np.full(np.shape(x), 0.05 * nc)), 0.02
-    else:   # a cold slab the pulse runs through (its later columns are injected), vacuum ahead of it
+    elif direction > 0:   # a cold slab the pulse runs through (its later columns are injected), vacuum ahead of it
         dens, sigma = (lambda x, y: np.where((x > 40 * dx) & (x < 150 * dx), 0.05 * nc, 0.0)), 0.0
+    else:
+        dens, sigma = (lambda x, y: np.where((x < (nx - 41) * dx) & (x > (nx - 151) * dx), 0.05 * nc, 0.0)), 0.0
     sim.add_species(Species("e", charge=-1, mass=1, density=dens, ppc=4, momentum_sigma=sigma))
     sim.initialize()
     # a compact plane-wave packet travelling in +x (Ez, By = -Ez / c), uniform in y
     eng, ng = sim.engine, sim.n_guard
     xs = torch.arange(nx, dtype=torch.float64, device=eng.device)
-    env = torch.where((xs - 24).abs() < 16, torch.cos(np.pi * (xs - 24) / 32) ** 2, torch.zeros_like(xs))
+    x_c = 24 if direction > 0 else nx - 1 - 24
+    env = torch.where((xs - x_c).abs() < 16, torch.cos(np.pi * (xs - x_c) / 32) ** 2, torch.zeros_like(xs))
     E0 = 0.3 * constants.M_E * C * (2 * np.pi * C / lam) / constants.E_CHARGE
     ez = (E0 * env * torch.sin(2 * np.pi * xs / 16))[:, None].expand(nx, ny)
     eng.grid.view("ez")[ng:ng + nx, ng:ng + ny] = ez
-    eng.grid.view("by")[ng:ng + nx, ng:ng + ny] = -ez / C
+    # (By on the half nodes i + 1/2: a packet travelling to -x has By = +Ez / c, sampled half a cell further)
+    byv = -ez / C if direction > 0 else (E0 * torch.where((xs + 0.5 - x_c).abs() < 16, torch.cos(np.pi * (xs + 0.5 - x_c) / 32) ** 2,
+                                                           torch.zeros_like(xs)) * torch.sin(2 * np.pi * (xs + 0.5) / 16))[:, None].expand(nx, ny) / C
+    eng.grid.view("by")[ng:ng + nx, ng:ng + ny] = byv
     eng.sync_guard_fields(("ex", "ey", "ez", "bx", "by", "bz"))
-    win = MovingWindow(velocity=C, start_time=0.0)
+    win = MovingWindow(velocity=direction * C, start_time=0.0)
     sim.download()
     P = copy.deepcopy(sim.patches._m)             # the oracle's patches start as the device state's mirrors
     id_next = dict(sim._id_next)
@@ -112,17 +120,18 @@ def _pair(thermal, nsteps=150):
         # the device slab, through the product's callback and stage loop
         sim.run(1, callbacks=[win])
         # the patch recycling, stage "start" of the same step (callback/utils.py:540-585), then the stage loop
-        acc += C * sim.dt
-        if acc >= patch_Lx:
-            acc -= patch_Lx
-            last = [p for p in P if p.ipatch_x == npx - 1][0]
-            # B at the seam at the moment of the shift: what the recycled patch's first E half step does not see
+        acc += direction * C * sim.dt
+        if (acc >= patch_Lx) if direction > 0 else (acc <= -patch_Lx):     # callback/utils.py:567-572
+            acc -= direction * patch_Lx
+            last = [p for p in P if p.ipatch_x == (npx - 1 if direction > 0 else 0)][0]
+            # the field at the seam at the moment of the shift: what the recycled patch's first half step does not see
             # (wrapped guard layout, core/fields.py:24-27: the interior is [0, n))
-            edge.append(np.stack([getattr(last.fields, a)[last.nx - 1, :last.ny] for a in ("by", "bz")]))
-            _recycle_left_column(P, sim, species, id_next)
+            edge.append(np.stack([getattr(last.fields, a)[last.nx - 1 if direction > 0 else 0, :last.ny]
+                                  for a in (("by", "bz") if direction > 0 else ("ey", "ez"))]))
+            _recycle_left_column(P, sim, species, id_next, direction)
             shifts += 1
         driver.step(P, ks, sim.dt, qm, do_sort=(it % 4 == 0))
-    assert shifts == sim.window_shifts and shifts >= 5
+    assert shifts == sim.window_shifts and shifts >= (5 if direction > 0 else 4)
     sim.download()
     by_x = sorted(P, key=lambda p: p.ipatch_x)
     return sim, by_x, np.stack(edge), E0
@@ -132,14 +141,17 @@ def _stack(patches, a):
     return np.concatenate([getattr(p.fields, a)[:p.nx, :p.ny] for p in patches], axis=0)
 
 
-def test_window_recycling_matches_patch_restatement_when_the_edge_is_quiet():
-    sim, ref, edge, E0 = _pair(thermal=False)
-    assert np.abs(edge).max() <= 1e-12 * E0 / C                 # nothing has reached the leading edge
+@pytest.mark.parametrize("direction", [1, -1])
+def test_window_recycling_matches_patch_restatement_when_the_edge_is_quiet(direction):
+    """direction -1: the backward window (callback/utils.py:570-573,622-648) against the same restatement, mirrored"""
+    sim, ref, edge, E0 = _pair(thermal=False, direction=direction, nsteps=150 if direction > 0 else 170)
+    assert np.abs(edge).max() <= 1e-12 * E0 / (C if direction > 0 else 1.0)     # nothing has reached the leading edge
     dev = sorted(sim.patches._m, key=lambda p: p.x0)
-    assert [p.x0 for p in dev] == pytest.approx([p.x0 for p in ref], rel=1e-13)
+    assert [p.x0 for p in dev] == pytest.approx([p.x0 for p in ref], rel=1e-13, abs=1e-20)
     margin = 4        # columns next to the open trailing edge (no neighbour, stale guard) are not compared
+    cut = (lambda v: v[margin:]) if direction > 0 else (lambda v: v[:-margin])
     for a in FIELDS:
-        d, r = _stack(dev, a)[margin:], _stack(ref, a)[margin:]
+        d, r = cut(_stack(dev, a)), cut(_stack(ref, a))
         scale = np.abs(r).max()
         if a in ("ez", "by", "jz", "rho"):
             assert scale > 0, a
