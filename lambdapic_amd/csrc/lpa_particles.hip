@@ -447,7 +447,6 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     __syncthreads();
 
     const double inv_dx = 1.0 / g.dx, inv_dy = 1.0 / g.dy;
-    [[maybe_unused]] double abl = 0.0;  // only used by the LPA_ABLATE_* diagnostic builds
     // wave-uniform trip count: every lane of a wave runs the same iterations (the deposit below uses
     // wave-wide DPP / permlane operations)
     // software pipeline: the seven attribute loads of the NEXT iteration are issued before the current
@@ -492,9 +491,6 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             }
         }
         if (NOIG) ig = inv_gamma_of(ux, uy, uz);
-#ifdef LPA_ABLATE_PSTORE_SAME
-        const double x0_loaded = x, y0_loaded = y, u0_loaded[3] = {ux, uy, uz};
-#endif
         valid = valid && !(isnan(x) || isnan(y));  // NaN: killed since the last sort (migration)
         // first half push and the nearest node (ix1, iy1) of the mid-step position.  The LDS path is
         // valid iff that node lies within the tile + margin: the gather then reads nodes ix1-2..ix1+1
@@ -550,16 +546,10 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 tsc3(iy2 - yo + 0.5, hy);
                 // in range by the margin test (ix2 is ix1 or ix1 - 1)
                 int lx1 = ix1 - rx0, lx2 = ix2 - rx0, ly1 = iy1 - ry0, ly2 = iy2 - ry0;
-#ifdef LPA_ABLATE_NO_GATHER  // diagnostic build: keep the weights, drop the 54 LDS reads
-                eb[0] = hx[0] * gy[1] + lx2; eb[1] = gx[1] * hy[2] + ly2; eb[2] = gx[2] * gy[0] + lx1;
-                eb[3] = gx[0] * hy[1] + ly1; eb[4] = hx[1] * gy[2]; eb[5] = hx[2] * hy[0];
-                abl += eb[0];
-#else
                 gather9_pair_l(s_eb + EB_PAIR_B, lx2, ly1, hx, gy, eb[0], eb[4]);   // ex, by
                 gather9_pair_l(s_eb + EB_PAIR_A, lx1, ly2, gx, hy, eb[1], eb[3]);   // ey, bx
                 eb[2] = gather9_l(s_eb + EB_EZ, lx1, ly1, gx, gy);
                 eb[5] = gather9_l(s_eb + EB_BZ, lx2, ly2, hx, hy);
-#endif
             }
             if (WRITE_EB) {
 #pragma unroll
@@ -591,10 +581,6 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                         rl.cls[ip] = (uint16_t)ccls;
                     }
                     mover = cnow != ccls;
-#ifdef LPA_RL_NO_PARK     // diagnostic build: classes read and compared, nobody re-seated
-                    if (mover) abl += 1.0;
-                    mover = false;
-#endif
                 }
 #endif
                 tsc3(d1x, ax.S1);
@@ -621,23 +607,9 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             report_leaver(k, xs, ip);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
-            // diagnostic builds (wrong physics; profiles/r03_k1_streams.txt): what the attribute stores cost
-#if defined(LPA_ABLATE_NO_PSTORE)          // none at all
-            if (xs == 1.2345e300) { stp(p.x, o, xs); stp(p.y, o, ys); stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); }
-#elif defined(LPA_ABLATE_PSTORE_OOP)       // to the scratch arrays (out of place; LPA_ABLATE_PSTORE_OOP = 2: w with them)
-            stp(sc.a[0], o, xs); stp(sc.a[1], o, ys); stp(sc.a[2], o, ux); stp(sc.a[3], o, uy); stp(sc.a[4], o, uz);
-            if (!NOIG) stp(sc.a[5], o, ig);
-            if (LPA_ABLATE_PSTORE_OOP == 2) stp(sc.a[6], o, w);
-#elif defined(LPA_ABLATE_PSTORE_SAME)      // in place, values that do not move the particle (no drift between sorts)
-            stp(p.x, o, x0_loaded + 1e-300 * xs); stp(p.y, o, y0_loaded + 1e-300 * ys);
-            stp(p.ux, o, u0_loaded[0] + 1e-300 * ux); stp(p.uy, o, u0_loaded[1] + 1e-300 * uy);
-            stp(p.uz, o, u0_loaded[2] + 1e-300 * uz);
-            if (!NOIG) stp(p.ig, o, ig);
-#else
             stp(p.x, o, xs); stp(p.y, o, ys);
             stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz);
             if (!NOIG) stp(p.ig, o, ig);
-#endif
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -707,10 +679,8 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 if (DEFER && (cross || (RELOC && mover))) {
                     const int slot = atomicAdd(&s_ncross, 1);
                     const uint32_t o = (uint32_t)(begin - rb + slot) * 8u;
-#ifndef LPA_ABLATE_NO_PARK   // diagnostic build (wrong physics, with LPA_ABLATE_NO_PASS2): what the seven parking stores cost
                     st(sc.a[0], o, x); st(sc.a[1], o, y); st(sc.a[2], o, ux); st(sc.a[3], o, uy);
                     st(sc.a[4], o, uz); if (!NOIG) st(sc.a[5], o, ig); st(sc.a[6], o, w);
-#endif
                     if (RELOC) {
                         rl.aux_slot[begin + slot] = (uint32_t)ip;
                         rl.aux_info[begin + slot] = (ccls << 8) | (cnow << 16) | (cross ? RL_DEP : 0u) | (mover ? RL_MOV : 0u);
@@ -719,18 +689,12 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                 esirkepov_2d<true>(ax, ay, vz, w, k.q, g.dx, g.dy, k.dt,
                                    [&](int kk, int ll, double djx, double djy, double djz, double drho) {
                                        int o = b0 + kk * RSJ + ll;
-#ifdef LPA_ABLATE_NO_ATOMICS  // diagnostic build: keep the arithmetic, drop the LDS atomics
-                                       abl += djx + djy + djz + drho + o;
-#else
                                        // window row 3 / column 3 carry exact zeros unless the particle
                                        // changed cell along that axis: predicate on the crossing flags
                                        // (one exec-mask region per run of cells) instead of testing 64
                                        // values -- crossers are ~3 % of the lanes
                                        bool on = (kk < 3 || !ax.tail_zero) && (ll < 3 || !ay.tail_zero);
                                        if (DEFER) on = kk < 3 && ll < 3 && !cross;   // cell-crossers come later
-#ifdef LPA_ABLATE_NO_TAIL  // diagnostic build: drop window row 3 / column 3 (wrong for cell crossers)
-                                       on = kk < 3 && ll < 3;
-#endif
                                        // the running sum of jx over the 3 window rows of a particle that
                                        // stayed in its x-cell is (sum of DS) * b = 0 up to rounding (the
                                        // reference adds that 1e-16-relative residue): row 2 of jx and column
@@ -744,7 +708,6 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
                                            atomicAdd(&s_j[2][o], djz);
                                            if (RHO) atomicAdd(&s_j[NJ - 1][o], drho);
                                        }
-#endif
                                    }, &k.dep);
             }
             continue;
@@ -813,11 +776,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
         [[maybe_unused]] unsigned long long mid = 0;
         [[maybe_unused]] bool mvac = false;
         [[maybe_unused]] int mcls = 0, mh = -1;
-#ifdef LPA_ABLATE_NO_PASS2   // diagnostic build (wrong physics): what the second pass costs
-        for (int i = threadIdx.x; i < 0; i += blockDim.x) {
-#else
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
-#endif
             uint32_t info = RL_DEP;
             if (RELOC) info = rl.aux_info[begin + i];
             const bool first = RELOC && i == (int)threadIdx.x;
@@ -826,11 +785,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), ux = ld(sc.a[2], o), uy = ld(sc.a[3], o),
                          uz = ld(sc.a[4], o), ig = NOIG ? inv_gamma_of(ux, uy, uz) : ld(sc.a[5], o), w = ld(sc.a[6], o);
 #if LPA_K1_VARIANTS
-#ifdef LPA_RL_NO_PHASES   // diagnostic build: movers are parked but stay where they are
-            if (false) {
-#else
             if (first && (info & RL_MOV)) {
-#endif
                 // phase A: the mover's slot joins the pool of its class (it only leaves if the pool has room)
                 const int c = (int)((info >> 8) & 31u);
                 const int pos = atomicAdd(&s_stk_cnt[c], 1);
@@ -916,9 +871,6 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
 #endif
     }
     __syncthreads();
-#if defined(LPA_ABLATE_NO_ATOMICS) || defined(LPA_ABLATE_NO_GATHER) || defined(LPA_RL_NO_PARK)
-    if (abl == 1.2345e-300) s_j[0][0] = abl;  // keeps the ablated arithmetic alive
-#endif
 
     // ---- flush the J tile: one FP64 global atomic per touched cell and component.  Consecutive
     //      threads walk consecutive y -> each wave instruction covers contiguous 8-B segments of a row

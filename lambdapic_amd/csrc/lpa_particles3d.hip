@@ -386,18 +386,6 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
                                              double ddz) {
     double fx[3], fy[3], fz[3];
     tsc3(ddx, fx); tsc3(ddy, fy); tsc3(ddz, fz);
-#ifdef LPA_ABLATE3_NO_GATHER   // diagnostic build (wrong physics): the 27 FMAs stay, the 27 LDS reads go
-    const double c0 = 1e-3 * (lx + ly + lz);
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double pl = 0.0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) pl += fy[j] * (fx[0] * c0 + fx[1] * (c0 + j) + fx[2] * (c0 + k));
-        acc += fz[k] * pl;
-    }
-    return acc;
-#else
     lds_ptr3 c = (lds_ptr3)(f + lx * EBSX + ly * EBSY + lz);
     // the 3-D loop runs at 3 waves per SIMD: the reads of a batch are issued back to back and the arithmetic waits on
     // them with counted lgkmcnt (LDS returns in order).  Left to itself the scheduler, short of registers, issued 1-2
@@ -438,7 +426,6 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
     }
 #endif
     return acc;
-#endif
 }
 
 // DEFER (as in the 2-D kernel): particles that change cell during the step park their advanced state (8
@@ -539,7 +526,6 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
     const int lane = threadIdx.x & 63;
     int &s_ncross = *s_ncross_p;
     const double inv_dx = k.inv_d[0], inv_dy = k.inv_d[1], inv_dz = k.inv_d[2];
-    [[maybe_unused]] double abl3v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // LPA_ABLATE3_* diagnostic builds (independent chains)
     auto ld = [](const double *base, uint32_t off) { return *(const double *)((const char *)base + off); };
     auto st = [](double *base, uint32_t off, double v) { *(double *)((char *)base + off) = v; };
     // the particle attributes stream through once per step (0.5 MB per tile visit against a 4 MB L2 per XCD): with the
@@ -561,11 +547,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
             nuz = ldp(p.uz, o); nig = ldp(p.ig, o); nw = ldp(p.w, o);
         }
     }
-#ifdef LPA_ABLATE3_NO_LOOP   // diagnostic build (wrong physics): only the per-tile phases (zero, stage E/B, flush) run
-    for (int it = end; it < end; it += blockDim.x) {
-#else
     for (int it = begin + (int)(threadIdx.x & ~63u); it < end; it += blockDim.x) {
-#endif
         const int ip = it + lane;
         bool valid = ip < end;
         double x = nx_, y = ny_, z = nz_, ux = nux, uy = nuy, uz = nuz, ig = nig, w = nw;
@@ -726,29 +708,15 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
                 // crossed along x / y / z
                 bool on = (i < (LPA_SKIP_NULL_RUN ? 2 : 3) || !ax.tail_zero) && (j < 3 || !ay.tail_zero) &&
                           (kk < 3 || !az.tail_zero);
-#ifdef LPA_ABLATE_NO_TAIL
-                on = i < 3 && j < 3 && kk < 3;
-#endif
-#ifdef LPA_ABLATE3_NO_ATOMICS   // diagnostic build (wrong physics): the arithmetic stays, the LDS atomics go
-                if (on) abl3v[(i * 9 + j * 3 + kk) & 7] += djx + (b0 + (i * R3Y + j) * R3ZS + kk);
-#else
                 if (on) atomicAdd(&s_j[0][b0 + (i * R3Y + j) * R3ZS + kk], djx);
-#endif
             },
             [&](int i, int j, int kk, double djy, double djz, double dr) {
                 bool on = (i < 3 || !ax.tail_zero) && (j < 3 || !ay.tail_zero) && (kk < 3 || !az.tail_zero);
-#ifdef LPA_ABLATE_NO_TAIL
-                on = i < 3 && j < 3 && kk < 3;
-#endif
                 if (on) {
                     int o = b0 + (i * R3Y + j) * R3ZS + kk;
-#ifdef LPA_ABLATE3_NO_ATOMICS
-                    abl3v[(i * 9 + j * 3 + kk) & 7] += djy + djz + dr + o;
-#else
                     if (!LPA_SKIP_NULL_RUN || j < 2 || !ay.tail_zero) atomicAdd(&s_j[1][o], djy);
                     if (!LPA_SKIP_NULL_RUN || kk < 2 || !az.tail_zero) atomicAdd(&s_j[2][o], djz);
                     if (RHO) atomicAdd(&s_j[NJ - 1][o], dr);
-#endif
                 }
             });
     }
@@ -756,11 +724,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
         // ---- the particles that changed cell: the general 4 x 4 x 4 window, every lane busy
         __syncthreads();
         const int ncross = s_ncross;
-#ifdef LPA_ABLATE_NO_PASS2   // diagnostic build (wrong physics): what the second pass costs
-        for (int i = threadIdx.x; i < 0; i += blockDim.x) {
-#else
         for (int i = threadIdx.x; i < ncross; i += blockDim.x) {
-#endif
             const uint32_t o = (uint32_t)(begin - rb + i) * 8u;
             const double x = ld(sc.a[0], o), y = ld(sc.a[1], o), z = ld(sc.a[2], o), ux = ld(sc.a[3], o),
                          uy = ld(sc.a[4], o), uz = ld(sc.a[5], o), ig = ld(sc.a[6], o), w = ld(sc.a[7], o);
@@ -792,13 +756,6 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
                 });
         }
     }
-#ifdef LPA_ABLATE3_NO_ATOMICS
-    {
-        double abl3 = 0.0;
-        for (int q = 0; q < 8; q++) abl3 += abl3v[q];
-        if (abl3 == 1.2345e-300) s_j[0][0] = abl3;  // keeps the ablated arithmetic alive
-    }
-#endif
 }
 
 // One kernel, two work partitions.  Work blocks (blk_tile != nullptr; ONE species): a workgroup per (tile, particle

@@ -77,12 +77,22 @@ class _Lib:
 
     def __init__(self, path):
         self.dll = C.CDLL(path)
+        # libhdf5 >= 1.12 exports only the versioned H5Literate1 / H5Literate2 (the callback here ignores the info struct, so
+        # either serves) and deprecates H5Dvlen_reclaim in favour of H5Treclaim (same signature): take what the library has
+        alias = {"H5Dvlen_reclaim": ("H5Dvlen_reclaim", "H5Treclaim"), "H5Literate": ("H5Literate", "H5Literate2", "H5Literate1")}
+
+        def sym(name):
+            for cand in alias.get(name, (name,)):
+                if hasattr(self.dll, cand):
+                    return getattr(self.dll, cand)
+            raise AttributeError(f"{path}: none of {alias.get(name, (name,))} exported")
+
         for name, (res, args) in self._SIGS.items():
-            fn = getattr(self.dll, name)
+            fn = sym(name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)
         for name in ("H5Literate", "H5Aiterate2"):
-            fn = getattr(self.dll, name)
+            fn = sym(name)
             fn.restype = C.c_int
             fn.argtypes = [_hid, C.c_int, C.c_int, C.POINTER(_hsize), self._ITER, C.c_void_p]
             setattr(self, name, fn)

@@ -217,6 +217,12 @@ class SaveParticlesToHDF5(_Writer):
         self.prefix.mkdir(parents=True, exist_ok=True)
         self.attrs = None if attrs is None else [a for a in attrs if a != "id"]      # ('id' is always written)
 
+    @property
+    def reads_part_eb(self):
+        """does this writer store ex_part ... bz_part (every attribute, or one of them by name)?  The pushes that precede
+        it must then write the gathered fields back (Simulation.run: ``engine.write_part_eb``), as the reference's do"""
+        return self.attrs is None or any(a.endswith("_part") for a in self.attrs)
+
     def _call(self, sim):
         if self.attrs is None:
             self.attrs = store_attributes(sim, self.species)

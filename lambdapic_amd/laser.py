@@ -91,6 +91,9 @@ def _factorise(laser, sim, coords):
 def _inject(laser, sim, coords, key):
     """one '_laser' stage: the factorised form when the profile allows it, else the general one"""
     eng = sim.engine
+    # (the factorisation depends on every parameter of the beam: a laser mutated between two runs must not keep it)
+    key = key + tuple(sorted((k, v) for k, v in vars(laser).items() if isinstance(v, (int, float, bool, str, type(None)))
+                             and not k.startswith("_")))
     if getattr(laser, "_sep_key", None) != key:
         laser._sep, laser._sep_key = _factorise(laser, sim, coords), key
     if laser._sep is not None:

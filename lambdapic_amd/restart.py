@@ -35,6 +35,7 @@ from . import device as _device
 class RestartDump:
     DEFAULT_STAGE = "end"
     device_native = True            # reads the device state directly: no mirror refresh around it
+    reads_part_eb = True            # the dumped stores carry ex_part ... bz_part: the push before a dump writes them
 
     def __init__(self, out_dir, interval=1000, keep=None, dump_signals=False):
         self.stage, self.interval, self.keep = self.DEFAULT_STAGE, interval, keep

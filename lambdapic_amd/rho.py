@@ -193,7 +193,8 @@ class RhoContinuityMixin:
         """bookkeeping at the end of a step's current fold (nothing is launched): the rho bracket closes and the chain
         clock ticks -- every sort / phase decision of the step has seen the same clock"""
         phase, self._phase = self._phase, "idle"
-        self._tick_chain_clock()
+        if phase != "idle":           # (a second fold inside one step -- a density diagnostic between the species' deposits
+            self._tick_chain_clock()  # syncs the currents itself -- is not another step)
         return phase
 
     def _jx_plane_bufs(self):
@@ -215,7 +216,7 @@ class RhoContinuityMixin:
         # dt of the step: from this rank's pushes, or -- a rank that holds no particle (yet) still receives its
         # neighbours' guard-plane currents through the fold and has to advance rho with them -- from the step driver
         dt_step = self._dt_step if self._dt_step > 0.0 else (getattr(self, "_dt_hint", 0.0) if self.comm.size > 1 else 0.0)
-        exchange = self.comm.size > 1 and self.rho_continuity and self._rho_available()
+        exchange = self.comm.size > 1 and self.rho_continuity and self._rho_available() and phase != "idle"
         if exchange and self.defer_rho:
             self._rho_pending = (phase, dt_step)
             return

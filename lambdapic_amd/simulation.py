@@ -602,7 +602,25 @@ class Simulation:
 
     # ---- the stage loop (`simulation.py:937-1130`) ----------------------------------------------------
     def _triggered(self, cbs):
-        return [cb for cb in cbs if interval_triggered(self, getattr(cb, "interval", 1))]
+        """the callbacks of ``cbs`` that fire in this step.  An interval FUNCTION is asked once per step and callback (the
+        reference evaluates it once, at the callback's stage): the stage loop asks several times, a stateful predicate
+        must not see that"""
+        cache = self.__dict__.setdefault("_trig_cache", {})
+        if cache.get("step") != (self.itime, id(self)):
+            cache.clear()
+            cache["step"] = (self.itime, id(self))
+        out = []
+        for cb in cbs:
+            iv = getattr(cb, "interval", 1)
+            if callable(iv):
+                if id(cb) not in cache:
+                    cache[id(cb)] = bool(interval_triggered(self, iv))
+                hit = cache[id(cb)]
+            else:
+                hit = interval_triggered(self, iv)
+            if hit:
+                out.append(cb)
+        return out
 
     def _run_stage(self, table, stage):
         cbs = self._triggered(table.get(stage, []))
@@ -694,7 +712,10 @@ class Simulation:
                 (self.nsteps if self.nsteps is not None else int(self.sim_time / self.dt))
         # host callbacks may read ex_part..bz_part: the pushes that precede one write them (decided step by step below;
         # registering a diagnostic that runs every 100 steps must not cost six more attribute streams in every step)
-        host_cbs = [cb for cb in callbacks or [] if not getattr(cb, "device_native", False)]
+        # (+ the device-native writers that store the per-particle fields: SaveParticlesToHDF5 with every attribute,
+        # RestartDump)
+        host_cbs = [cb for cb in callbacks or [] if not getattr(cb, "device_native", False) or
+                    getattr(cb, "reads_part_eb", False)]
         self.engine.write_part_eb = bool(host_cbs)
         unified = not (self._PUSHER_STAGES & {s for s, c in table.items() if c})   # :896-911
         # rho between two sorts comes from the continuity equation (rho.py) unless the split path deposits with the

@@ -272,8 +272,7 @@ class Simulation3D:
             self._upload_particles(s.ispec)
 
     # ---- the stage loop --------------------------------------------------------------------------------------
-    def _triggered(self, cbs):
-        return [cb for cb in cbs if interval_triggered(self, getattr(cb, "interval", 1))]
+    _triggered = Simulation._triggered
 
     def _run_stage(self, table, stage):
         cbs = self._triggered(table.get(stage, []))

@@ -183,6 +183,38 @@ def test_particle_files_2d(tmp_path):
     assert np.array_equal(x[oo], d["x"][o]) and np.array_equal(w[oo], d["w"][o])
 
 
+def test_particle_file_carries_the_fields_the_last_push_gathered_2d(tmp_path):
+    """attrs=None writes every attribute, ex_part ... bz_part included (`callback/hdf5.py:660-663`): the push before the
+    writer must store them although the writer itself is device native -- the same numbers a host callback at the same
+    stage sees in the mirrors (which makes every push write them)"""
+    files = {}
+    for host in (False, True):
+        sim, e = _sim2()
+        seen = {}
+
+        def probe(s, seen=seen):                       # a host callback: forces the E/B write-back in every push
+            q = [p.particles[0] for p in s.patches]
+            seen["ex"] = np.concatenate([v.ex_part[~v.is_dead] for v in q])
+            seen["bz"] = np.concatenate([v.bz_part[~v.is_dead] for v in q])
+            seen["id"] = np.concatenate([v.id[~v.is_dead] for v in q])
+        probe.stage, probe.interval = "end", 10
+        out = tmp_path / ("host" if host else "native")
+        cbs = [SaveParticlesToHDF5(species=e, prefix=str(out), interval=10)] + ([probe] if host else [])
+        sim.run(11, callbacks=cbs)
+        with h5lite.File(out / "electrons_particles_000010.h5", "r") as f:
+            assert {"ex_part", "ey_part", "ez_part", "bx_part", "by_part", "bz_part"} <= set(f.keys())
+            o = np.argsort(f["id"][:])
+            files[host] = {a: f[a][:][o] for a in ("ex_part", "bz_part", "x")}
+        if host:
+            oo = np.argsort(seen["id"].view(np.uint64))
+            assert np.array_equal(files[True]["ex_part"], seen["ex"][oo]) and np.array_equal(files[True]["bz_part"], seen["bz"][oo])
+    assert np.abs(files[False]["ex_part"]).max() > 0                                   # not the zeros of a lazily allocated row
+    scale = np.abs(files[True]["ex_part"]).max()
+    # (two runs of the same problem: the order of the FP64 atomics differs, nothing else)
+    assert np.abs(files[False]["ex_part"] - files[True]["ex_part"]).max() <= 1e-9 * scale
+    assert np.abs(files[False]["bz_part"] - files[True]["bz_part"]).max() <= 1e-9 * np.abs(files[True]["bz_part"]).max()
+
+
 def test_particle_files_default_attributes_3d_and_dead_particles(tmp_path):
     """attrs=None = everything the store holds (`callback/hdf5.py:660-663`); dead slots are not written (`:686-691`)"""
     bc = dict(PERIODIC3, xmin="pml", xmax="pml")
