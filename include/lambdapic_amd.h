@@ -652,6 +652,10 @@ typedef struct {
     int64_t area_capacity;
     int32_t edge_cols;                  /* leaver scan: tile columns at each face (lpa_migrate_pack_edges_x), 0 = all slots */
     int32_t reserved_;
+    /* overlapped steps (lpa_step_slab.overlap_cols > 0): the edge part of the tiled push runs on a second stream beside the
+     * interior part and needs an overflow list and counter of its own; optional event pair around its launch */
+    uint32_t *overflow_edge, *overflow_edge_count;
+    void *ev_edge_start, *ev_edge_stop;
 } lpa_step_migrate;
 
 typedef struct {
@@ -672,7 +676,14 @@ typedef struct {
     double *cur_r_lo, *cur_r_hi;    /* 4 * ng * plane doubles each: the neighbours' J / rho guard planes */
     double *jx_left_plane;          /* plane doubles (continuity steps: the left neighbour's folded jx at its node nx-1) */
     int32_t rho_exchange;           /* != 0: the jx plane travels in LPA_STAGE_B2_GUARD (every step: all ranks alike) */
-    int32_t reserved_;
+    int32_t overlap_cols;           /* > 0 (and LPA_STAGE_PUSH .. LPA_STAGE_FOLD in one call, every store tile ordered): the
+                                       `overlap_cols` tile columns at each x face (+ overflow list + arrival area: everything
+                                       that can deposit into the x guard planes or leave the slab) are pushed first, on the
+                                       communicator's second stream (high priority), followed there by the leaver pack and the
+                                       J / rho + particle exchange -- while the main stream pushes the interior tiles (the
+                                       reference's sync_currents_start .. intra-rank work .. _wait bracket,
+                                       simulation.py:1155-1188); the streams join before the fold.  The caller chooses
+                                       overlap_cols * tile width >= the drift since the sort + 4 cells (engines: edge_columns) */
 } lpa_step_slab;
 
 typedef struct {

@@ -86,7 +86,9 @@ class lpa_face_msg(C.Structure):
 class lpa_step_migrate(C.Structure):
     _fields_ = [("s_lo", C.c_void_p), ("s_hi", C.c_void_p), ("r_lo", C.c_void_p), ("r_hi", C.c_void_p),
                 ("cursor", C.c_void_p), ("surplus", C.c_void_p), ("fs", C.POINTER(lpa_free_slots)),
-                ("area_capacity", C.c_int64), ("edge_cols", C.c_int32), ("reserved_", C.c_int32)]
+                ("area_capacity", C.c_int64), ("edge_cols", C.c_int32), ("reserved_", C.c_int32),
+                ("overflow_edge", C.c_void_p), ("overflow_edge_count", C.c_void_p), ("ev_edge_start", C.c_void_p),
+                ("ev_edge_stop", C.c_void_p)]
 
 
 class lpa_step_species(C.Structure):
@@ -99,7 +101,7 @@ class lpa_step_slab(C.Structure):
     _fields_ = [("comm", C.c_void_p), ("xlo", C.c_double), ("xhi", C.c_double), ("shift_lo", C.c_double),
                 ("shift_hi", C.c_double), ("migrate_capacity", C.c_int64), ("cur_r_lo", C.c_void_p),
                 ("cur_r_hi", C.c_void_p), ("jx_left_plane", C.c_void_p), ("rho_exchange", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("overlap_cols", C.c_int32)]
 
 
 class lpa_step_desc(C.Structure):

@@ -97,7 +97,26 @@ __global__ void __launch_bounds__(256) k_copy_segments(CopySegs s) {
 struct lpa_comm {
     int kind, rank, size, left, right, periodic, version;
     NcclComm nccl;
+    hipStream_t side = nullptr;          // second stream of the overlapped steps (lpa_step), created on first use
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
+
+// the communicator's second stream (high priority: what runs there goes first) and two events, created on first use
+int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done) {
+    LPA_REQUIRE(c && side && ev_ready && ev_done, "lpai_comm_side: bad args");
+    if (!c->side) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (hi = the numerically lowest = highest priority)
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess) {
+            lpa_set_error("lpa_comm: cannot create the side stream");
+            return LPA_ERR_HIP;
+        }
+    }
+    *side = c->side; *ev_ready = c->ev[0]; *ev_done = c->ev[1];
+    return LPA_OK;
+}
 
 extern "C" int lpa_comm_unique_id(void *id128, const char *librccl_path) {
     LPA_REQUIRE(id128, "lpa_comm_unique_id: null id");
@@ -147,6 +166,12 @@ extern "C" int lpa_comm_create_loopback(lpa_comm **out, int32_t size, int32_t pe
 extern "C" int lpa_comm_destroy(lpa_comm *c) {
     if (!c) return LPA_OK;
     if (c->kind == LPA_COMM_RCCL && c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+        (void)hipEventDestroy(c->ev[0]);
+        (void)hipEventDestroy(c->ev[1]);
+    }
     delete c;
     return LPA_OK;
 }

@@ -50,6 +50,13 @@ int lpai_push_deposit_rest_3d(const lpa_grid *g, const lpa_particles *p, const l
 // jx jy jz (and rho) including guards = 0 and up to 32 device words = 0, one launch (lpa_step: reset + per-step counters)
 // (`also`: one more array shaped like rho to zero, or NULL)
 int lpai_reset_step(const lpa_grid *g, int with_rho, double *also, uint32_t *const *words, int nwords, void *stream);
+// the communicator's second stream and two events (overlapped steps)
+int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done);
+// lpa_push_deposit_tiled_multi_3d restricted to the edge / interior tile columns (LPA_PART_*)
+int lpai_push_deposit_tiled_multi_part_3d(const lpa_grid *g, int32_t nspecies, const lpa_particles *const *p,
+                                          const lpa_push_params *const *pp, const lpa_tiling *const *t,
+                                          uint32_t *const *overflow, uint32_t *const *overflow_count, int part, int edge_cols,
+                                          void *stream);
 // zero up to 32 device words in one launch (the per-step counters: overflow lists, message headers)
 int lpai_zero_words(uint32_t *const *words, int n, void *stream);
 // the current fold of a step in one launch: periodic fold along `axes` + (slab ranks) the J / rho guard planes received

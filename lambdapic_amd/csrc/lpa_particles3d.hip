@@ -1021,6 +1021,15 @@ extern "C" int lpa_push_deposit_tiled_multi_3d(const lpa_grid *g, int32_t nspeci
                                                const lpa_push_params *const *pp, const lpa_tiling *const *t,
                                                uint32_t *const *overflow, uint32_t *const *overflow_count,
                                                void *stream) {
+    return lpai_push_deposit_tiled_multi_part_3d(g, nspecies, p, pp, t, overflow, overflow_count, LPA_PART_ALL, 0, stream);
+}
+
+int lpai_push_deposit_tiled_multi_part_3d(const lpa_grid *g, int32_t nspecies, const lpa_particles *const *p,
+                                          const lpa_push_params *const *pp, const lpa_tiling *const *t,
+                                          uint32_t *const *overflow, uint32_t *const *overflow_count, int part, int edge_cols,
+                                          void *stream) {
+    LPA_REQUIRE(part == LPA_PART_ALL || ((part == LPA_PART_EDGE || part == LPA_PART_INTERIOR) && edge_cols >= 1),
+                "lpa_push_deposit_tiled_multi_3d: bad part / edge_cols");
     LPA_REQUIRE(nspecies >= 1 && nspecies <= K13_MAX_SPECIES && p && pp && t && overflow && overflow_count,
                 "lpa_push_deposit_tiled_multi_3d: 1 .. %d species", K13_MAX_SPECIES);
     MultiArgs m;
@@ -1049,7 +1058,7 @@ extern "C" int lpa_push_deposit_tiled_multi_3d(const lpa_grid *g, int32_t nspeci
         d.overflow_count = overflow_count[s];
     }
     if (m.ns == 0) return LPA_OK;
-    launch_tiled_3d(g, m, t[0], false, defer, !(pp[0]->flags & LPA_PUSH_NO_RHO), LPA_PART_ALL, 0, stream);
+    launch_tiled_3d(g, m, t[0], false, defer, !(pp[0]->flags & LPA_PUSH_NO_RHO), part, edge_cols, stream);
     LPA_CHECK_LAUNCH("lpa_push_deposit_tiled_multi_3d");
     return LPA_OK;
 }

@@ -55,44 +55,6 @@ static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_spe
     return pp;
 }
 
-// 3-D, fuse_species: the tile-ordered part of every species in one launch (one E / B staging per tile), then each
-// species' overflow list and loose particles; unsorted species take the per-species path below
-static int step_push_fused_3d(const lpa_step_desc *d, void *st, bool *done) {
-    const lpa_grid *g = &d->grid;
-    constexpr int MAXS = 4;
-    const lpa_particles *p[MAXS];
-    const lpa_push_params *ppp[MAXS];
-    const lpa_tiling *t[MAXS];
-    uint32_t *ovf[MAXS], *cnt[MAXS];
-    lpa_push_params pp[MAXS];
-    int idx[MAXS], n = 0;
-    for (int s = 0; s < d->nspecies && n < MAXS; s++) {
-        const lpa_step_species *sp = &d->species[s];
-        if (sp->p.n == 0 || !sp->t || sp->n_sorted <= 0) continue;
-        pp[n] = species_params(d, sp);
-        p[n] = &sp->p; ppp[n] = &pp[n]; t[n] = sp->t; ovf[n] = sp->overflow; cnt[n] = sp->overflow_count; idx[n] = s;
-        n++;
-    }
-    if (n == 0) return LPA_OK;
-    const lpa_step_species *first = &d->species[idx[0]];
-    if (first->ev_start && hipEventRecord((hipEvent_t)first->ev_start, (hipStream_t)st) != hipSuccess) {
-        lpa_set_error("lpa_step: hipEventRecord failed");
-        return LPA_ERR_HIP;
-    }
-    if (int e = lpa_push_deposit_tiled_multi_3d(g, n, p, ppp, t, ovf, cnt, st)) return e;
-    if (first->ev_stop && hipEventRecord((hipEvent_t)first->ev_stop, (hipStream_t)st) != hipSuccess) {
-        lpa_set_error("lpa_step: hipEventRecord failed");
-        return LPA_ERR_HIP;
-    }
-    for (int k = 0; k < n; k++) {
-        const lpa_step_species *sp = &d->species[idx[k]];
-        if (int e = lpai_push_deposit_rest_3d(g, &sp->p, &pp[k], sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
-                                              sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st)) return e;
-        done[idx[k]] = true;
-    }
-    return LPA_OK;
-}
-
 // every per-step device counter: the overflow-list counters of the tiled pushes and, on slab ranks, the count headers of
 // the particle messages (send side; receive side of a face without a neighbour: nothing arrives).  Zeroed by ONE launch --
 // the current reset's when LPA_STAGE_RESET runs in the same call, else one of their own
@@ -105,6 +67,7 @@ static int step_counters(const lpa_step_desc *d, uint32_t **w, bool overflow) {
         const lpa_step_species *sp = &d->species[s];
         if (overflow && sp->p.n > 0 && sp->t && sp->n_sorted > 0 && sp->overflow_count) w[n++] = sp->overflow_count;
         if (overflow && sp->pp.leaver_count) w[n++] = sp->pp.leaver_count;
+        if (overflow && sl && sl->overlap_cols > 0 && sp->mig.overflow_edge_count) w[n++] = sp->mig.overflow_edge_count;
         if (sl && sl->comm) {
             uint32_t *h[4] = {(uint32_t *)sp->mig.s_lo, (uint32_t *)sp->mig.s_hi,
                               info[3] < 0 ? (uint32_t *)sp->mig.r_lo : nullptr, info[4] < 0 ? (uint32_t *)sp->mig.r_hi : nullptr};
@@ -116,48 +79,84 @@ static int step_counters(const lpa_step_desc *d, uint32_t **w, bool overflow) {
 }
 
 static int step_zero_counters(const lpa_step_desc *d, void *st, bool overflow = true) {
-    uint32_t *w[9 * 64];
+    uint32_t *w[11 * 64];
     const int n = step_counters(d, w, overflow);
     if (n < 0) return LPA_ERR_ARG;
     return n ? lpai_zero_words(w, n, st) : LPA_OK;
 }
 
-static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
+static int record(void *ev, void *st) {
+    if (ev && hipEventRecord((hipEvent_t)ev, (hipStream_t)st) != hipSuccess) {
+        lpa_set_error("lpa_step: hipEventRecord failed");
+        return LPA_ERR_HIP;
+    }
+    return LPA_OK;
+}
+
+// One PART of the pushes of every species on `st`: LPA_PART_ALL (the in-line step), or -- overlapped slab steps --
+// LPA_PART_EDGE: the `cols` tile columns at each x face with the species' edge overflow lists, plus everything that is not
+// tile ordered (the arrival area, unsorted stores): all that can deposit into the x guard planes or leave the slab;
+// LPA_PART_INTERIOR: the other tiles with the main overflow lists.
+// 3-D, fuse_species: the tile-ordered part of every species in one launch (one E / B staging per tile).
+static int push_part(const lpa_step_desc *d, int part, int cols, void *st) {
     const lpa_grid *g = &d->grid;
+    const bool edge = part == LPA_PART_EDGE, loose = part != LPA_PART_INTERIOR;
     bool done[64] = {false};
-    LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
-    if (!counters_zeroed)
-        if (int e = step_zero_counters(d, st)) return e;
-    if (d->dim == 3 && d->fuse_species && d->nspecies <= 64)
-        if (int e = step_push_fused_3d(d, st, done)) return e;
+    auto ovf_of = [&](const lpa_step_species *sp) { return edge ? sp->mig.overflow_edge : sp->overflow; };
+    auto cnt_of = [&](const lpa_step_species *sp) { return edge ? sp->mig.overflow_edge_count : sp->overflow_count; };
+    auto rest = [&](const lpa_step_species *sp, const lpa_push_params *pp, bool with_list) -> int {
+        const uint32_t *list = with_list ? ovf_of(sp) : nullptr;
+        const int64_t nloose = loose ? sp->p.n - sp->n_sorted : 0;
+        if (!list && nloose <= 0) return LPA_OK;
+        return d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
+                                                       (const int32_t *)sp->mig.cursor, st)
+                           : lpai_push_deposit_rest_3d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
+                                                       (const int32_t *)sp->mig.cursor, st);
+    };
+    if (d->dim == 3 && d->fuse_species) {
+        constexpr int MAXS = 4;
+        const lpa_particles *p[MAXS];
+        const lpa_push_params *ppp[MAXS];
+        const lpa_tiling *t[MAXS];
+        uint32_t *ovf[MAXS], *cnt[MAXS];
+        lpa_push_params pp[MAXS];
+        int idx[MAXS], n = 0;
+        for (int s = 0; s < d->nspecies && n < MAXS; s++) {
+            const lpa_step_species *sp = &d->species[s];
+            if (sp->p.n == 0 || !sp->t || sp->n_sorted <= 0) continue;
+            pp[n] = species_params(d, sp);
+            p[n] = &sp->p; ppp[n] = &pp[n]; t[n] = sp->t; ovf[n] = ovf_of(sp); cnt[n] = cnt_of(sp); idx[n] = s;
+            n++;
+        }
+        if (n > 0) {
+            const lpa_step_species *first = &d->species[idx[0]];
+            if (int e = record(edge ? first->mig.ev_edge_start : first->ev_start, st)) return e;
+            if (int e = lpai_push_deposit_tiled_multi_part_3d(g, n, p, ppp, t, ovf, cnt, part, cols, st)) return e;
+            if (int e = record(edge ? first->mig.ev_edge_stop : first->ev_stop, st)) return e;
+            for (int k = 0; k < n; k++) {
+                if (int e = rest(&d->species[idx[k]], &pp[k], true)) return e;
+                done[idx[k]] = true;
+            }
+        }
+    }
     for (int s = 0; s < d->nspecies; s++) {
-        if (s < 64 && done[s]) continue;
+        if (done[s]) continue;
         const lpa_step_species *sp = &d->species[s];
         if (sp->p.n == 0) continue;
         lpa_push_params pp = species_params(d, sp);
         int e;
         if (sp->t && sp->n_sorted > 0) {
-            if (sp->ev_start && hipEventRecord((hipEvent_t)sp->ev_start, (hipStream_t)st) != hipSuccess) {
-                lpa_set_error("lpa_step: hipEventRecord failed");
-                return LPA_ERR_HIP;
-            }
-            e = d->dim == 2 ? lpa_push_deposit_tiled_2d(g, &sp->p, &pp, sp->t, sp->overflow, sp->overflow_count, st)
-                            : lpa_push_deposit_tiled_3d(g, &sp->p, &pp, sp->t, sp->overflow, sp->overflow_count, st);
+            if ((e = record(edge ? sp->mig.ev_edge_start : sp->ev_start, st))) return e;
+            e = d->dim == 2 ? lpa_push_deposit_tiled_part_2d(g, &sp->p, &pp, sp->t, ovf_of(sp), cnt_of(sp), part, cols, st)
+                            : lpa_push_deposit_tiled_part_3d(g, &sp->p, &pp, sp->t, ovf_of(sp), cnt_of(sp), part, cols, st);
             if (e) return e;
-            if (sp->ev_stop && hipEventRecord((hipEvent_t)sp->ev_stop, (hipStream_t)st) != hipSuccess) {
-                lpa_set_error("lpa_step: hipEventRecord failed");
-                return LPA_ERR_HIP;
-            }
+            if ((e = record(edge ? sp->mig.ev_edge_stop : sp->ev_stop, st))) return e;
             // the overflow list and the loose particles (appended / arrived since the sort) in one launch
-            e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
-                                                        sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st)
-                            : lpai_push_deposit_rest_3d(g, &sp->p, &pp, sp->overflow, sp->overflow_count, sp->n_sorted, sp->n_sorted,
-                                                        sp->p.n - sp->n_sorted, (const int32_t *)sp->mig.cursor, st);
-            if (e) return e;
+            if ((e = rest(sp, &pp, true))) return e;
+        } else if (!loose) {
+            continue;                             // (not tile ordered: all of it went with the edge part)
         } else if (sp->t && sp->mig.cursor) {     // a slab rank's store without a tile-ordered particle: its arrival area
-            e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, &pp, nullptr, nullptr, 0, 0, sp->p.n, (const int32_t *)sp->mig.cursor, st)
-                            : lpai_push_deposit_rest_3d(g, &sp->p, &pp, nullptr, nullptr, 0, 0, sp->p.n, (const int32_t *)sp->mig.cursor, st);
-            if (e) return e;
+            if ((e = rest(sp, &pp, false))) return e;
         } else {
             e = d->dim == 2 ? lpa_push_deposit_2d(g, &sp->p, &pp, 0, sp->p.n, st)
                             : lpa_push_deposit_3d(g, &sp->p, &pp, 0, sp->p.n, st);
@@ -167,17 +166,20 @@ static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
     return LPA_OK;
 }
 
-// slab ranks, LPA_STAGE_FOLD: leavers of every species into their face messages, ONE exchange for the J / rho guard
-// planes and all particle messages (sync_currents + sync_particles back to back, simulation.py:1043-1080), the planes
-// folded in, the periodic fold along the local axes, the arrivals seated
-static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
+static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
+    LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
+    if (!counters_zeroed)
+        if (int e = step_zero_counters(d, st)) return e;
+    return push_part(d, LPA_PART_ALL, 0, st);
+}
+
+// slab ranks, first half of the fold: leavers of every species into their face messages, then ONE exchange for the J / rho
+// guard planes and all particle messages (sync_currents + sync_particles back to back, simulation.py:1043-1080)
+static int slab_pack_exchange(const lpa_step_desc *d, bool headers_zeroed, void *st) {
     const lpa_step_slab *sl = d->slab;
-    if (!headers_zeroed)      // (LPA_STAGE_PUSH of this call did it otherwise)
+    if (!headers_zeroed)      // (LPA_STAGE_PUSH / RESET of this call did it otherwise)
         if (int e = step_zero_counters(d, st, false)) return e;
     const lpa_grid *g = &d->grid;
-    int32_t info[6];
-    if (int e = lpa_comm_info(sl->comm, info)) return e;
-    const bool has_left = info[3] >= 0, has_right = info[4] >= 0;
     LPA_REQUIRE(sl->cur_r_lo && sl->cur_r_hi && sl->migrate_capacity > 0 && sl->xlo < sl->xhi, "lpa_step: bad slab descriptor");
     const long plane = plane_of(g), n = (long)g->ng * plane;
     const long nmig = 1 + (long)LPA_MIG_NATTR * sl->migrate_capacity;
@@ -205,7 +207,16 @@ static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
         m[nm].n_send_lo = m[nm].n_send_hi = m[nm].n_recv_lo = m[nm].n_recv_hi = nmig;
         nm++;
     }
-    if (int e = lpa_comm_exchange(sl->comm, m, nm, st)) return e;
+    return lpa_comm_exchange(sl->comm, m, nm, st);
+}
+
+// second half: the received planes folded in (+ the periodic fold along the local axes), the arrivals seated
+static int slab_fold_unpack(const lpa_step_desc *d, void *st) {
+    const lpa_step_slab *sl = d->slab;
+    const lpa_grid *g = &d->grid;
+    int32_t info[6];
+    if (int e = lpa_comm_info(sl->comm, info)) return e;
+    const bool has_left = info[3] >= 0, has_right = info[4] >= 0;
     if (int e = lpai_fold_all(g, d->local_axes, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr, st)) return e;
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
@@ -213,6 +224,34 @@ static int slab_fold(const lpa_step_desc *d, bool headers_zeroed, void *st) {
         if (int e = lpai_migrate_unpack2(&sp->p, g, sp->t, (mg->edge_cols > 0 || sp->pp.leavers) ? mg->fs : nullptr, sp->n_sorted, mg->area_capacity,
                                          mg->cursor, mg->r_lo, mg->r_hi, sl->migrate_capacity, sl->shift_lo, sl->shift_hi, st))
             return e;
+    }
+    return LPA_OK;
+}
+
+// Overlapped slab step (lpa_step_slab.overlap_cols): the edge part, the leaver pack and the whole exchange on the
+// communicator's second stream, the interior part on the caller's; joined before the fold.
+static int slab_push_overlapped(const lpa_step_desc *d, bool counters_zeroed, void *st) {
+    const lpa_step_slab *sl = d->slab;
+    LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
+    if (!counters_zeroed)
+        if (int e = step_zero_counters(d, st)) return e;
+    void *side, *ev_ready, *ev_done;
+    if (int e = lpai_comm_side(sl->comm, &side, &ev_ready, &ev_done)) return e;
+    if (hipEventRecord((hipEvent_t)ev_ready, (hipStream_t)st) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)side, (hipEvent_t)ev_ready, 0) != hipSuccess) {
+        lpa_set_error("lpa_step: cannot fork the side stream");
+        return LPA_ERR_HIP;
+    }
+    if (int e = push_part(d, LPA_PART_EDGE, sl->overlap_cols, side)) return e;
+    if (int e = slab_pack_exchange(d, true, side)) return e;
+    if (hipEventRecord((hipEvent_t)ev_done, (hipStream_t)side) != hipSuccess) {
+        lpa_set_error("lpa_step: hipEventRecord failed");
+        return LPA_ERR_HIP;
+    }
+    if (int e = push_part(d, LPA_PART_INTERIOR, sl->overlap_cols, st)) return e;
+    if (hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev_done, 0) != hipSuccess) {
+        lpa_set_error("lpa_step: cannot join the side stream");
+        return LPA_ERR_HIP;
     }
     return LPA_OK;
 }
@@ -237,7 +276,13 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     const bool slab = d->slab && d->slab->comm;
     LPA_REQUIRE(!slab || !(d->local_axes & 1), "lpa_step: x is split over slabs, not periodic inside one");
     LPA_REQUIRE(!slab || !d->slab->rho_exchange || d->slab->jx_left_plane, "lpa_step: jx_left_plane missing");
-    bool headers_zeroed = false, counters_zeroed = false;
+    bool headers_zeroed = false, counters_zeroed = false, exchanged = false;
+    // overlapped push + exchange: only when this call runs on through the fold and every store is tile ordered
+    bool overlap = slab && d->slab->overlap_cols > 0 && first_stage <= LPA_STAGE_PUSH && last_stage >= LPA_STAGE_FOLD;
+    for (int s_ = 0; overlap && s_ < d->nspecies; s_++) {
+        const lpa_step_species *sp = &d->species[s_];
+        overlap = sp->t && sp->mig.overflow_edge && sp->mig.overflow_edge_count && sp->overflow && sp->overflow_count;
+    }
     for (int stage = first_stage; stage <= last_stage; stage++) {
         int e = LPA_OK;
         switch (stage) {
@@ -254,7 +299,7 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             break;
         case LPA_STAGE_RESET: { // current_depositor.reset(): :980-981
             // (+ the per-step counters of the push that follows in the same call: one launch for both)
-            uint32_t *w[9 * 64 + 1];
+            uint32_t *w[11 * 64 + 1];
             int ns = 0;
             if (last_stage >= LPA_STAGE_PUSH) {
                 ns = step_counters(d, w, true);
@@ -274,12 +319,18 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             break;
         }
         case LPA_STAGE_PUSH:    // pusher[ispec](dt, unified=True) for every species: :983-990
-            e = step_push(d, counters_zeroed, stream);
+            if (overlap) {      // edge part + leaver pack + exchange on the second stream beside the interior part
+                e = slab_push_overlapped(d, counters_zeroed, stream);
+                exchanged = !e;
+            } else {
+                e = step_push(d, counters_zeroed, stream);
+            }
             headers_zeroed = true;
             break;
         case LPA_STAGE_FOLD:    // sync_currents (+ sync_particles between slabs): :1043-1080, 1155-1176
             if (slab) {
-                e = slab_fold(d, headers_zeroed, stream);
+                if (!exchanged) e = slab_pack_exchange(d, headers_zeroed, stream);
+                if (!e) e = slab_fold_unpack(d, stream);
                 // (rho: with rho_exchange the jx plane rides with the B planes of LPA_STAGE_B2_GUARD and rho follows there)
                 if (!e && d->continuity && !d->slab->rho_exchange) e = slab_rho(d, stream);
                 break;

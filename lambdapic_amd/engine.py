@@ -822,6 +822,10 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             fs = None        # the order is older than the stacks were sized for
         out = {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
                "area": ws["area"], "cols": cols}
+        if self.overlap and self.native_slab():       # the edge part of an overlapped push has a list and counter of its own
+            if "overflow_edge" not in ws:
+                ws["overflow_edge"] = torch.empty(sp.capacity, dtype=torch.int32, device=self.device)
+            out.update(overflow_edge=ws["overflow_edge"], edge_count=ws["counters"][2:3])
         if self.leaver_lists and self.native_slab():
             # the push kernels list the slots that left the slab (exact: no scan of the edge tile columns, and the free-slot
             # stacks stay usable however old the order is)
@@ -843,6 +847,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if slab.rho_exchange:
             self._jx_plane_bufs()
             slab.jx_left_plane = self._jx_plane.data_ptr()
+        # overlapped: edge tile columns, leaver pack and the exchange on a second stream beside the interior tiles
+        dt = getattr(self, "_dt_hint", 0.0)
+        slab.overlap_cols = self.edge_columns(dt) if (self.overlap and dt > 0) else 0
         return h
 
     def _mig_pack(self, ispec):

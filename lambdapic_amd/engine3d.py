@@ -572,6 +572,10 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             fs = None
         out = {"bufs": ws["mig"], "cursor": ws["counters"][1:2], "surplus": ws["counters"][3:4], "fs": fs,
                "area": self.arrival_area(), "cols": cols}
+        if self.overlap and self.native_slab():
+            if "overflow_edge" not in ws:
+                ws["overflow_edge"] = torch.empty_like(ws["overflow"])
+            out.update(overflow_edge=ws["overflow_edge"], edge_count=ws["counters"][2:3])
         if self.leaver_lists and self.native_slab() and sp["tiling"] is not None:      # (see PicEngine2D._slab_species)
             if ws.get("leavers") is None:
                 ws["leavers"] = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
@@ -591,6 +595,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         if slab.rho_exchange:
             self._jx_plane_bufs()
             slab.jx_left_plane = self._jx_plane.data_ptr()
+        dt = getattr(self, "_dt_hint", 0.0)
+        slab.overlap_cols = self.edge_columns(dt) if (self.overlap and dt > 0) else 0
         return h
 
     def _mig_pack(self, i):

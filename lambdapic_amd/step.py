@@ -90,6 +90,7 @@ class FusedStepMixin:
         entries = list(self._species_entries(dt, slab_rank, pushed=not push)) if (push or (native and fold)) else []
         arr = (_lib.lpa_step_species * max(len(entries), 1))()
         stream = torch.cuda.current_stream(self.device)
+        edge_events = []
         for k, ent in enumerate(entries):
             e = arr[k]
             tiling, n_sorted = ent["tiling"], ent["n_sorted"]
@@ -97,13 +98,6 @@ class FusedStepMixin:
             e.t = C.pointer(tiling) if tiling is not None else None
             if ent["overflow"] is not None:
                 e.overflow, e.overflow_count = ent["overflow"].data_ptr(), ent["count"].data_ptr()
-            if timed and tiling is not None and n_sorted > 0 and not (d.fuse_species and self.kernel_events_step):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)          # (creates the HIP events; lpa_step records them again around the launch)
-                e1.record(stream)
-                e.ev_start, e.ev_stop = e0.cuda_event, e1.cuda_event
-                self.kernel_events.append((e0, e1))
-                self.kernel_events_step = True
             mig = ent.get("mig")
             if mig is not None:
                 m = mig["bufs"]
@@ -111,6 +105,22 @@ class FusedStepMixin:
                 e.mig.cursor, e.mig.surplus = mig["cursor"].data_ptr(), mig["surplus"].data_ptr()
                 e.mig.fs = C.pointer(mig["fs"]) if mig["fs"] is not None else None
                 e.mig.area_capacity, e.mig.edge_cols = mig["area"], mig["cols"]
+                if mig.get("overflow_edge") is not None:       # (overlapped steps: the edge part's own list and counter)
+                    e.mig.overflow_edge, e.mig.overflow_edge_count = mig["overflow_edge"].data_ptr(), mig["edge_count"].data_ptr()
+            if timed and tiling is not None and n_sorted > 0 and not (d.fuse_species and self.kernel_events_step):
+                def pair():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)           # (creates the HIP events; lpa_step records them again around the launch)
+                    b.record(stream)
+                    return a, b
+                e0, e1 = pair()
+                e.ev_start, e.ev_stop = e0.cuda_event, e1.cuda_event
+                self.kernel_events.append((e0, e1))
+                self.kernel_events_step = True
+                if mig is not None and mig.get("overflow_edge") is not None:     # the edge part is a launch of its own
+                    f0, f1 = pair()
+                    e.mig.ev_edge_start, e.mig.ev_edge_stop = f0.cuda_event, f1.cuda_event
+                    edge_events.append((f0, f1))
             keep.append(ent)
         d.nspecies, d.species = len(entries), arr
         if native:
@@ -120,6 +130,8 @@ class FusedStepMixin:
             d.slab = C.pointer(slab)
             keep.append(slab)
         check(self.L.lpa_step(C.byref(d), first, last, stream.cuda_stream), "lpa_step")
+        if edge_events and native and push and fold and slab.overlap_cols > 0:
+            self.kernel_events.extend(edge_events)        # (the edge and the interior launch of a species add up)
         self._step_keep = (d, arr, keep)      # alive until the next call (the launches copy what they need)
         if push:
             self._dt_step = dt

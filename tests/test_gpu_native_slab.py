@@ -80,12 +80,13 @@ def _problem2d():
     return dx, dy, dt, x, y, u, w
 
 
-def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True):
+def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True, overlap=False):
     from lambdapic_amd.engine import PicEngine2D
     dx, dy, dt, x, y, u, w = _problem2d()
     eng = PicEngine2D(nx_cells, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
                       migrate_capacity=4096)
     eng.rho_continuity = rho
+    eng.overlap = overlap
     n = x.size * copies
     eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=2 * n + 20000)
     s = eng.species[0].cset
@@ -140,6 +141,22 @@ def test_mirrored_slab_is_half_of_the_doubled_box_2d(doubled2d, transport):
     assert eng.rho_steps["continuity"] > eng.rho_steps["anchor"] > 0
 
 
+@pytest.mark.parametrize("transport", ["loopback", "rccl"])
+def test_overlapped_mirrored_slab_2d(doubled2d, transport):
+    """lpa_step_slab.overlap_cols: edge tile columns, leaver pack and the whole exchange on the communicator's second stream
+    beside the interior tiles (north_star: halo exchange overlapped with interior work on a second HIP stream)"""
+    tr2, f2 = doubled2d
+    comm = _comm(transport, NX * _problem2d()[0], 4096)
+    tr, f, eng = _engine2d(NX, comm, 1, overlap=True)
+    assert eng.one_call_step() and eng.edge_columns(_problem2d()[2]) > 0
+    assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
+    for a in f:
+        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
+
+
 def test_run_steps_equals_steps_on_a_mirrored_slab(doubled2d):
     """deferred E2 guards (one message round and one launch less per step): the state after run_steps(n) is the state after
     n step()s"""
@@ -172,10 +189,10 @@ def test_mirrored_slab_with_deposited_rho(doubled2d):
 
 
 # ---- 3-D twin ---------------------------------------------------------------------------------------------------------------
-N3 = (16, 16, 32)
+N3 = (32, 16, 32)
 
 
-def _engine3d(nx_cells, comm, copies, nsteps=12):
+def _engine3d(nx_cells, comm, copies, nsteps=12, overlap=False):
     from lambdapic_amd import constants
     from lambdapic_amd.engine3d import PicEngine3D
     lam = 0.8e-6
@@ -190,7 +207,7 @@ def _engine3d(nx_cells, comm, copies, nsteps=12):
            ((cell % N3[2]) + rng.uniform(-0.5, 0.5, n)) * d[2]]
     u = rng.normal(size=(3, n)) * 0.3
     eng = PicEngine3D(nx_cells, N3[1], N3[2], *d, 3, sort_interval=5, comm=comm, migrate_capacity=8192)
-    eng.overlap = False
+    eng.overlap = overlap
     ntot = n * copies
     data = torch.full((8, 2 * ntot + eng.arrival_area() + 1024), float("nan"), dtype=torch.float64, device="cuda:0")
     cat = lambda a: torch.from_numpy(np.concatenate([a] * copies)).cuda()
@@ -216,13 +233,16 @@ def doubled3d():
     return tr, f
 
 
-@pytest.mark.parametrize("transport", ["loopback", "rccl", "python"])
-def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport):
+@pytest.mark.parametrize("transport,overlap", [("loopback", False), ("rccl", False), ("python", False), ("loopback", True),
+                                               ("rccl", True)])
+def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overlap):
     tr2, f2 = doubled3d
     lam = 0.8e-6
     comm = _comm(transport, N3[0] * lam / 20, 8192)
-    tr, f, eng, _ = _engine3d(N3[0], comm, 1)
+    tr, f, eng, d = _engine3d(N3[0], comm, 1, overlap=overlap)
     assert eng.one_call_step() == (transport != "python")
+    if overlap:
+        assert eng.edge_columns(0.95 / (CL * np.sqrt(sum(v ** -2 for v in d)))) > 0
     assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])
     for k in range(3):
         assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)

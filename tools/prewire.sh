@@ -18,6 +18,7 @@ for cfg in "512 512 16" "128 1024 64"; do
   mir $1 $2 $3 --transport python
   mir $1 $2 $3 --transport loopback
   mir $1 $2 $3 --transport loopback --run-steps
+  mir $1 $2 $3 --transport loopback --overlap
   mir $1 $2 $3 --transport rccl
   mir $1 $2 $3 --transport rccl --run-steps
 done
@@ -27,5 +28,7 @@ echo "== the same slab as rank 0 of a mirrored 2-slab ring"
 for t in python loopback rccl; do python tools/bench_mirror3d.py --steps 40 --warmup 12 --transport $t 2>&1 | tail -1; done
 python tools/bench_mirror3d.py --steps 40 --warmup 12 --transport loopback --run-steps 2>&1 | tail -1
 python tools/bench_mirror3d.py --steps 40 --warmup 12 --transport python --overlap 2>&1 | tail -1
+python tools/bench_mirror3d.py --steps 40 --warmup 12 --transport loopback --overlap 2>&1 | tail -1
+python tools/bench_mirror3d.py --steps 40 --warmup 12 --transport rccl --overlap 2>&1 | tail -1
 } > $out 2>&1
 cat $out
