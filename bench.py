@@ -111,10 +111,40 @@ def parity_c1(nsteps=200):
             "charge_rel_err": rel(d["charge"], driver.total_charge(P))}
 
 
+def _reference_kernel():
+    """the reference's own fused 2-D kernel (unified_boris_pusher_cpu_2d of core/pusher/unified/unified_pusher_2d.c, compiled
+    in the build container by oracle/Makefile into oracle/_ref -- a binary of this repo's making that travels with the
+    snapshot).  A child process tries it first on a tiny case (the binary was built on another host: an illegal instruction
+    must cost the baseline's kind, not the run): ('native' | 'portable', module) or (None, None)."""
+    import subprocess
+    import oracle
+    if not oracle.ref_available():
+        return None, None
+    probe = ("import numpy as np, oracle, sys\n"
+             "from oracle import driver\n"
+             "from lambdapic_amd.patch import make_patches_2d\n"
+             "m = oracle.ref_module('pusher', 'unified_pusher_2d', portable=sys.argv[1] == 'portable')\n"
+             "P = make_patches_2d(32, 32, 4e-8, 4e-8, 1, 1)\n"
+             "driver.load_uniform_plasma(P, 0, 4, 1e27, 0.05, np.random.default_rng(1))\n"
+             "m.unified_boris_pusher_cpu_2d([p.particles[0] for p in P], [p.fields for p in P], P.npatches, 1e-17, -1.6e-19, 9.1e-31)\n")
+    for flavour in ("native", "portable"):
+        try:
+            r = subprocess.run([sys.executable, "-c", probe, flavour], cwd=ROOT, timeout=120, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL)
+            if r.returncode == 0:
+                return flavour, oracle.ref_module("pusher", "unified_pusher_2d", portable=flavour == "portable")
+        except (subprocess.TimeoutExpired, OSError):
+            pass
+    return None, None
+
+
 def cpu_baseline(args):
-    """oracle port (oracle/picoracle.c, rebuilt -O3 -march=native on this host) on a bounded sample:
-    same physics and cell size, smaller box; fused push+deposit (OpenMP over patches) + the four
-    FDTD half steps + guard copies / current fold; no sort, no particle migration."""
+    """CPU path on a bounded sample of the same workload: same physics and cell size, smaller box; fused push+deposit
+    (OpenMP over patches) + the four FDTD half steps + guard copies / current fold; no sort, no particle migration.
+    The fused kernel -- 95 % of the CPU step -- is the REFERENCE's own compiled one when its binary (oracle/_ref) runs on
+    this host (kind "reference"); the field half steps and guard copies around it are the oracle port's C (the reference's
+    are numba JIT functions, which cannot run here); otherwise everything is the port (kind "port":
+    oracle/picoracle.c rebuilt -O3 -march=native on this host)."""
     import oracle
     from oracle import driver
     from lambdapic_amd.patch import make_patches_2d
@@ -153,12 +183,17 @@ def cpu_baseline(args):
     def guards(attrs):
         oracle.sync_guard_fields_2d_c(fl, pl, attrs, npat, P.nx, P.ny, ng, native=True)
 
+    flavour, ref = _reference_kernel()
+
     def one_step():
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         fdtd_e(0.5 * dt); guards(E)
         fdtd_b(0.5 * dt); guards(B)
         oracle.reset_current(fl, npat)
-        oracle.unified_boris_pusher_cpu_2d(parts, fl, npat, dt, q, m, native=True)
+        if ref is not None:
+            ref.unified_boris_pusher_cpu_2d(parts, fl, npat, dt, q, m)
+        else:
+            oracle.unified_boris_pusher_cpu_2d(parts, fl, npat, dt, q, m, native=True)
         oracle.sync_currents_2d_c(fl, pl, npat, P.nx, P.ny, ng, native=True)
         fdtd_b(0.5 * dt); guards(B)
         fdtd_e(0.5 * dt); guards(E)
@@ -171,9 +206,9 @@ def cpu_baseline(args):
         one_step()
         steps += 1
     el = time.perf_counter() - t0
-    # how the port compares with the reference's own compiled kernel: measured in the build container, where both
-    # exist (python -m oracle.cpu_ratio -> profiles/r03_cpu_port_vs_reference.txt, which names the sha256 of the
-    # oracle source it timed); the reference cannot travel.  Refused when oracle/picoracle.c changed since.
+    # how the port compares with the reference's own compiled kernel: measured in the build container on the same cores
+    # (python -m oracle.cpu_ratio -> profiles/r03_cpu_port_vs_reference.txt, which names the sha256 of the oracle source it
+    # timed).  Refused when oracle/picoracle.c changed since.
     ratio, ratio_src = None, "profiles/r03_cpu_port_vs_reference.txt missing"
     try:
         import hashlib
@@ -185,17 +220,21 @@ def cpu_baseline(args):
         if rec and rec[0] == sha:
             ratio = float(txt.strip().splitlines()[-1].split("=")[-1])
             ratio_src = (f"recorded in the build container (python -m oracle.cpu_ratio -> "
-                         f"profiles/r03_cpu_port_vs_reference.txt @ oracle/picoracle.c {sha}); the reference cannot travel")
+                         f"profiles/r03_cpu_port_vs_reference.txt @ oracle/picoracle.c {sha}: both kernels on the same cores)")
         else:
             ratio_src = "recorded ratio is for another oracle/picoracle.c: re-run python -m oracle.cpu_ratio"
     except (OSError, ValueError) as e:
         ratio_src = f"no recorded ratio ({e.__class__.__name__})"
-    return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+    kernel = ("the reference's unified_boris_pusher_cpu_2d (oracle/_ref, " +
+              ("-march=native of the build host" if flavour == "native" else "-march=x86-64-v3 build") +
+              "; field half steps / guard copies: oracle/picoracle.c)") if ref is not None else \
+        "oracle/picoracle.c -O3 -march=native"
+    return {"value": n * steps / el, "unit": "particle-updates/s", "cores": threads,
+            "kind": "reference" if ref is not None else "port",
             "port_over_reference_same_cores": ratio, "port_over_reference_source": ratio_src,
             "parity_c1": parity_c1(),
             "sample": f"{nx}x{ny} cells, {ppc} ppc ({n} particles, {npat} patches of 32x32), {steps} steps "
-                      f"of push+deposit+FDTD+guard sync (no sort / migration), oracle/picoracle.c "
-                      f"-O3 -march=native, {threads} OpenMP threads"}
+                      f"of push+deposit+FDTD+guard sync (no sort / migration), {kernel}, {threads} OpenMP threads"}
 
 
 def source_hash():
@@ -213,7 +252,7 @@ def recorded_traffic(args, kernel_prefix):
     """HBM bytes of one K1 launch from the committed rocprofv3 --pmc passes (tools/prof_pmc.sh ->
     tools/make_traffic_json.py): counters cannot be read from inside this process.  Refused (None + the reason)
     when the file was recorded for another kernel, another workload or other kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r03_k1_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_k1_traffic.json")
     try:
         with open(path) as fh:
             tr = json.load(fh)
@@ -225,7 +264,7 @@ def recorded_traffic(args, kernel_prefix):
         return None, "traffic profile is for another kernel"
     if tr.get("source_sha256_16") != source_hash():
         return None, "traffic profile predates the current kernel sources: re-run tools/prof_pmc.sh"
-    return tr["traffic_bytes_per_launch"], f"recorded: profiles/r03_k1_traffic.json @ sources {tr['source_sha256_16']}"
+    return tr["traffic_bytes_per_launch"], f"recorded: profiles/r04_k1_traffic.json @ sources {tr['source_sha256_16']}"
 
 
 class StageTimer:
@@ -381,10 +420,10 @@ def extra_c5(steps=40, warm=12):
 
 def recorded_traffic_3d():
     """HBM bytes per algorithmic byte of the K1-3D launch of THIS leg (e- + p in one launch) from the committed counter
-    passes (tools/prof_pmc_c5.sh on tools/bench_c5leg.py -> profiles/r03_k13d_c5_traffic.json); refused for other sources"""
+    passes (tools/prof_pmc_c5.sh on tools/bench_c5leg.py -> profiles/r04_k13d_c5_traffic.json); refused for other sources"""
     import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_k13d_c5_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r04_k13d_c5_traffic.json")) as fh:
             tr = json.load(fh)
         h = hashlib.sha256()
         for f in ("lambdapic_amd/csrc/lpa_particles3d.hip", "lambdapic_amd/csrc/lpa_common.hpp"):
@@ -393,7 +432,7 @@ def recorded_traffic_3d():
         if tr.get("source_sha256_16") != h.hexdigest()[:16]:
             return {"traffic_per_algorithmic_byte": None, "traffic_source": "3-D traffic profile predates the kernel sources"}
         return {"traffic_per_algorithmic_byte": tr["traffic_per_algorithmic_byte"],
-                "traffic_source": f"recorded: profiles/r03_k13d_c5_traffic.json (this leg, tools/prof_pmc_c5.sh) @ sources {tr['source_sha256_16']}"}
+                "traffic_source": f"recorded: profiles/r04_k13d_c5_traffic.json (this leg, tools/prof_pmc_c5.sh) @ sources {tr['source_sha256_16']}"}
     except Exception as e:   # noqa: BLE001
         return {"traffic_per_algorithmic_byte": None, "traffic_source": f"no 3-D traffic profile ({e.__class__.__name__})"}
 

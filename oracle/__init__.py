@@ -281,14 +281,15 @@ def ref_available() -> bool:
     return any((HERE / "_ref").glob("pusher/unified_pusher_2d*.so"))
 
 
-def ref_module(group: str, name: str):
+def ref_module(group: str, name: str, portable: bool = False):
     """import oracle/_ref/<group>/<name>.<EXT_SUFFIX> as a CPython module (no reference source
-    is read at run time -- these are binaries this repo's Makefile compiled)."""
+    is read at run time -- these are binaries this repo's Makefile compiled).  ``portable``: the -march=x86-64-v3 build
+    (oracle/_ref/portable/, `make ref_portable`) for hosts whose CPU is not the build container's."""
     import importlib.machinery
     import importlib.util
     import sysconfig
 
-    path = HERE / "_ref" / group / (name + sysconfig.get_config_var("EXT_SUFFIX"))
+    path = HERE / "_ref" / ("portable/" if portable else "") / group / (name + sysconfig.get_config_var("EXT_SUFFIX"))
     if not path.exists():
         raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` in the build container")
     loader = importlib.machinery.ExtensionFileLoader(name, str(path))

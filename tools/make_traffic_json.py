@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_k1_traffic.json from the 'fetch' and 'write' passes of tools/prof_pmc.sh.
+"""profiles/<round>_k1_traffic.json (LPA_ROUND, default r04) from the 'fetch' and 'write' passes of tools/prof_pmc.sh.
 
 usage: tools/make_traffic_json.py <pmc-outdir> [2d|3d]   (run where the passes were collected, or on their merged
 gpurun_out copy; 3d = the passes of tools/prof_pmc3d.sh -> profiles/r03_k13d_traffic.json).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KB; on gfx950
@@ -54,6 +54,7 @@ if mode == "c5":
                                  "both species in one launch", "alive": alive, "algorithmic_bytes_per_launch": 121.0 * alive}
     out["source"] = "tools/prof_pmc_c5.sh passes 'fetch' and 'write', tools/bench_c5leg.py 6 12"
     out["traffic_per_algorithmic_byte"] = out["traffic_bytes_per_launch"] / (121.0 * alive)
-name = {"2d": "r03_k1_traffic.json", "3d": "r03_k13d_traffic.json", "c5": "r03_k13d_c5_traffic.json"}[mode]
+rnd = os.environ.get("LPA_ROUND", "r04")
+name = {"2d": f"{rnd}_k1_traffic.json", "3d": f"{rnd}_k13d_traffic.json", "c5": f"{rnd}_k13d_c5_traffic.json"}[mode]
 json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))
