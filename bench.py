@@ -803,10 +803,12 @@ def main():
     ap.add_argument("--inv-gamma", default="recomputed", choices=["recomputed", "streamed"],
                     help="1 / gamma of a particle: recomputed from its momenta by the fused kernels (default; two of the "
                          "thirteen attribute streams go) or loaded and stored like the reference's kernel")
-    ap.add_argument("--run-steps", action="store_true",
-                    help="time engine.run_steps(K) instead of K engine.step() calls: the E guard stage after the second E "
-                         "half step is left to the next step's first one (same state after K steps; one launch and, between "
-                         "slabs, one message round less per step).  Default at N > 1.")
+    ap.add_argument("--per-step", action="store_true",
+                    help="time K engine.step() calls instead of engine.run_steps(K) (the default): run_steps does the second E "
+                         "half step of a step and the first one of the next in ONE sweep (same B, same J, cell-local update: "
+                         "the two sweeps bit for bit) with one guard stage -- same state after K steps, one field sweep, one "
+                         "launch and, between slabs, one message round less per step")
+    ap.add_argument("--run-steps", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--rho", default="continuity", choices=["continuity", "deposited"],
                     help="rho between two sorts: advanced with the discrete continuity equation (default; the fused "
                          "kernel skips its rho atomics, a real deposit re-anchors rho on every sort step) or deposited "
@@ -907,7 +909,7 @@ def main():
     torch.cuda.synchronize(device)
     comm.barrier()
     torch.cuda.synchronize(device)
-    run_steps = args.run_steps or comm.size > 1
+    run_steps = not args.per_step
     t0 = time.perf_counter()
     if run_steps:
         eng.run_steps(args.steps, dt)
@@ -944,8 +946,9 @@ def main():
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
                    "comm": comm_note, "world": world, "rccl_version": rccl_version,
-                   "e_guards": "once per step (engine.run_steps: the guard stage after E2 is the next step's after E1)"
-                               if run_steps else "after both E half steps",
+                   "e_half_steps": "engine.run_steps: the second E half step of a step and the first of the next are one "
+                                   "sweep (two sequential updates per cell) + one guard stage; the last step is a plain one"
+                                   if run_steps else "two sweeps, two guard stages per step (engine.step)",
                    "part_eb_writeback": False,
                    # rho between two sorts (lambdapic_amd/rho.py): "continuity" = advanced from the folded currents,
                    # re-anchored by a real deposit on every sort step; "deposited" = the reference's kernel

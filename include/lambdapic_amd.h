@@ -708,6 +708,12 @@ typedef struct {
  * its own guard stage (simulation.py:1112-1118, then :946-952 of the following step) and the E update itself never reads
  * E guards -- one launch and, between slabs, one message round less per step.  The LAST step of such a run must not set it. */
 #define LPA_STEP_DEFER_E2_GUARDS 1
+/* LPA_STEP_DEFER_E2: LPA_STAGE_E2 is left out altogether -- the caller's NEXT lpa_step starts with LPA_STEP_E1_DOUBLE, whose
+ * LPA_STAGE_E1 applies both half steps in one sweep (B and J are the same for both; a cell's E update reads no other cell's
+ * E, so two sequential updates in registers are the two sweeps bit for bit, for a third of the pair's E traffic) before its
+ * guard stage.  Between the two calls E is half a step behind: nothing may read it (engines: run_steps). */
+#define LPA_STEP_DEFER_E2 2
+#define LPA_STEP_E1_DOUBLE 4
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

@@ -37,8 +37,9 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
 
 // ---- internal helpers shared between the translation units (not part of the C ABI; used by lpa_step) --------------
 // one E / B half step with the periodic guard wrap of the axes in `wrap` fused into the sweep (lpa_fields.hip)
+// (`twice`: the E sweep applies two half steps in one pass -- see FDTD_TWICE in lpa_fields.hip)
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              void *stream);
+              int twice, void *stream);
 // the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
 // [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
 int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,

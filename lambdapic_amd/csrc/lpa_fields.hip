@@ -24,6 +24,7 @@ extern "C" int lpa_version(void) { return 100; }
 __device__ __forceinline__ void store3_wrapped(const GridV &g, double *fa, double *fb, double *fc, long c, int i, int j,
                                                int k, int axes, double va, double vb, double vc) {
     fa[c] = va; fb[c] = vb; fc[c] = vc;
+    axes &= 7;                       // (bit 8 of the sweeps' `wrap` argument: FDTD_TWICE)
     if (!axes) return;
     const int ng = g.ng;
     const bool d3 = g.NZ > 1;
@@ -45,6 +46,12 @@ __device__ __forceinline__ void store3_wrapped(const GridV &g, double *fa, doubl
     }
 }
 
+// bit 8 of the E sweeps' `wrap` argument: TWO half steps in one sweep (lpa_step, LPA_STEP_E1_DOUBLE: the E half step
+// that ended the previous step was left out -- no reader in between -- and is done here together with this step's
+// first one: B and J are the same for both, every cell's update reads only its own E, so the two sequential updates in
+// registers are the two sweeps, bit for bit, for a third of the E traffic of the pair)
+constexpr int FDTD_TWICE = 256;
+
 // =====================================================================================================
 // FDTD.  Restates update_efield_2d / update_bfield_2d (core/maxwell/cpu.py:9-35) on the conventional
 // layout: interior node (i,j) is at [i+ng][j+ng]; i-1 at i=0 is the low guard, i+1 at nx-1 the high one.
@@ -57,9 +64,11 @@ __global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double 
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xm = c - g.NY, ym = c - 1;
     double bzc = g.bz[c];
-    double ex = g.ex[c] + (bfac * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c]);
-    double ey = g.ey[c] + (bfac * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c]);
-    double ez = g.ez[c] + (bfac * ((g.by[c] - g.by[xm]) / g.dx - (g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c]);
+    const double kx = bfac * ((bzc - g.bz[ym]) / g.dy) - jfac * g.jx[c];
+    const double ky = bfac * (-(bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    const double kz = bfac * ((g.by[c] - g.by[xm]) / g.dx - (g.bx[c] - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+    double ex = g.ex[c] + kx, ey = g.ey[c] + ky, ez = g.ez[c] + kz;
+    if (wrap & FDTD_TWICE) { ex += kx; ey += ky; ez += kz; }
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
@@ -85,9 +94,11 @@ __global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double 
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
     long xm = c - sx, ym = c - sy, zm = c - 1;
     double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
-    double ex = g.ex[c] + (bfac * ((bzc - g.bz[ym]) / g.dy - (byc - g.by[zm]) / g.dz) - jfac * g.jx[c]);
-    double ey = g.ey[c] + (bfac * ((bxc - g.bx[zm]) / g.dz - (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c]);
-    double ez = g.ez[c] + (bfac * ((byc - g.by[xm]) / g.dx - (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c]);
+    const double kx = bfac * ((bzc - g.bz[ym]) / g.dy - (byc - g.by[zm]) / g.dz) - jfac * g.jx[c];
+    const double ky = bfac * ((bxc - g.bx[zm]) / g.dz - (bzc - g.bz[xm]) / g.dx) - jfac * g.jy[c];
+    const double kz = bfac * ((byc - g.by[xm]) / g.dx - (bxc - g.bx[ym]) / g.dy) - jfac * g.jz[c];
+    double ex = g.ex[c] + kx, ey = g.ey[c] + ky, ez = g.ez[c] + kz;
+    if (wrap & FDTD_TWICE) { ex += kx; ey += ky; ez += kz; }
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, k, wrap, ex, ey, ez);
 }
 
@@ -314,28 +325,38 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bf
     double bxc = g.bx[c], byc = g.by[c], bzc = g.bz[c];
     double bz_xm = g.bz[xm], bz_ym = g.bz[ym], by_xm = g.by[xm], bx_ym = g.bx[ym];
     double ex = g.ex[c], ey = g.ey[c], ez = g.ez[c];
-    ex += bfy * ((bzc - bz_ym) / g.dy) - jfac * g.jx[c];
-    ey += bfx * (-(bzc - bz_xm) / g.dx) - jfac * g.jy[c];
-    ez += bfx * ((byc - by_xm) / g.dx) - bfy * ((bxc - bx_ym) / g.dy) - jfac * g.jz[c];
-    int l, nl;
-    if (int w = cpml_layer(ax, i, l, nl)) {          // cpml.py:531-548
-        double *pa_ = w == 1 ? ax.pa_lo : ax.pa_hi, *pb_ = w == 1 ? ax.pb_lo : ax.pb_hi;
-        long ps = (long)l * g.ny + j;
-        double b = ax.bco[i], cc = ax.cco[i];
-        double pa = b * pa_[ps] + cc * (bzc - bz_xm);
-        double pb = b * pb_[ps] + cc * (byc - by_xm);
-        pa_[ps] = pa; pb_[ps] = pb;
-        ey -= fac * pa; ez += fac * pb;
+    const double kx = bfy * ((bzc - bz_ym) / g.dy) - jfac * g.jx[c];
+    const double ky = bfx * (-(bzc - bz_xm) / g.dx) - jfac * g.jy[c];
+    const double kz = bfx * ((byc - by_xm) / g.dx) - bfy * ((bxc - bx_ym) / g.dy) - jfac * g.jz[c];
+    int lx_, nlx, ly_, nly;
+    const int wx = cpml_layer(ax, i, lx_, nlx), wy = cpml_layer(ay, j, ly_, nly);
+    double *pax = nullptr, *pbx = nullptr, *pay = nullptr, *pby = nullptr;
+    double pa_x = 0.0, pb_x = 0.0, pa_y = 0.0, pb_y = 0.0, bx_ = 0.0, cx_ = 0.0, by_ = 0.0, cy_ = 0.0;
+    if (wx) {                                        // cpml.py:531-548
+        const long ps = (long)lx_ * g.ny + j;
+        pax = (wx == 1 ? ax.pa_lo : ax.pa_hi) + ps; pbx = (wx == 1 ? ax.pb_lo : ax.pb_hi) + ps;
+        pa_x = *pax; pb_x = *pbx; bx_ = ax.bco[i]; cx_ = ax.cco[i];
     }
-    if (int w = cpml_layer(ay, j, l, nl)) {          // cpml.py:569-586
-        double *pa_ = w == 1 ? ay.pa_lo : ay.pa_hi, *pb_ = w == 1 ? ay.pb_lo : ay.pb_hi;
-        long ps = (long)i * nl + l;
-        double b = ay.bco[j], cc = ay.cco[j];
-        double pa = b * pa_[ps] + cc * (bzc - bz_ym);
-        double pb = b * pb_[ps] + cc * (bxc - bx_ym);
-        pa_[ps] = pa; pb_[ps] = pb;
-        ex += fac * pa; ez -= fac * pb;
+    if (wy) {                                        // cpml.py:569-586
+        const long ps = (long)i * nly + ly_;
+        pay = (wy == 1 ? ay.pa_lo : ay.pa_hi) + ps; pby = (wy == 1 ? ay.pb_lo : ay.pb_hi) + ps;
+        pa_y = *pay; pb_y = *pby; by_ = ay.bco[j]; cy_ = ay.cco[j];
     }
+    for (int rep = (wrap & FDTD_TWICE) ? 2 : 1; rep > 0; rep--) {     // (FDTD_TWICE: two half steps, see above)
+        ex += kx; ey += ky; ez += kz;
+        if (wx) {
+            pa_x = bx_ * pa_x + cx_ * (bzc - bz_xm);
+            pb_x = bx_ * pb_x + cx_ * (byc - by_xm);
+            ey -= fac * pa_x; ez += fac * pb_x;
+        }
+        if (wy) {
+            pa_y = by_ * pa_y + cy_ * (bzc - bz_ym);
+            pb_y = by_ * pb_y + cy_ * (bxc - bx_ym);
+            ex += fac * pa_y; ez -= fac * pb_y;
+        }
+    }
+    if (wx) { *pax = pa_x; *pbx = pb_x; }
+    if (wy) { *pay = pa_y; *pby = pb_y; }
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
@@ -436,22 +457,25 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bf
     double dbz_y = bzc - g.bz[c - sy], dbx_y = bxc - g.bx[c - sy];
     double dby_z = byc - g.by[c - 1], dbx_z = bxc - g.bx[c - 1];
     double ex = g.ex[c], ey = g.ey[c], ez = g.ez[c];
-    ex += (bfy * dbz_y / g.dy - bfz * dby_z / g.dz) - jfac * g.jx[c];
-    ey += (bfz * dbx_z / g.dz - bfx * dbz_x / g.dx) - jfac * g.jy[c];
-    ez += (bfx * dby_x / g.dx - bfy * dbx_y / g.dy) - jfac * g.jz[c];
+    const double kx = (bfy * dbz_y / g.dy - bfz * dby_z / g.dz) - jfac * g.jx[c];
+    const double ky = (bfz * dbx_z / g.dz - bfx * dbz_x / g.dx) - jfac * g.jy[c];
+    const double kz = (bfx * dby_x / g.dx - bfy * dbx_y / g.dy) - jfac * g.jz[c];
     int l, nl;
     double pa, pb;
-    if (int w = cpml_layer(ax, i, l, nl)) {   // psi(ey,ez) <- (bz,by); ey -=, ez +=   (cpml.py:609-628)
-        psi_step(ax, w, psi_index_3d(0, i, j, k, l, nl, g.ny, g.nz), i, dbz_x, dby_x, pa, pb);
-        ey -= fac * pa; ez += fac * pb;
-    }
-    if (int w = cpml_layer(ay, j, l, nl)) {   // psi(ex,ez) <- (bz,bx); ex +=, ez -=   (:651-669)
-        psi_step(ay, w, psi_index_3d(1, i, j, k, l, nl, g.ny, g.nz), j, dbz_y, dbx_y, pa, pb);
-        ex += fac * pa; ez -= fac * pb;
-    }
-    if (int w = cpml_layer(az, k, l, nl)) {   // psi(ex,ey) <- (by,bx); ex -=, ey +=   (:691-710)
-        psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dby_z, dbx_z, pa, pb);
-        ex -= fac * pa; ey += fac * pb;
+    for (int rep = (wrap & FDTD_TWICE) ? 2 : 1; rep > 0; rep--) {     // (FDTD_TWICE: two half steps; psi_step re-reads what it wrote)
+        ex += kx; ey += ky; ez += kz;
+        if (int w = cpml_layer(ax, i, l, nl)) {   // psi(ey,ez) <- (bz,by); ey -=, ez +=   (cpml.py:609-628)
+            psi_step(ax, w, psi_index_3d(0, i, j, k, l, nl, g.ny, g.nz), i, dbz_x, dby_x, pa, pb);
+            ey -= fac * pa; ez += fac * pb;
+        }
+        if (int w = cpml_layer(ay, j, l, nl)) {   // psi(ex,ez) <- (bz,bx); ex +=, ez -=   (:651-669)
+            psi_step(ay, w, psi_index_3d(1, i, j, k, l, nl, g.ny, g.nz), j, dbz_y, dbx_y, pa, pb);
+            ex += fac * pa; ez -= fac * pb;
+        }
+        if (int w = cpml_layer(az, k, l, nl)) {   // psi(ex,ey) <- (by,bx); ex -=, ey +=   (:691-710)
+            psi_step(az, w, psi_index_3d(2, i, j, k, l, nl, g.ny, g.nz), k, dby_z, dbx_z, pa, pb);
+            ex -= fac * pa; ey += fac * pb;
+        }
     }
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, k, wrap, ex, ey, ez);
 }
@@ -526,8 +550,10 @@ extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_
 // one half step of E or B over the slab with the guard wrap of the axes in `wrap` fused in (lpa_step); ax[]: the fused
 // CPML descriptors, all NULL = the plain Yee update
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              void *stream) {
+              int twice, void *stream) {
     LPA_REQUIRE(g && g->nx >= g->ng && g->ny >= g->ng && (dim == 2 || g->nz >= g->ng), "lpai_fdtd: slab thinner than the guard");
+    LPA_REQUIRE(!twice || efield, "lpai_fdtd: only the E sweep does two half steps at once");
+    wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0);
     const bool cpml = ax && ax[0];
     if (dim == 2) {
         if (efield) return cpml ? fdtd_e_cpml_fused_2d(g, dt, eps0, ax[0], ax[1], wrap, stream) : fdtd_e_2d(g, dt, eps0, wrap, stream);

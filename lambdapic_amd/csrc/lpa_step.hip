@@ -42,8 +42,8 @@ static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx,
     return lpa_comm_exchange(sl->comm, m, nm, st);
 }
 
-static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st) {
-    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, st);
+static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false) {
+    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, st);
 }
 
 static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
@@ -288,8 +288,10 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
         switch (stage) {
         case LPA_STAGE_E1:
         case LPA_STAGE_E2: {    // update_efield(dt / 2) + sync_guard_fields(E): simulation.py:946-952, 1112-1118
+            if (stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2)) break;     // (done by the next call's LPA_STAGE_E1)
             const bool defer = stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2_GUARDS);
-            e = step_fields(d, true, defer ? 0 : d->local_axes, stream);      // (the periodic guard wrap rides in the sweep)
+            const bool twice = stage == LPA_STAGE_E1 && (d->flags & LPA_STEP_E1_DOUBLE);
+            e = step_fields(d, true, defer ? 0 : d->local_axes, stream, twice);      // (the periodic guard wrap rides in the sweep)
             if (!e && slab && !defer) e = slab_exchange_guards(d, 1, false, stream);
             break;
         }

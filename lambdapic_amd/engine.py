@@ -1116,6 +1116,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             self._step_segments(dt, defer_e2)
             return
         E, B = ("ex", "ey", "ez"), ("bx", "by", "bz")
+        self._flush_e2()            # (the per-stage path neither defers nor doubles: complete what a fused step left)
+        defer_e2 = False
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(E)
         self.update_bfield(0.5 * dt)
@@ -1166,7 +1168,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             laser(self, dt)
             self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
         self._exchange_guards(2)                                    # (+ the jx plane; completes rho)
-        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)
+        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)      # (deferred: nothing is launched, the next E1 doubles)
         if not defer_e2:
             self._exchange_guards(1)
 
@@ -1202,6 +1204,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
     def diagnostics(self, reduce=False):
         """dict of field energy (E, B parts), total charge, current sums, kinetic energy and live
         count per species -- local to this rank; ``reduce=True`` sums over the ranks (one all-reduce)."""
+        self._flush_e2()
         st = self.stream
         self.check_migration()
         self._diag.zero_()

@@ -1039,6 +1039,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             self._step_segments(dt, laser, defer_e2)
             return
         L, st, g = self.L, self.stream, self._g()
+        self._flush_e2()            # (the per-stage path neither defers nor doubles: complete what a fused step left)
+        defer_e2 = False
         self.update_efield(0.5 * dt)
         self.sync_guard_fields(1)
         self.update_bfield(0.5 * dt)
@@ -1078,7 +1080,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             laser(self, dt)
             self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
         self._exchange_guards(2)
-        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)
+        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)      # (deferred: nothing is launched, the next E1 doubles)
         if not defer_e2:
             self._exchange_guards(1)
 
@@ -1094,6 +1096,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def diagnostics(self, reduce=False):
         """this rank's share; ``reduce=True`` sums over the ranks (one all-reduce)"""
+        self._flush_e2()
         self.check_migration()
         self._diag.zero_()
         check(self.L.lpa_diag_fields(self._g(), self.eps0, self.mu0, self._diag.data_ptr(), self.stream), "diag")

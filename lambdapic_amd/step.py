@@ -35,6 +35,16 @@ class FusedStepMixin:
     ``_cpml_axes``, ``pml``, ``fused_cpml``, ``local_axes``, ``eps0``, ``absorb`` and the rho mixin"""
 
     fused_step = True          # steps go through lpa_step (False: the per-stage calls)
+    _e2_pending = False        # the last step left its second E half step to the next one's first (run_steps)
+    _e2_dt = 0.0
+
+    def _flush_e2(self):
+        """complete a deferred second E half step now (with its guard stage): whoever is about to read or advance the
+        fields outside ``run_steps`` sees the state a plain ``step()`` leaves"""
+        if self._e2_pending:
+            self._e2_pending = False
+            self.update_efield(0.5 * self._e2_dt)
+            self.sync_guard_fields(("ex", "ey", "ez") if self.dim == 2 else 1)
     fuse_species = True        # 3-D: every tile-ordered species in ONE launch (lpa_push_deposit_tiled_multi_3d)
 
     def can_fuse(self):
@@ -51,8 +61,9 @@ class FusedStepMixin:
     def step_stages(self, dt, first, last, defer_e2=False):
         """enqueue stages ``first .. last`` (LPA_STAGE_*) of one step in one call.  The stores must be sorted when
         they are due BEFORE LPA_STAGE_RESET is reached (``sort_due_species``); the rho mode of the step is decided
-        when LPA_STAGE_RESET is part of the range and closed when LPA_STAGE_FOLD is.  ``defer_e2``: LPA_STAGE_E2 leaves
-        the E guards to the next step's LPA_STAGE_E1 (LPA_STEP_DEFER_E2_GUARDS: the caller runs another step next)."""
+        when LPA_STAGE_RESET is part of the range and closed when LPA_STAGE_FOLD is.  ``defer_e2``: LPA_STAGE_E2 is left
+        to the next step's LPA_STAGE_E1, which then applies both half steps in one sweep (LPA_STEP_DEFER_E2 /
+        LPA_STEP_E1_DOUBLE: the caller runs another step next and nothing reads E in between)."""
         if not self.can_fuse():
             raise _lib.LpaError("lpa_step drives the fused CPML sweeps")
         native = self.native_slab()
@@ -62,7 +73,13 @@ class FusedStepMixin:
         d = _lib.lpa_step_desc()
         d.grid = self._grid_struct()
         d.dim, d.local_axes, d.dt, d.eps0 = self.dim, self.local_axes, dt, self.eps0
-        d.flags = _lib.LPA_STEP_DEFER_E2_GUARDS if defer_e2 else 0
+        # a deferred second E half step (run_steps): left out at the end of one step, done together with the first half
+        # step of the next one in a single sweep
+        d.flags = 0
+        if defer_e2 and last >= _lib.LPA_STAGE_E2:
+            d.flags |= _lib.LPA_STEP_DEFER_E2
+        if first <= _lib.LPA_STAGE_E1 and self._e2_pending:
+            d.flags |= _lib.LPA_STEP_E1_DOUBLE
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):
@@ -132,6 +149,10 @@ class FusedStepMixin:
         check(self.L.lpa_step(C.byref(d), first, last, stream.cuda_stream), "lpa_step")
         if edge_events and native and push and fold and slab.overlap_cols > 0:
             self.kernel_events.extend(edge_events)        # (the edge and the interior launch of a species add up)
+        if d.flags & _lib.LPA_STEP_E1_DOUBLE:
+            self._e2_pending = False
+        if d.flags & _lib.LPA_STEP_DEFER_E2:
+            self._e2_pending, self._e2_dt = True, dt
         self._step_keep = (d, arr, keep)      # alive until the next call (the launches copy what they need)
         if push:
             self._dt_step = dt
@@ -150,9 +171,14 @@ class FusedStepMixin:
         self.step_stages(dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2, defer_e2)
 
     def run_steps(self, nsteps, dt, laser=None):
-        """``nsteps`` steps back to back with nothing reading the fields in between: the E guards are brought up to date
-        once per step instead of twice (after E1 of the following step; the last step leaves them current) -- one launch
-        and, between slabs, one message round less per step; the state after the call is that of ``nsteps`` ``step()``s."""
-        for k in range(int(nsteps)):
-            self.step(dt, laser=laser, defer_e2=k < nsteps - 1) if laser is not None else \
-                self.step(dt, defer_e2=k < nsteps - 1)
+        """``nsteps`` steps back to back with nothing reading the fields in between: the second E half step of a step and
+        the first one of the next are ONE sweep (same B, same J; a cell's E update reads no other cell's E: two sequential
+        updates in registers = the two sweeps bit for bit) followed by one guard stage -- one field sweep, one launch and,
+        between slabs, one message round less per step.  The last step is a plain one: the state after the call is that
+        of ``nsteps`` ``step()``s."""
+        try:
+            for k in range(int(nsteps)):
+                self.step(dt, laser=laser, defer_e2=k < nsteps - 1) if laser is not None else \
+                    self.step(dt, defer_e2=k < nsteps - 1)
+        finally:
+            self._flush_e2()          # (an exception in the middle must not leave E half a step behind)

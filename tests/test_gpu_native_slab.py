@@ -249,3 +249,75 @@ def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overl
     for a in f:
         lo, hi = (3, 3 + N3[0]) if a == "rho" else (0, N3[0] + 6)
         assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
+
+
+# ---- run_steps with CPML layers: the doubled E half step carries the psi recursions of both half steps ---------------------
+@pytest.mark.parametrize("dim", [2, 3])
+def test_run_steps_equals_steps_with_cpml(dim):
+    from lambdapic_amd import constants
+    lam = 0.8e-6
+    rng = np.random.default_rng(3)
+
+    def build():
+        if dim == 2:
+            from lambdapic_amd.engine import PicEngine2D
+            nx, ny, dx = 64, 64, lam / 16
+            dt = 0.95 / (CL * np.sqrt(2) / dx)
+            bc = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax")}
+            eng = PicEngine2D(nx, ny, dx, dx, device="cuda:0", boundary_conditions=bc, cpml_thickness=6, sort_interval=4,
+                              block_particles=1024)
+            view = eng.grid.view
+            shape = (nx, ny)
+        else:
+            from lambdapic_amd.engine3d import PicEngine3D
+            nx, ny, dx = 32, 32, lam / 10
+            dt = 0.95 / (CL * np.sqrt(3) / dx)
+            bc = {k: "pml" for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
+            eng = PicEngine3D(nx, ny, 32, dx, dx, dx, 3, sort_interval=4, boundary_conditions=bc, cpml_thickness=4)
+            view = eng.view
+            shape = (nx, ny, 32)
+        g = np.random.default_rng(9)
+        inner = tuple(slice(3, 3 + m) for m in shape)
+        # a smooth blob of E / B that reaches the layers within the run
+        grids = np.meshgrid(*[np.arange(m) - m / 2 for m in shape], indexing="ij")
+        blob = np.exp(-sum(v ** 2 for v in grids) / 60.0)
+        for a, amp in (("ez", 1e11), ("ey", 5e10), ("by", 300.0), ("bz", -200.0)):
+            view(a)[inner] = torch.from_numpy(amp * blob * (1 + 0.1 * g.normal(size=shape))).cuda()
+        n = 20000
+        pos = [rng.uniform(0.3, 0.7, n) * m * dx for m in shape]
+        u = rng.normal(size=(3, n)) * 0.2
+        w = np.full(n, 1e27 * dx ** dim / 4)
+        if dim == 2:
+            eng.add_species(-constants.E_CHARGE, constants.M_E, capacity=2 * n)
+            cs = eng.species[0].cset
+            for name, arr in (("x", pos[0]), ("y", pos[1]), ("ux", u[0]), ("uy", u[1]), ("uz", u[2]),
+                              ("inv_gamma", 1 / np.sqrt(1 + (u ** 2).sum(0))), ("w", w)):
+                cs.arr(name)[:n] = torch.from_numpy(arr).cuda()
+            cs.id[:n] = torch.arange(n, device="cuda:0")
+            eng.species[0].n = n
+        else:
+            data = torch.full((8, 2 * n), float("nan"), dtype=torch.float64, device="cuda:0")
+            data[:, :n] = torch.from_numpy(np.concatenate([np.stack(pos), u, (1 / np.sqrt(1 + (u ** 2).sum(0)))[None], w[None]])).cuda()
+            eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
+        return eng, dt, view
+
+    out = []
+    for batched in (False, True):
+        rng = np.random.default_rng(3)
+        eng, dt, view = build()
+        if batched:
+            for _ in range(4):
+                eng.run_steps(4, dt)
+        else:
+            for _ in range(16):
+                eng.step(dt)
+        torch.cuda.synchronize()
+        psi = torch.cat([torch.cat([l["psi_a"].reshape(-1), l["psi_b"].reshape(-1)]) for l in eng.pml.layers]).cpu().numpy()
+        out.append(({a: view(a).cpu().numpy() for a in ("ex", "ey", "ez", "bx", "by", "bz", "rho")}, psi,
+                    eng.diagnostics()))
+    (fa, pa, da), (fb, pb, db) = out
+    assert np.abs(pa).max() > 0 and da["nalive"] == db["nalive"]
+    # (two runs of the same problem: the order of the FP64 deposit atomics differs, nothing else)
+    assert _close(pb, pa, 1e-9)
+    for a in fa:
+        assert _close(fb[a], fa[a], 1e-9), a
