@@ -282,6 +282,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         """everything but handles and scratch: the library handle, sort workspaces (and with them the tilings),
         halo buffers, the side stream and cached ctypes descriptors are rebuilt on load; the grid, the particle
         stores and the CPML layers pickle as host arrays (device.py)"""
+        self._flush_e2()
         torch.cuda.synchronize(self.device)
         st = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
         st["device"] = str(self.device)
@@ -315,6 +316,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     # ---- Maxwell (MaxwellSolver2D.update_efield/bfield, core/maxwell/solver/solver.py:143-190) ----
     def update_efield(self, dt):
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         if self.pml is None:
             check(self.L.lpa_fdtd_e_2d(self._g(), dt, self.eps0, self.stream), "lpa_fdtd_e_2d")
             return
@@ -329,6 +331,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self._psi(True, dt)
 
     def update_bfield(self, dt):
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         if self.pml is None:
             check(self.L.lpa_fdtd_b_2d(self._g(), dt, self.stream), "lpa_fdtd_b_2d")
             return
@@ -430,6 +433,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         return run
 
     def sync_guard_fields(self, attrs):
+        self._flush_e2()
         which = (1 if any(a in attrs for a in ("ex", "ey", "ez")) else 0) | \
                 (2 if any(a in attrs for a in ("bx", "by", "bz")) else 0)
         st = self.stream
@@ -943,6 +947,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         the neighbour behind it, whose leading columns and guard they become (a rotation of the neighbour ring
         by one patch width); the leading rank's new columns start from zero fields and zero psi.  Particles behind the new
         bound follow their columns; on the trailing rank they are dropped."""
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         fwd = ncells > 0
         n, g = abs(int(ncells)), self.grid
         if not 0 < n <= g.nx - g.ng:

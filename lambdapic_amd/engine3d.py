@@ -269,6 +269,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def __getstate__(self):
         """see PicEngine2D.__getstate__: fields and the slots in use of every store as host arrays, handles,
         workspaces and tilings dropped (the first push after a load re-sorts)"""
+        self._flush_e2()
         torch.cuda.synchronize(self.device)
         st = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
         st["device"], st["buf_host"] = str(self.device), to_host(self.buf)
@@ -523,6 +524,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def sync_guard_fields(self, which):
         """``which``: 1 = E, 2 = B"""
+        self._flush_e2()
         st = self.stream
         check(self.L.lpa_guard_wrap(self._g(), which, self.local_axes, st), "lpa_guard_wrap")
         if self.comm.size > 1:
@@ -675,6 +677,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     # ---- Maxwell with CPML layers (update_e/bfield_cpml_patches_3d, cpml.py:477-530) --------------------
     def update_efield(self, dt):
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         g, st = self._g(), self.stream
         if self.pml is None:
             check(self.L.lpa_fdtd_e_3d(g, dt, self.eps0, st), "lpa_fdtd_e_3d")
@@ -690,6 +693,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self._psi(True, dt)
 
     def update_bfield(self, dt):
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         g, st = self._g(), self.stream
         if self.pml is None:
             check(self.L.lpa_fdtd_b_3d(g, dt, st), "lpa_fdtd_b_3d")
@@ -793,6 +797,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         """move every slab ``ncells`` to the right, or to the left when negative (see PicEngine2D.shift_window): field
         columns and the psi rows of the y / z layers that leave through a slab's trailing face travel to the neighbour
         behind it; the leading rank's new columns start from zero; particles behind the new bound follow or are dropped"""
+        self._flush_e2()      # (a deferred E half step of run_steps / Simulation.run is completed first)
         fwd = ncells > 0
         n, ng, nx = abs(int(ncells)), self.ng, self.n[0]
         if not 0 < n <= nx - ng:

@@ -402,6 +402,11 @@ class MPIFacade:
         return None
 
 
+def _NO_STOP():
+    """the default ``stop_callback`` of ``run`` (`simulation/simulation.py:858`: ``lambda: False``)"""
+    return False
+
+
 class MovingWindow:
     """Mirror of the reference's ``MovingWindow`` callback (`callback/utils.py:471-648`): stage
     ``start``; once ``sim.time >= start_time`` (default Lx / c) the x layers are removed and the
@@ -418,6 +423,19 @@ class MovingWindow:
         self.inject_particles, self.stop_inject_time = inject_particles, stop_inject_time
         self.total_shift = self.patch_this_shift = None
         self.num_shifts = 0
+
+    def fields_untouched(self, sim):
+        """will the NEXT call (stage 'start' of the step after this one) leave the field arrays and the layers alone?
+        (Simulation.run: the second E half step of this step may then be done together with the next step's first)"""
+        t = sim.time + sim.dt
+        start = sim.Lx / constants.C_LIGHT if self.start_time is None else self.start_time
+        if t < start:
+            return True
+        if self.num_shifts == 0:
+            return False               # its first active call removes the x layers
+        patch_Lx = sim.nx_per_patch * sim.dx
+        v = self.velocity(t) if callable(self.velocity) else self.velocity
+        return abs(self.patch_this_shift + v * sim.dt) < patch_Lx
 
     def __call__(self, sim):
         patch_Lx = sim.nx_per_patch * sim.dx
@@ -655,7 +673,28 @@ class Simulation:
 
     _INNER_STAGES = ("maxwell_1", "current_deposition", "qed_create_particles")
 
-    def _fused_step(self, table, unified=True):
+    def _can_defer_e2(self, table, last_step, stop_default):
+        """may this step leave its second E half step to the next step's first (engines: ``run_steps``)?  Only when nothing
+        can read or move E in between: no callback at 'maxwell_2' / 'end' of this step, the default ``stop_callback``, and at
+        'start' of the next step only callbacks that say they will leave the fields alone (``fields_untouched``);
+        interval FUNCTIONS cannot be asked about the next step: they block.  The next step need not be a fused one: the
+        per-stage facades complete a pending half step before they touch the fields (``engine._flush_e2``)."""
+        if last_step or not stop_default or not self.defer_e2:
+            return False
+        if any(self._triggered(table.get(st, [])) for st in ("maxwell_2", "end")):
+            return False
+        for cb in table.get("start", []):
+            iv = getattr(cb, "interval", 1)
+            if callable(iv):
+                return False
+            nxt = ((self.time + self.dt) % iv) < self.dt if isinstance(iv, float) else (self.itime + 1) % int(iv) == 0
+            if nxt and not (hasattr(cb, "fields_untouched") and cb.fields_untouched(self)):
+                return False
+        return True
+
+    defer_e2 = True        # Simulation.run may merge E half steps across the step boundary (see _can_defer_e2)
+
+    def _fused_step(self, table, unified=True, defer_e2=False):
         """When no callback is triggered between 'start' and '_laser' / 'maxwell_2' (the predicate the reference uses to
         skip work around callbacks, ``has_triggered_callbacks``, `simulation/simulation.py:1493-1508`) and every facade is
         enabled, the whole stage sequence of this step is enqueued by ONE engine call (``lpa_step``, step.py) -- two when a
@@ -673,14 +712,15 @@ class Simulation:
         from . import _lib
         lasers = bool(self._triggered(table.get("_laser", [])))
         if segments:      # slab ranks whose faces travel through torch.distributed: sub-ranges between the exchanges
-            eng._step_segments(self.dt, laser=(lambda e, dt: self._run_stage(table, "_laser")) if lasers else None)
+            eng._step_segments(self.dt, laser=(lambda e, dt: self._run_stage(table, "_laser")) if lasers else None,
+                               defer_e2=defer_e2)
             self.current_synced, self.ispec = True, None
             return True
-        eng.step_stages(self.dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_B2 if lasers else _lib.LPA_STAGE_E2)
+        eng.step_stages(self.dt, _lib.LPA_STAGE_E1, _lib.LPA_STAGE_B2 if lasers else _lib.LPA_STAGE_E2, defer_e2 and not lasers)
         self.current_synced, self.ispec = True, None
         if lasers:
             self._run_stage(table, "_laser")
-            eng.step_stages(self.dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2)
+            eng.step_stages(self.dt, _lib.LPA_STAGE_B2_GUARD, _lib.LPA_STAGE_E2, defer_e2)
         return True
 
     def sync_currents(self):
@@ -695,9 +735,10 @@ class Simulation:
         self.maxwell.update_bfield(0.5 * self.dt)
         self.patches.sync_guard_fields(["bx", "by", "bz"])
 
-    def run(self, nsteps=None, sim_time=None, callbacks=None, stop_callback=lambda: False):
+    def run(self, nsteps=None, sim_time=None, callbacks=None, stop_callback=None):
         if nsteps is not None and sim_time is not None:
             raise ValueError("Cannot specify both nsteps and sim_time in run() method")
+        stop_callback = _NO_STOP if stop_callback is None else stop_callback
         if not self.initialized:
             self.initialize()
         table = {}
@@ -734,7 +775,9 @@ class Simulation:
             self.engine.rho_continuity_blocked = not unified or bool(self._triggered(table.get("current_deposition", [])))
             self.engine.write_part_eb = self._host_callback_near(host_cbs, self.istep == self.itime_end - 1)
             self._run_stage(table, "start")
-            if self._fused_step(table, unified):
+            defer = self._can_defer_e2(table, self.istep == self.itime_end - 1, stop_callback is _NO_STOP) and \
+                not (restart_cb is not None and restart_cb._dump_requested)
+            if self._fused_step(table, unified, defer):
                 self._run_stage(table, "maxwell_2")
                 self._run_stage(table, "end")
                 if restart_cb is not None and restart_cb._dump_requested:
@@ -797,4 +840,5 @@ class Simulation:
             self.itime += 1
             if stop_callback():
                 return "stop by callback"
+        self.engine._flush_e2()
         self._run_stage(table, "final")

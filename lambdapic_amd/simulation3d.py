@@ -299,9 +299,14 @@ class Simulation3D:
             self.patches.sync_currents()
             self.current_synced = True
 
-    def run(self, nsteps=None, sim_time=None, callbacks=None, stop_callback=lambda: False):
+    _can_defer_e2 = Simulation._can_defer_e2
+    defer_e2 = True
+
+    def run(self, nsteps=None, sim_time=None, callbacks=None, stop_callback=None):
         if nsteps is not None and sim_time is not None:
             raise ValueError("Cannot specify both nsteps and sim_time in run() method")
+        from .simulation import _NO_STOP
+        stop_callback = _NO_STOP if stop_callback is None else stop_callback
         if not self.initialized:
             self.initialize()
         table = {}
@@ -326,12 +331,14 @@ class Simulation3D:
         restart_cb = next((cb for cb in callbacks or [] if cb.__class__.__name__ == "RestartDump"), None)
         E, B = ["ex", "ey", "ez"], ["bx", "by", "bz"]
         eng = self.engine
+        last_istep = self.itime + nsteps - 1
         for self.istep in range(self.itime, self.itime + nsteps):
             self.engine._dt_hint = self.dt      # (rho.py, the engines' first sort: the step's dt before any push)
             # a callback between the species' deposits reads per-species rho: that step deposits rho for real
             self.engine.rho_continuity_blocked = bool(self._triggered(table.get("current_deposition", [])))
             self._run_stage(table, "start")
-            if self._fused_step(table):
+            defer = self._can_defer_e2(table, self.istep == last_istep, stop_callback is _NO_STOP) and not (restart_cb is not None and restart_cb._dump_requested)
+            if self._fused_step(table, True, defer):
                 self._run_stage(table, "maxwell_2")
                 self._run_stage(table, "end")
                 if restart_cb is not None and restart_cb._dump_requested:
@@ -378,4 +385,5 @@ class Simulation3D:
             self.itime += 1
             if stop_callback():
                 return "stop by callback"
+        self.engine._flush_e2()
         self._run_stage(table, "final")

@@ -241,9 +241,10 @@ def test_one_call_per_step_equals_the_staged_loop():
         calls = {"lpa_step": 0, "end": 0, "maxwell_1": 0}
         inner = sim.engine.step_stages
 
-        def counted(dt, first, last):
+        def counted(dt, first, last, *more):
             calls["lpa_step"] += 1
-            return inner(dt, first, last)
+            calls["deferred"] = calls.get("deferred", 0) + int(bool(more and more[0]))
+            return inner(dt, first, last, *more)
 
         sim.engine.step_stages = counted
 
@@ -267,6 +268,9 @@ def test_one_call_per_step_equals_the_staged_loop():
     # 80 of the 90 steps went through lpa_step: two calls while the laser injects, one once it is disabled (the window
     # removed the x-min layer), none in the 10 steps with the 'maxwell_1' callback
     assert 80 <= ca["lpa_step"] <= 160 and a.window_shifts == b.window_shifts >= 2
+    # ... and many of them left their second E half step to the next step's first (Simulation._can_defer_e2): never before a
+    # step whose 'end' callback fires, never before a window shift
+    assert ca.get("deferred", 0) >= 40
     for name in ("ex", "ey", "ez", "bx", "by", "bz", "jx", "jy", "jz", "rho"):
         va, vb = a.engine.grid.view(name), b.engine.grid.view(name)
         assert (va - vb).abs().max().item() <= 1e-9 * max(vb.abs().max().item(), 1e-300), name

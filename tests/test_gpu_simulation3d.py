@@ -184,9 +184,9 @@ def test_one_call_per_step_and_one_launch_for_all_species_equal_the_staged_loop(
         calls = {"n": 0}
         inner = sim.engine.step_stages
 
-        def counted(dt, first, last):
+        def counted(dt, first, last, *more):
             calls["n"] += 1
-            return inner(dt, first, last)
+            return inner(dt, first, last, *more)
 
         sim.engine.step_stages = counted
         sim.run(40, callbacks=[GaussianLaser3D(a0=3.0, l0=LAM, w0=1.0e-6, ctau=0.8e-6, x0=1.6e-6)])
