@@ -10,7 +10,7 @@
 //             ds_add_f64 and are flushed with one global atomic per touched cell.  The product build has ONE
 //             deposit path: per-lane LDS atomics, conflict free on STRIPED stores (the lanes of a half-wave sit
 //             in consecutive y-cells), cell-crossers deposited in a dense second pass.  Three measured-slower
-//             alternatives are compiled only with -DLPA_K1_VARIANTS=1 into
+//             alternatives (DESIGN_HISTORY.md) are compiled only with -DLPA_K1_VARIANTS=1 into
 //             csrc/build/liblambdapic_amd_variants.so: the wave reduce-scatter deposit of CELL_MAJOR stores, the
 //             in-kernel re-seating (slot classes) and the cooperative deposit of PADDED stores.
 //
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
     // (inv_gamma_of: ~10 VALU instructions) instead of being loaded, and is not written back: 16 of the 105 bytes per
     // particle-update.  K1 2-D moves its bytes at 72 % of what a plain streaming kernel with the same accesses reaches
     // (tools/ubench/stream_soa.hip: 6.07 TB/s) and every attribute stream it drops is worth 0.06-0.09 ms (DESIGN.md
-    // section 5, round 3).  The array goes stale; lpa_refresh_inv_gamma rebuilds it for whoever reads it.
+    // DESIGN_HISTORY.md, round 3).  The array goes stale; lpa_refresh_inv_gamma rebuilds it for whoever reads it.
     static_assert(!NOIG || (DEFER && !WRITE_EB && !WAVE_REDUCE && !RELOC_MODE && !COOP), "NOIG: product path only");
     static_assert(LPA_K1_VARIANTS || (!WAVE_REDUCE && !RELOC && !COOP), "variant paths need -DLPA_K1_VARIANTS=1");
     static_assert(RHO || (!WAVE_REDUCE && !COOP), "the variant deposits always carry rho");

@@ -389,7 +389,7 @@ __device__ __forceinline__ double gather27_l(const double *f, int lx, int ly, in
     lds_ptr3 c = (lds_ptr3)(f + lx * EBSX + ly * EBSY + lz);
     // the 3-D loop runs at 3 waves per SIMD: the reads of a batch are issued back to back and the arithmetic waits on
     // them with counted lgkmcnt (LDS returns in order).  Left to itself the scheduler, short of registers, issued 1-2
-    // reads, waited for lgkmcnt(0), used them ... 108 exposed LDS latencies per particle.
+    // reads, waited for lgkmcnt(0), used them ... 108 exposed LDS latencies per particle (see DESIGN_HISTORY.md, round 2).
     double acc = 0.0;
 #if LPA_GATHER3_BATCH == 27
     double v[3][3][3];

@@ -4,7 +4,7 @@
 The reference deposits rho with the currents in every step (`current/current_deposit.h:180`, `:436-439`).  Esirkepov's
 currents satisfy ``(rho1 - rho0) / dt + div J = 0`` per particle and node, so between two real deposits the engines
 advance rho from the folded currents and the fused kernel drops its rho atomics (9 of 30 in 2-D, 27 of 81 in 3-D -- the
-LDS array is what bounds those kernels).  Rules:
+LDS array is what bounds those kernels, DESIGN_HISTORY.md).  Rules:
 
 * a REAL deposit (the reference's kernel, everything zeroed first) re-anchors rho in every step in which a store is
   sorted -- which includes the step after an upload from the host mirrors, an append / injection and a window shift,
@@ -119,7 +119,7 @@ class RhoContinuityMixin:
     # following the overflow lists a hot store sorts every 3-5 steps; nothing in the scheme needs a real deposit there
     # (a sort moves particles between slots, rho and J do not notice) -- only the sorts that follow an upload, an append or
     # a window shift bring particles rho knows nothing of.  False: those forced sorts re-anchor, and the others only when
-    # ``sort_interval`` steps have passed since the last real deposit (single slab; measured in DESIGN.md section 5).
+    # ``sort_interval`` steps have passed since the last real deposit (single slab; measured in DESIGN_HISTORY.md, round 3).
     anchor_every_sort = True
     _steps_since_anchor = 0
 
