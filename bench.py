@@ -559,8 +559,8 @@ def leg_c2_strong(args, comm, device, steps, warm):
                        f"of {nx_loc}x1024 (fixed problem size)",
            "scaling": "strong", "value": n_tot * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
            "steps": steps, "alive_per_rank": _gather(eng.diagnostics()["nalive"][0]), "charge_rel_err": charge_err,
-           "rho": eng.rho_mode(), "overlap": bool(eng.overlap) and not eng.one_call_step(),
-           "one_call_step": eng.one_call_step(), "e_guards": "once per step (engine.run_steps)",
+           "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+           "one_call_step": eng.one_call_step(), "e_half_steps": "merged across the step boundary (engine.run_steps)",
            "roofline": _k1_roofline(eng, steps, BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * nx_loc * 1024,
                                     "k_push_deposit_tiled_2d")}
     del eng
@@ -628,14 +628,21 @@ def leg_c4(args, comm, device, steps, warm, make_comm):
     # nothing doubled, nothing from nowhere: the live count follows the ledger up to what the open low-x edge absorbs
     ok = n_end <= n_init - dropped + injected and n_end >= n_init - dropped + injected - 0.01 * n_init
     assert ok and err <= 1e-10, (n_init, dropped, injected, n_end, err)
-    return {"workload": f"C4: 2-D LWFA 4096x512 cells (lambda/20), e- 16 ppc at 0.01 nc, CPML, SimpleLaser2D a0=2, moving "
+    return _closing(chain, {"workload": f"C4: 2-D LWFA 4096x512 cells (lambda/20), e- 16 ppc at 0.01 nc, CPML, SimpleLaser2D a0=2, moving "
                         f"window at c with injection, tile sort every 20 steps, as {comm.size} x-slabs of {nxl}x512 "
                         f"(Simulation stage loop)",
             "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_2d(eng)[2]), "window_shifts": shifts[0],
             "ledger": {"initial": int(n_init), "dropped": int(dropped), "injected": int(injected), "final": int(n_end)},
             "charge_rel_err": err, "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(),
-            "overlap": bool(eng.overlap) and not eng.one_call_step(), "one_call_step": eng.one_call_step(), "roofline": roof}
+            "overlap": bool(eng.overlap), "one_call_step": eng.one_call_step(), "roofline": roof})
+
+
+def _closing(chain, result):
+    """a leg's own communicator is destroyed when the leg is done (the device work has been synchronised by then)"""
+    torch.cuda.synchronize()
+    chain.close()
+    return result
 
 
 def leg_c5(args, comm, device, steps, warm, make_comm):
@@ -673,13 +680,13 @@ def leg_c5(args, comm, device, steps, warm, make_comm):
     eng.kernel_events = None
     err, absorbed = _charge_check(sim, _live_3d, lambda e: e.view("rho").sum().item(), dx * dy * dz, cbs)
     assert err <= 1e-10 and 0 <= absorbed <= 0.01 * alive, (err, absorbed)
-    return {"workload": f"C5: 3-D laser-target 512x256x256 cells (dx=lambda/20, dy=dz=lambda/10), e- + p 8 ppc each for "
+    return _closing(chain, {"workload": f"C5: 3-D laser-target 512x256x256 cells (dx=lambda/20, dy=dz=lambda/10), e- + p 8 ppc each for "
                         f"x > 1 um, CPML on 6 faces, GaussianLaser3D a0=10, tile sort every 10 steps, as {comm.size} "
                         f"x-slabs of {nxl}x256x256 (Simulation3D stage loop)",
             "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_3d(eng)[2]), "charge_rel_err": err,
-            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap) and not eng.one_call_step(),
-            "one_call_step": eng.one_call_step(), "roofline": roof}
+            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+            "one_call_step": eng.one_call_step(), "roofline": roof})
 
 
 class Watchdog:

@@ -141,6 +141,29 @@ def test_mirrored_slab_is_half_of_the_doubled_box_2d(doubled2d, transport):
     assert eng.rho_steps["continuity"] > eng.rho_steps["anchor"] > 0
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_per_stage_path_over_the_native_transport_2d(doubled2d, overlap):
+    """what Simulation walks when a callback sits between the stages: the engine's per-stage methods (fused_step off), their
+    exchanges through ``SlabComm.exchange`` -> ``lpa_comm_exchange`` (the T1 overlap: edge part + J exchange on torch's side
+    stream)"""
+    tr2, f2 = doubled2d
+    from lambdapic_amd.engine import PicEngine2D
+    comm = _comm("loopback", NX * _problem2d()[0], 4096)
+    saved = PicEngine2D.fused_step
+    PicEngine2D.fused_step = False
+    try:
+        tr, f, eng = _engine2d(NX, comm, 1, overlap=overlap)
+    finally:
+        PicEngine2D.fused_step = saved
+    assert eng.comm.native is not None          # (fused_step was off while the engine ran: every stage a call of its own)
+    assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k]), k
+    for a in f:
+        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        assert _close(f[a][lo:hi], f2[a][lo:hi]), a
+
+
 @pytest.mark.parametrize("transport", ["loopback", "rccl"])
 def test_overlapped_mirrored_slab_2d(doubled2d, transport):
     """lpa_step_slab.overlap_cols: edge tile columns, leaver pack and the whole exchange on the communicator's second stream

@@ -101,3 +101,132 @@ def test_bad_configurations_are_refused():
         s.run(1, callbacks=[callback("no_such_stage")(lambda sim: None)])
     with pytest.raises(ValueError):
         s.run(nsteps=1, sim_time=1.0)
+
+
+# ---- round 4: E half steps merged across the step boundary -- the rule that decides where ------------------------------
+def test_defer_rule_blocks_on_every_possible_reader():
+    """Simulation._can_defer_e2: the second E half step of a step may wait for the next step's first one only when nothing
+    can read or move E in between"""
+    from lambdapic_amd.simulation import MovingWindow
+    s = _sim()
+    s.nx_per_patch = s.nx // s.npatch_x              # (set by initialize(), which needs the GPU)
+    s.itime, s.time = 5, 5 * s.dt
+    ok = lambda table, last=False, stop=True: s._can_defer_e2(table, last, stop)
+    assert ok({})
+    assert not ok({}, last=True)                     # the last step of a run() is a plain one
+    assert not ok({}, stop=False)                    # a user's stop_callback may look at anything
+
+    @callback("end", interval=1)
+    def at_end(sim):
+        pass
+
+    @callback("maxwell_2", interval=5)
+    def at_m2(sim):
+        pass
+
+    @callback("start", interval=3)
+    def at_start(sim):
+        pass
+
+    @callback("start", interval=lambda sim: False)
+    def moody(sim):
+        pass
+
+    @callback("maxwell_1", interval=1)
+    def inner(sim):
+        pass
+
+    assert not ok({"end": [at_end]})
+    assert not ok({"maxwell_2": [at_m2]})            # itime 5 % 5 == 0: fires in this step
+    s.itime = 6
+    assert ok({"maxwell_2": [at_m2]})
+    assert ok({"maxwell_1": [inner]})                # after E1 of the next step: no reader in between
+    s.itime = 4
+    assert ok({"start": [at_start]})                 # next step is 5: 5 % 3 != 0
+    s.itime = 5
+    assert not ok({"start": [at_start]})             # next step is 6: fires, and does not say it leaves the fields alone
+    assert not ok({"start": [moody]})                # an interval function cannot be asked about the next step
+    s.defer_e2 = False
+    assert not ok({})
+    s.defer_e2 = True
+    # the moving window: fires at every 'start', touches the fields only when it removes the layers or shifts
+    s.itime, s.time = 10, 10 * s.dt
+    win = MovingWindow(velocity=299792458.0, start_time=100 * s.dt)
+    assert ok({"start": [win]})                      # not started
+    win.start_time = 0.0
+    assert not ok({"start": [win]})                  # its first active call removes the x layers
+    win.num_shifts, win.total_shift = 3, 0.0
+    patch = s.nx_per_patch * s.dx
+    win.patch_this_shift = 0.2 * patch
+    assert ok({"start": [win]})
+    win.patch_this_shift = patch - 0.5 * 299792458.0 * s.dt
+    assert not ok({"start": [win]})                  # the next call shifts
+    back = MovingWindow(velocity=-299792458.0, start_time=0.0)
+    back.num_shifts, back.patch_this_shift = 3, -patch + 0.5 * 299792458.0 * s.dt
+    assert not ok({"start": [back]})
+    back.patch_this_shift = 0.0
+    assert ok({"start": [back]})
+
+
+def test_interval_functions_are_asked_once_per_step():
+    s = _sim()
+    asked = []
+
+    @callback("start", interval=lambda sim: asked.append(sim.itime) or True)
+    def cb(sim):
+        pass
+
+    for it in range(3):
+        s.itime = it
+        for _ in range(4):                               # the stage loop asks several times per step
+            assert s._triggered([cb]) == [cb]
+    assert asked == [0, 1, 2]
+
+
+# ---- round 4: the transport objects need no GPU to exist ---------------------------------------------------------------------
+def test_loopback_communicator_without_a_gpu():
+    import ctypes as C
+    from lambdapic_amd import _lib
+    from lambdapic_amd.dist import LoopbackComm
+    L = _lib.lib()
+    for size in (1, 2):
+        comm = LoopbackComm(1.0e-6, size)
+        kind, rank, csize, left, right, version = comm.native_info()
+        assert (kind, rank, csize, version) == (_lib.LPA_COMM_LOOPBACK, 0, size, 0) and left == right == size - 1
+        assert comm.arrival_shift(123.0) == (-1.0e-6, 1.0e-6)
+        assert (comm.has_left, comm.has_right) == (size == 2, size == 2)
+        assert L.lpa_comm_exchange(comm.native, None, 0, None) == 0          # an empty round is legal
+        bad = (_lib.lpa_face_msg * 1)()
+        bad[0].n_send_lo = -1
+        assert L.lpa_comm_exchange(comm.native, bad, 1, None) == -1 and b"negative count" in L.lpa_last_error()
+        comm.close()
+        assert comm.native is None
+    h = C.c_void_p()
+    assert L.lpa_comm_create_loopback(C.byref(h), 3, 1) == -1          # a ring of 1, or of 2 (slab + its copy)
+    assert L.lpa_comm_create_loopback(C.byref(h), 2, 0) == -1          # loopback rings are periodic
+
+
+def test_slab_communicators_pickle_without_their_handles():
+    import pickle
+    from lambdapic_amd.dist import SlabComm
+    c = SlabComm(None, single=True)
+    c.native = object()                  # (whatever it is, it must not travel)
+    assert pickle.loads(pickle.dumps(c)).native is None
+
+
+def test_bench_watchdog_prints_what_it_has_and_exits_nonzero():
+    """bench.py's Watchdog in a child process: an overrun section -> rank 0 prints the partial line with the section marked
+    "timeout", exit code 3"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Watchdog(0); d.partial = {'metric': 'm', 'value': 1.0}\n"
+            "d.arm('leg c4', 0.2); time.sleep(30)\n" % str(root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.0 and line["extra"] == [{"workload": "leg c4", "value": None, "error": "timeout"}]
+    assert "exceeded its time budget" in r.stderr
