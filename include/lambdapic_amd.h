@@ -310,11 +310,13 @@ typedef struct {
     uint32_t *absorbed_count;
     int64_t absorbed_capacity;
     /* optional (NULL = off; slab ranks): the slot of every particle whose advanced x lies outside [leave_lo, leave_hi]
-     * -- it now belongs to a neighbour slab -- is appended to `leavers` (uint32 slots; leaver_count = device uint32
+     * -- it now belongs to a neighbour slab -- is appended to `leavers` (uint64 entries: low 32 bits = the slot, high 32 bits
+     * = 1 + the tile whose range holds the slot when the reporting kernel knew it -- the tiled kernels do --, else 0;
+     * leaver_count = device uint32
      * the caller zeroes before the step's pushes; entries beyond leaver_capacity are dropped and only counted: such a
      * particle is reported again by the next step's push).  The migration pack then visits the listed slots instead of
      * scanning the edge tile columns for them (lpa_migrate_pack_list). */
-    uint32_t *leavers;
+    uint64_t *leavers;
     uint32_t *leaver_count;
     int64_t leaver_capacity;
     double leave_lo, leave_hi;
@@ -491,7 +493,7 @@ int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling *t, int32_
 /* the same pack over a list of slots (lpa_push_params.leavers, written by the push kernels of this step): visits
  * min(*list_count, list_capacity) slots; a listed slot whose particle is not (or no longer) outside [xlo, xhi] is left
  * alone.  `t` / `fs` as for lpa_migrate_pack_edges_x (both may be NULL: no free-slot bookkeeping). */
-int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint64_t *list, const uint32_t *list_count,
                           int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi,
                           int64_t capacity, const lpa_free_slots *fs, int32_t *surplus, void *stream);
 /* unpack for a tile-ordered store with free-slot stacks: an arrival whose tile (from its position on grid

@@ -69,7 +69,7 @@ int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_
                       double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,
                       int zero_headers, const int32_t *loose_limit, void *stream);
 // lpa_migrate_pack_list without its header memsets
-int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint64_t *list, const uint32_t *list_count,
                            int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
                            const lpa_free_slots *fs, int32_t *surplus, void *stream);
 // lpa_migrate_unpack(_tiled) of BOTH faces in one launch (fs == NULL: arrival area only)
@@ -201,13 +201,14 @@ __device__ __forceinline__ void spread_tsc(const GridV &g, double *dst, double e
 // a particle whose advanced position left the slab along x: its slot goes on the leaver list (lpa_push_params.leavers;
 // rare: one atomic each).  K = PushK / PushK3.
 template <class K>
-__device__ __forceinline__ void report_leaver(const K &k, double xs, long ip) {
+__device__ __forceinline__ void report_leaver(const K &k, double xs, long ip, int tile = -1) {
 #ifdef LPA_NO_LEAVERS      // A/B build: what the check costs the tiled kernels
     return;
 #endif
     if (k.leavers && (xs < k.leave_lo || xs > k.leave_hi)) {      // (NaN -- dead, absorbed -- compares false)
         const uint32_t slot = atomicAdd(k.leaver_count, 1u);
-        if ((long)slot < k.leaver_cap) k.leavers[slot] = (uint32_t)ip;
+        // (the tile the slot belongs to, when the caller knows it: the pack need not search for it)
+        if ((long)slot < k.leaver_cap) k.leavers[slot] = ((unsigned long long)(unsigned)(tile + 1) << 32) | (unsigned long long)(uint32_t)ip;
     }
 }
 

@@ -34,7 +34,8 @@ struct PushK {
     long absorbed_cap;
     double *absorbed_spill;
     // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
-    uint32_t *leavers, *leaver_count;
+    unsigned long long *leavers;
+    uint32_t *leaver_count;
     long leaver_cap;
     double leave_lo, leave_hi;
 };
@@ -55,7 +56,7 @@ __device__ __forceinline__ void report_absorbed_2d(const GridV &g, const PushK &
 
 static PushK make_pushk(const lpa_push_params *pp, const lpa_grid *g = nullptr) {
     PushK k;
-    k.leavers = pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
+    k.leavers = (unsigned long long *)pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
     k.leave_lo = pp->leave_lo; k.leave_hi = pp->leave_hi;
     k.dep.c_rho = k.dep.c_jx = k.dep.c_jy = 0.0;
     if (g) {   // current/current_deposit.h:238-241: (q / (dx dy)) w, (q / (dy dt)) w, (q / (dx dt)) w
@@ -604,7 +605,7 @@ __global__ void __launch_bounds__(K1_THREADS, (RELOC_MODE || COOP) ? 4 : 1) k_pu
             if (finish_position_2d(xs, ys, k) && k.absorbed)    // rare: a particle reached an open face
                 report_absorbed_2d(g, k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                    k.dep.c_rho * w);
-            report_leaver(k, xs, ip);
+            report_leaver(k, xs, ip, tile);
             if (RELOC) mover = mover && !isnan(xs);     // absorbed at an open face: the slot becomes a hole
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
             stp(p.x, o, xs); stp(p.y, o, ys);

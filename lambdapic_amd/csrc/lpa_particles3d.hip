@@ -24,7 +24,8 @@ struct PushK3 {
     long absorbed_cap;
     double *absorbed_spill;
     // slab ranks (optional): slots of the particles that now belong to a neighbour slab (lpa_push_params.leavers)
-    uint32_t *leavers, *leaver_count;
+    unsigned long long *leavers;
+    uint32_t *leaver_count;
     long leaver_cap;
     double leave_lo, leave_hi;
 };
@@ -451,12 +452,13 @@ template <bool RHO> struct K13Geom {
     static_assert(R3ZS >= R3Z, "J image z stride");
 };
 
-struct TileCtx { int t0[3], r0[3], e0[3]; };   // first node of the tile, of the J region, of the E / B image
+struct TileCtx { int t0[3], r0[3], e0[3]; int tile; };   // first node of the tile, of the J region, of the E / B image
 
 __device__ __forceinline__ TileCtx tile_ctx(int tile, int tiles_y, int tiles_z, int &tx_) {
     const int tz_ = tile % tiles_z, ty_ = (tile / tiles_z) % tiles_y;
     tx_ = tile / (tiles_z * tiles_y);
     TileCtx c;
+    c.tile = tile;
     c.t0[0] = tx_ * T3X; c.t0[1] = ty_ * T3Y; c.t0[2] = tz_ * T3Z;
 #pragma unroll
     for (int a = 0; a < 3; a++) { c.r0[a] = c.t0[a] - H3; c.e0[a] = c.t0[a] - G3L; }
@@ -684,7 +686,7 @@ __device__ __forceinline__ void species_pass(const GridV &g, const PartV &p_, co
             if (finish_position_3d(xs, ys, zs, k) && k.absorbed)    // rare: a particle reached an open face
                 report_absorbed(g, k, (x + vx * 0.5 * k.dt - g.x0) * inv_dx, (y + vy * 0.5 * k.dt - g.y0) * inv_dy,
                                 (z + vz * 0.5 * k.dt - g.z0) * inv_dz, k.c_rho * w);
-            report_leaver(k, xs, ip);
+            report_leaver(k, xs, ip, tc.tile);
             const uint32_t o = (uint32_t)(ip - rb) * 8u;
             stp(p.x, o, xs); stp(p.y, o, ys); stp(p.z, o, zs);
             stp(p.ux, o, ux); stp(p.uy, o, uy); stp(p.uz, o, uz); stp(p.ig, o, ig);
@@ -845,7 +847,7 @@ static PushK3 make_pushk3(const lpa_push_params *pp, const lpa_grid *g = nullptr
     k.flags = pp->flags;
     k.absorbed = pp->absorbed; k.absorbed_count = pp->absorbed_count; k.absorbed_cap = (long)pp->absorbed_capacity;
     k.absorbed_spill = pp->absorbed_spill;
-    k.leavers = pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
+    k.leavers = (unsigned long long *)pp->leavers; k.leaver_count = pp->leaver_count; k.leaver_cap = (long)pp->leaver_capacity;
     k.leave_lo = pp->leave_lo; k.leave_hi = pp->leave_hi;
     for (int a = 0; a < 3; a++) {
         k.lo[a] = pp->lo[a]; k.hi[a] = pp->hi[a];

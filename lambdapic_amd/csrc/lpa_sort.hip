@@ -852,7 +852,8 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
                                                  const FreeSlots &fs = FreeSlots{nullptr, nullptr, 0, 0},
                                                  const int32_t *tile_off = nullptr, int ntiles = 0,
                                                  long n_sorted = 0, bool active = true,
-                                                 int32_t *surplus = nullptr, bool have_x = false, double x_in = 0.0) {
+                                                 int32_t *surplus = nullptr, bool have_x = false, double x_in = 0.0,
+                                                 int known_tile = -1) {
     // called by every lane of the wave (`active` = this lane has a particle): the message slots are taken
     // with ONE atomic per wave and face -- tens of thousands of leavers bumping a single counter one by one
     // took 0.14 ms of the 3-D scan
@@ -896,6 +897,7 @@ __device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double
         if (p.dead) p.dead[ip] = 1;
         if (fs.count && ip < n_sorted) {   // the freed slot belongs to the tile whose range holds it
             int lo = 0, hi = ntiles;       // last tile with tile_off[tile] <= ip
+            if (known_tile >= 0) lo = known_tile, hi = known_tile + 1;      // (the tiled push kernels say which)
             while (hi - lo > 1) {
                 int mid = (lo + hi) >> 1;
                 if ((long)tile_off[mid] <= ip) lo = mid; else hi = mid;
@@ -959,7 +961,7 @@ __global__ void __launch_bounds__(256) k_migrate_pack_edges_x(PartV p, const int
 }
 
 // the same over the slots the push kernels of this step reported (lpa_push_params.leavers): no scan at all
-__global__ void __launch_bounds__(256) k_migrate_pack_list(PartV p, const uint32_t *__restrict__ list,
+__global__ void __launch_bounds__(256) k_migrate_pack_list(PartV p, const unsigned long long *__restrict__ list,
                                                            const uint32_t *__restrict__ list_count, long list_cap,
                                                            const int32_t *__restrict__ tile_off, int ntiles, long n_sorted,
                                                            double xlo, double xhi, double *buf_lo, double *buf_hi,
@@ -970,8 +972,11 @@ __global__ void __launch_bounds__(256) k_migrate_pack_list(PartV p, const uint32
     for (long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; t0 < total; t0 += (long)gridDim.x * blockDim.x) {
         const long t = t0 + lane;
         const bool active = t < total;
-        long ip = active ? (long)list[t] : 0;
-        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active && ip < p.n, surplus);
+        const unsigned long long ent = active ? list[t] : 0ull;
+        const long ip = (long)(ent & 0xffffffffull);
+        const int tile = (int)(ent >> 32) - 1;
+        migrate_pack_one(p, ip, xlo, xhi, buf_lo, buf_hi, cap, fs, tile_off, ntiles, n_sorted, active && ip < p.n, surplus, false,
+                         0.0, tile < ntiles ? tile : -1);
     }
 }
 
@@ -1122,7 +1127,7 @@ extern "C" int lpa_migrate_pack_edges_x(const lpa_particles *p, const lpa_tiling
     return LPA_OK;
 }
 
-static int migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+static int migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint64_t *list, const uint32_t *list_count,
                              int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
                              const lpa_free_slots *fs, int32_t *surplus, int zero_headers, void *stream) {
     LPA_REQUIRE(lpa_part_ok(p, 2) && list && list_count && list_capacity > 0 && buf_lo && buf_hi && capacity > 0 && xlo < xhi,
@@ -1141,21 +1146,21 @@ static int migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const 
     // the list is short (what crosses a face in one step): a fixed small grid, grid-stride over the device-side count
     long nblk = (list_capacity + 255) / 256;
     if (nblk > 64) nblk = 64;
-    hipLaunchKernelGGL(k_migrate_pack_list, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), list, list_count,
+    hipLaunchKernelGGL(k_migrate_pack_list, dim3((unsigned)nblk), dim3(256), 0, st, make_partv(p), (const unsigned long long *)list, list_count,
                        (long)list_capacity, fs ? t->tile_off : nullptr, ntiles, fs ? (long)t->n_sorted : 0L, xlo, xhi, buf_lo,
                        buf_hi, (long)capacity, make_free_slots(fs, t), surplus);
     LPA_CHECK_LAUNCH("lpa_migrate_pack_list");
     return LPA_OK;
 }
 
-extern "C" int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list,
+extern "C" int lpa_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint64_t *list,
                                      const uint32_t *list_count, int64_t list_capacity, double xlo, double xhi,
                                      double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs,
                                      int32_t *surplus, void *stream) {
     return migrate_pack_list(p, t, list, list_count, list_capacity, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, 1, stream);
 }
 
-int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint32_t *list, const uint32_t *list_count,
+int lpai_migrate_pack_list(const lpa_particles *p, const lpa_tiling *t, const uint64_t *list, const uint32_t *list_count,
                            int64_t list_capacity, double xlo, double xhi, double *buf_lo, double *buf_hi, int64_t capacity,
                            const lpa_free_slots *fs, int32_t *surplus, void *stream) {
     return migrate_pack_list(p, t, list, list_count, list_capacity, xlo, xhi, buf_lo, buf_hi, capacity, fs, surplus, 0, stream);

@@ -834,7 +834,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             # the push kernels list the slots that left the slab (exact: no scan of the edge tile columns, and the free-slot
             # stacks stay usable however old the order is)
             if ws.get("leavers") is None:
-                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int64, device=self.device)
             out.update(leavers=ws["leavers"], leaver_count=ws["counters"][4:5], fs=ws.get("fs") if self.reuse_slots else None)
         return out
 

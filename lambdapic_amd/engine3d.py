@@ -580,7 +580,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             out.update(overflow_edge=ws["overflow_edge"], edge_count=ws["counters"][2:3])
         if self.leaver_lists and self.native_slab() and sp["tiling"] is not None:      # (see PicEngine2D._slab_species)
             if ws.get("leavers") is None:
-                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int32, device=self.device)
+                ws["leavers"] = torch.empty(2 * cap, dtype=torch.int64, device=self.device)
             out.update(leavers=ws["leavers"], leaver_count=ws["counters"][4:5], fs=ws.get("fs") if self.reuse_slots else None)
         return out
 
