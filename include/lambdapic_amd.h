@@ -255,7 +255,9 @@ int lpa_rho_absorbed_spill(const lpa_grid *g, const double *list, uint32_t *coun
 /* ---- periodic guard handling inside one slab (replaces sync_guard_fields_2d and
  *      sync_currents_2d with a self-neighbour table, core/patch/sync_fields2d.c:150-255,43-148).
  *      `which`: bit 0 = ex ey ez, bit 1 = bx by bz.  `axes`: bit 0 = x, bit 1 = y (, bit 2 = z):
- *      the axes that are periodic INSIDE this slab (x is excluded when x is split over ranks). */
+ *      the axes that are periodic INSIDE this slab (x is excluded when x is split over ranks).
+ *      lpa_guard_wrap, bit 3 of `axes` (x split over ranks): the x guard planes wrap their own y / z guards too (slabs that
+ *      advance B on those planes themselves, LPA_STEP_B_EXT_*). */
 int lpa_guard_wrap(const lpa_grid *g, int which, int axes, void *stream);
 int lpa_current_fold(const lpa_grid *g, int axes, void *stream);
 
@@ -643,7 +645,8 @@ int lpa_comm_exchange(lpa_comm *c, const lpa_face_msg *msgs, int32_t nmsgs, void
  *      every species' leavers in ONE exchange (guard planes straight from the arrays into slab->cur_r_*; they are added to the
  *      interior edge and the sent planes zeroed by one launch; arrivals are unpacked by one launch per species), and
  *      on continuity steps the left neighbour's folded jx plane rides with the B planes of LPA_STAGE_B2_GUARD, after
- *      which rho is advanced (instead of at LPA_STAGE_FOLD).  Stores must be tile ordered (arrival area behind
+ *      which rho is advanced (instead of at LPA_STAGE_FOLD; see rho_exchange and LPA_STEP_B_EXT_* for the form without B
+ *      messages: two rounds per step).  Stores must be tile ordered (arrival area behind
  *      n_sorted).  With slab->comm == NULL the caller moves the faces itself (another transport): the stages then do
  *      the work of a single slab with `local_axes` and the caller packs / exchanges / unpacks between sub-ranges. */
 typedef struct {
@@ -677,7 +680,12 @@ typedef struct {
     int64_t migrate_capacity;
     double *cur_r_lo, *cur_r_hi;    /* 4 * ng * plane doubles each: the neighbours' J / rho guard planes */
     double *jx_left_plane;          /* plane doubles (continuity steps: the left neighbour's folded jx at its node nx-1) */
-    int32_t rho_exchange;           /* != 0: the jx plane travels in LPA_STAGE_B2_GUARD (every step: all ranks alike) */
+    int32_t rho_exchange;           /* every step, all ranks alike -- 1: the left neighbour's folded jx plane travels with the
+                                       B planes of LPA_STAGE_B2_GUARD, after which rho is advanced; 2: each rank's OWN jx deposit
+                                       on its last node plane travels to the right with the J / rho guard planes of
+                                       LPA_STAGE_FOLD into jx_left_plane, the fold forms the neighbour's folded plane from it in
+                                       the jx guard plane at node -1 (the same sums, bit for bit) and rho is advanced at once --
+                                       for steps whose B guard planes do not travel (LPA_STEP_B_EXT_*) */
     int32_t overlap_cols;           /* > 0 (and LPA_STAGE_PUSH .. LPA_STAGE_FOLD in one call, every store tile ordered): the
                                        `overlap_cols` tile columns at each x face (+ overflow list + arrival area: everything
                                        that can deposit into the x guard planes or leave the slab) are pushed first, on the
@@ -716,6 +724,16 @@ typedef struct {
  * guard stage.  Between the two calls E is half a step behind: nothing may read it (engines: run_steps). */
 #define LPA_STEP_DEFER_E2 2
 #define LPA_STEP_E1_DOUBLE 4
+/* LPA_STEP_B_EXT_LO / _HI: this slab has a neighbour at its low / high x face and the B half steps advance the x guard planes
+ * there themselves (ng planes low, ng - 1 high) instead of receiving them: a B update reads E at its node and one node up, the
+ * E guard planes are current after every E guard stage, so the guard values are the ones the neighbour computes for its
+ * interior, bit for bit.  With either flag set the B guard stages exchange nothing (slab ranks: two message rounds per step
+ * instead of four -- E, J + rho + particles); use lpa_step_slab.rho_exchange = 2 with it.  The psi arrays of the y / z CPML
+ * layers (lpa_cpml_axis) must then hold ng extra x rows in front of and behind the nx the pointers address, and whoever
+ * changes B outside lpa_step (initial fields, an injection within ng + 1 nodes of such a face, a window shift) leaves all ng
+ * guard planes current, as lpa_halo_faces / a shift do. */
+#define LPA_STEP_B_EXT_LO 8
+#define LPA_STEP_B_EXT_HI 16
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

@@ -37,9 +37,10 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
 
 // ---- internal helpers shared between the translation units (not part of the C ABI; used by lpa_step) --------------
 // one E / B half step with the periodic guard wrap of the axes in `wrap` fused into the sweep (lpa_fields.hip)
-// (`twice`: the E sweep applies two half steps in one pass -- see FDTD_TWICE in lpa_fields.hip)
+// (`twice`: the E sweep applies two half steps in one pass -- see FDTD_TWICE in lpa_fields.hip; `ext_lo` / `ext_hi`: the
+// B sweep of a slab split along x also advances that many x guard planes at the low / high face -- FDTD_EXT_* there)
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, void *stream);
+              int twice, int ext_lo, int ext_hi, void *stream);
 // the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
 // [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
 int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
@@ -62,8 +63,9 @@ int lpai_push_deposit_tiled_multi_part_3d(const lpa_grid *g, int32_t nspecies, c
 int lpai_zero_words(uint32_t *const *words, int n, void *stream);
 // the current fold of a step in one launch: periodic fold along `axes` + (slab ranks) the J / rho guard planes received
 // from the neighbours (r_lo / r_hi: [4][ng][plane] each, NULL = no neighbour on that face) added to the interior edge,
-// consumed guards and the guard planes this rank sent away zeroed
-int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, void *stream);
+// consumed guards and the guard planes this rank sent away zeroed (`left_own`, may be NULL: the left neighbour's own jx
+// deposit on its last node plane -- the jx guard plane at node -1 then ends up holding that neighbour's folded jx)
+int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, const double *left_own, void *stream);
 // lpa_migrate_pack_edges_x / lpa_migrate_pack_x without their header memsets (zero_headers == 0: the caller zeroed them)
 int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_cols, double xlo, double xhi,
                       double *buf_lo, double *buf_hi, int64_t capacity, const lpa_free_slots *fs, int32_t *surplus,

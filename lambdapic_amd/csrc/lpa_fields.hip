@@ -52,6 +52,15 @@ __device__ __forceinline__ void store3_wrapped(const GridV &g, double *fa, doubl
 // registers are the two sweeps, bit for bit, for a third of the E traffic of the pair)
 constexpr int FDTD_TWICE = 256;
 
+// bits 3-4 / 5-6 of the B sweeps' `wrap` argument: the sweep also advances that many x GUARD planes below node 0 / above
+// node nx - 1 (lpa_step, LPA_STEP_B_EXT_*).  A B update reads E at the node and one node up, so with all ng E guard planes
+// current (they are exchanged after every E sweep) B is exact on the ng low and the ng - 1 high guard planes -- the same
+// arithmetic on the same E values the neighbour slab performs on its interior -- and never has to travel: two of a slab
+// step's four message rounds are gone.  (psi arrays of the y / z CPML layers carry x guard rows for this, see the engines.)
+constexpr int FDTD_EXT_LO_SHIFT = 3, FDTD_EXT_HI_SHIFT = 5;
+__device__ __forceinline__ int fdtd_ext_lo(int wrap) { return (wrap >> FDTD_EXT_LO_SHIFT) & 3; }
+static int fdtd_ext_rows(int wrap) { return ((wrap >> FDTD_EXT_LO_SHIFT) & 3) + ((wrap >> FDTD_EXT_HI_SHIFT) & 3); }
+
 // =====================================================================================================
 // FDTD.  Restates update_efield_2d / update_bfield_2d (core/maxwell/cpu.py:9-35) on the conventional
 // layout: interior node (i,j) is at [i+ng][j+ng]; i-1 at i=0 is the low guard, i+1 at nx-1 the high one.
@@ -74,7 +83,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double 
 
 __global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = blockIdx.y;
+    int i = (int)blockIdx.y - fdtd_ext_lo(wrap);
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xp = c + g.NY, yp = c + 1;
@@ -104,7 +113,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double 
 
 __global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y, i = blockIdx.z;
+    int j = blockIdx.y, i = (int)blockIdx.z - fdtd_ext_lo(wrap);
     if (k >= g.nz) return;
     long sy = g.NZ, sx = (long)g.NY * g.NZ;
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
@@ -131,7 +140,7 @@ extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *st
 static int fdtd_b_2d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0), "lpa_fdtd_b_2d: bad grid");
     GridV v = make_gridv(g, 2);
-    dim3 grid((g->ny + 255) / 256, g->nx);
+    dim3 grid((g->ny + 255) / 256, g->nx + fdtd_ext_rows(wrap));
     hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_2d");
     return LPA_OK;
@@ -155,7 +164,7 @@ static int fdtd_b_3d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0), "lpa_fdtd_b_3d: bad grid");
     LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_3d: nx, ny must be <= 65535");
     GridV v = make_gridv(g, 3);
-    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx + fdtd_ext_rows(wrap));
     hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_3d");
     return LPA_OK;
@@ -362,11 +371,13 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bf
 
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = blockIdx.y;
+    int i = (int)blockIdx.y - fdtd_ext_lo(wrap);
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xp = c + g.NY, yp = c + 1;
-    double efx = dt / ax.kappa[i], efy = dt / ay.kappa[j];
+    // (an x guard plane lies outside every x layer -- a face with a neighbour slab has none: kappa_x = 1 there; the y
+    // layers' psi arrays have rows for it)
+    double efx = dt / ax.kappa[min(max(i, 0), g.nx - 1)], efy = dt / ay.kappa[j];
     double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
     double ez_xp = g.ez[xp], ez_yp = g.ez[yp], ey_xp = g.ey[xp], ex_yp = g.ex[yp];
     double bx = g.bx[c], by = g.by[c], bz = g.bz[c];
@@ -416,7 +427,7 @@ static int fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axi
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
                 "lpa_fdtd_b_cpml_fused_2d: bad args");
     GridV v = make_gridv(g, 2);
-    dim3 grid((g->ny + 255) / 256, g->nx);
+    dim3 grid((g->ny + 255) / 256, g->nx + fdtd_ext_rows(wrap));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
                        make_axisv(ay), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_2d");
@@ -483,11 +494,11 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bf
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay,
                                                               CpmlAxisV az, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y, i = blockIdx.z;
+    int j = blockIdx.y, i = (int)blockIdx.z - fdtd_ext_lo(wrap);
     if (k >= g.nz) return;
     long sy = g.NZ, sx = (long)g.NY * g.NZ;
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
-    double efx = dt / ax.kappa[i], efy = dt / ay.kappa[j], efz = dt / az.kappa[k];
+    double efx = dt / ax.kappa[min(max(i, 0), g.nx - 1)], efy = dt / ay.kappa[j], efz = dt / az.kappa[k];
     double exc = g.ex[c], eyc = g.ey[c], ezc = g.ez[c];
     double dez_x = g.ez[c + sx] - ezc, dey_x = g.ey[c + sx] - eyc;
     double dez_y = g.ez[c + sy] - ezc, dex_y = g.ex[c + sy] - exc;
@@ -536,7 +547,7 @@ static int fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axi
                     g->ny <= 65535 && g->nx <= 65535,
                 "lpa_fdtd_b_cpml_fused_3d: bad args");
     GridV v = make_gridv(g, 3);
-    dim3 grid((g->nz + 255) / 256, g->ny, g->nx);
+    dim3 grid((g->nz + 255) / 256, g->ny, g->nx + fdtd_ext_rows(wrap));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
                        make_axisv(ay), make_axisv(az), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_3d");
@@ -550,10 +561,13 @@ extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_
 // one half step of E or B over the slab with the guard wrap of the axes in `wrap` fused in (lpa_step); ax[]: the fused
 // CPML descriptors, all NULL = the plain Yee update
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, void *stream) {
+              int twice, int ext_lo, int ext_hi, void *stream) {
     LPA_REQUIRE(g && g->nx >= g->ng && g->ny >= g->ng && (dim == 2 || g->nz >= g->ng), "lpai_fdtd: slab thinner than the guard");
     LPA_REQUIRE(!twice || efield, "lpai_fdtd: only the E sweep does two half steps at once");
-    wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0);
+    LPA_REQUIRE(ext_lo >= 0 && ext_hi >= 0 && ext_lo <= g->ng && ext_hi < g->ng && ext_lo <= 3 && ext_hi <= 3 &&
+                    (!(ext_lo | ext_hi) || (!efield && !(wrap & 1))),
+                "lpai_fdtd: only the B sweep of a slab split along x advances x guard planes (ng low, ng - 1 high at most)");
+    wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0) | (ext_lo << FDTD_EXT_LO_SHIFT) | (ext_hi << FDTD_EXT_HI_SHIFT);
     const bool cpml = ax && ax[0];
     if (dim == 2) {
         if (efield) return cpml ? fdtd_e_cpml_fused_2d(g, dt, eps0, ax[0], ax[1], wrap, stream) : fdtd_e_2d(g, dt, eps0, wrap, stream);
@@ -881,7 +895,8 @@ __global__ void __launch_bounds__(256) k_guard_wrap(GridV g, Ptr6 f, int axes) {
     int cy = g.NZ > 1 ? blockIdx.y : z;
     int cz = g.NZ > 1 ? z : 0;
     bool guard = false;
-    int sx = image_of(cx, g.nx, g.ng, axes & 1, guard);
+    // (axes & 8: x is split over slabs and the x guard planes are advanced in place -- they wrap their own y / z guards)
+    int sx = (axes & 8) ? cx : image_of(cx, g.nx, g.ng, axes & 1, guard);
     int sy = image_of(cy, g.ny, g.ng, axes & 2, guard);
     int sz = g.NZ > 1 ? image_of(cz, g.nz, g.ng, axes & 4, guard) : 0;
     if (!guard || sx < 0 || sy < 0 || sz < 0) return;
@@ -1165,9 +1180,13 @@ int lpai_zero_words(uint32_t *const *words, int n, void *stream) {
 //   * on a slab rank the planes received from a neighbour (r_lo / r_hi: [4][ng][plane], NULL = no neighbour) are added
 //     on the fly, to the cell and to its y / z images alike: (f + r) per cell first, then the fold -- the sums the
 //     separate launches form (fill of sync_currents, core/mpi/sync_fields2d.c:76-102);
-//   * a cell of an x guard plane that was sent to a neighbour is zeroed (:44-74).
+//   * a cell of an x guard plane that was sent to a neighbour is zeroed (:44-74) -- except, with `left_own` (the LEFT
+//     neighbour's own jx deposit on its last node plane, [plane] doubles, which travelled with the guard planes), the jx
+//     plane at node -1: it becomes the neighbour's FOLDED jx there -- (mine + its own) per cell, then the y / z images, the
+//     very sums the neighbour forms for that plane, bit for bit -- which the backward difference of the rho continuity
+//     update at node 0 reads (no message of its own for that plane).
 __global__ void __launch_bounds__(256) k_fold_all(GridV g, int axes, const double *__restrict__ r_lo,
-                                                  const double *__restrict__ r_hi) {
+                                                  const double *__restrict__ r_hi, const double *__restrict__ left_own) {
     const int z = blockIdx.x * blockDim.x + threadIdx.x;
     const bool d3 = g.NZ > 1;
     const int NF = d3 ? g.NZ : g.NY;
@@ -1179,10 +1198,27 @@ __global__ void __launch_bounds__(256) k_fold_all(GridV g, int axes, const doubl
     double *arr[4] = {g.jx, g.jy, g.jz, g.rho};
     const int i = cx - ng, j = cy - ng, k = d3 ? cz - ng : 0;
     if (i < 0 || i >= g.nx) {                       // x guard plane: sent to a neighbour -> zero
-        if ((i < 0 && r_lo) || (i >= g.nx && r_hi)) {
+        if (!((i < 0 && r_lo) || (i >= g.nx && r_hi))) return;
+        const bool mirror = i == -1 && left_own;
 #pragma unroll
-            for (int a = 0; a < 4; a++) arr[a][c] = 0.0;
+        for (int a = mirror ? 1 : 0; a < 4; a++) arr[a][c] = 0.0;
+        if (!mirror) return;
+        double *f = g.jx;
+        const long pc = (long)cy * sY + cz;
+        const int j = cy - ng, k = d3 ? cz - ng : 0;
+        const bool gy = j < 0 || j >= g.ny, gz = d3 && (k < 0 || k >= g.nz);
+        if (gy || gz) {     // (a consumed y / z guard cell is read by its owner below and rewritten by the next reset)
+            const bool consumed = !((gy && !(axes & 2)) || (gz && !(axes & 4)));
+            if (!consumed) f[c] += left_own[pc];
+            return;
         }
+        const int oy = (axes & 2) ? (j < ng ? g.ny : (j >= g.ny - ng ? -g.ny : 0)) : 0;
+        const int oz = (d3 && (axes & 4)) ? (k < ng ? g.nz : (k >= g.nz - ng ? -g.nz : 0)) : 0;
+        double v = f[c] + left_own[pc];
+        if (oy) v += f[c + oy * sY] + left_own[pc + oy * sY];
+        if (oz) v += f[c + oz] + left_own[pc + oz];
+        if (oy && oz) v += f[c + oy * sY + oz] + left_own[pc + oy * sY + oz];
+        f[c] = v;
         return;
     }
     // received planes cover the interior edge rows i < ng (low face) / i >= nx - ng (high face), whole planes
@@ -1227,12 +1263,13 @@ __global__ void __launch_bounds__(256) k_fold_all(GridV g, int axes, const doubl
     }
 }
 
-int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, void *stream) {
+int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, const double *left_own, void *stream) {
     LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx > 0 && g->ny > 0 && g->ng > 0, "lpai_fold_all: bad grid");
     const int dim = g->nz > 1 ? 3 : 2;
     LPA_REQUIRE(g->nx >= 2 * g->ng && g->ny >= 2 * g->ng && (dim == 2 || g->nz >= 2 * g->ng),
                 "lpai_fold_all: slab thinner than 2*ng");
     LPA_REQUIRE(!((r_lo || r_hi) && (axes & 1)), "lpai_fold_all: x is either folded locally or split over slabs");
+    LPA_REQUIRE(!left_own || r_lo, "lpai_fold_all: the left neighbour's own jx plane comes with its guard planes");
     if (axes == 0 && !r_lo && !r_hi) return LPA_OK;
     GridV v;
     memset(&v, 0, sizeof v);
@@ -1240,7 +1277,7 @@ int lpai_fold_all(const lpa_grid *g, int axes, const double *r_lo, const double 
     v.NX = g->nx + 2 * g->ng; v.NY = g->ny + 2 * g->ng; v.NZ = dim == 3 ? g->nz + 2 * g->ng : 1;
     v.jx = g->jx; v.jy = g->jy; v.jz = g->jz; v.rho = g->rho;
     dim3 gp = dim == 3 ? dim3((v.NZ + 255) / 256, v.NY, v.NX) : dim3((v.NY + 255) / 256, v.NX);
-    hipLaunchKernelGGL(k_fold_all, gp, dim3(256), 0, (hipStream_t)stream, v, axes, r_lo, r_hi);
+    hipLaunchKernelGGL(k_fold_all, gp, dim3(256), 0, (hipStream_t)stream, v, axes, r_lo, r_hi, left_own);
     LPA_CHECK_LAUNCH("lpai_fold_all");
     return LPA_OK;
 }

@@ -11,7 +11,9 @@
 // (simulation.py:948-960, 1043-1080, 1104-1118).  x planes are contiguous in the field arrays, so E / B guard planes are
 // sent from and received into the arrays themselves (no pack / unpack launch); the J / rho guard planes leave from the
 // arrays and are added by one launch; four message rounds per step (B1 | J + rho + every species' leavers | B2 + the jx
-// plane of the continuity update | E2, E1 of the next step when the caller defers the E2 guards).
+// plane of the continuity update | E2, E1 of the next step when the caller defers the E2 guards) -- or two, with
+// LPA_STEP_B_EXT_*: the B sweeps advance the x guard planes themselves (exact: they read only E, whose guard planes are
+// current) and the jx plane of the continuity update is formed from what travels with J.
 #include "lpa_common.hpp"
 
 static long plane_of(const lpa_grid *g) { return (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1); }
@@ -42,8 +44,13 @@ static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx,
     return lpa_comm_exchange(sl->comm, m, nm, st);
 }
 
+// (B sweeps of a slab with LPA_STEP_B_EXT_*: the x guard planes at a face with a neighbour are advanced in place)
+static bool local_b(const lpa_step_desc *d) { return (d->flags & (LPA_STEP_B_EXT_LO | LPA_STEP_B_EXT_HI)) != 0; }
+
 static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false) {
-    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, st);
+    const int ng = d->grid.ng > 3 ? 3 : d->grid.ng;
+    const int lo = (!efield && (d->flags & LPA_STEP_B_EXT_LO)) ? ng : 0, hi = (!efield && (d->flags & LPA_STEP_B_EXT_HI)) ? ng - 1 : 0;
+    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, lo, hi, st);
 }
 
 static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
@@ -225,7 +232,7 @@ static int slab_pack_exchange(const lpa_step_desc *d, bool headers_zeroed, void 
     LPA_REQUIRE(sl->cur_r_lo && sl->cur_r_hi && sl->migrate_capacity > 0 && sl->xlo < sl->xhi, "lpa_step: bad slab descriptor");
     const long plane = plane_of(g), n = (long)g->ng * plane;
     const long nmig = 1 + (long)LPA_MIG_NATTR * sl->migrate_capacity;
-    lpa_face_msg m[4 + 64];
+    lpa_face_msg m[5 + 64];
     double *f[4] = {g->jx, g->jy, g->jz, g->rho};
     for (int c = 0; c < 4; c++) {
         m[c].send_lo = f[c];                                   // my low guard planes -> the left neighbour's interior edge
@@ -235,6 +242,13 @@ static int slab_pack_exchange(const lpa_step_desc *d, bool headers_zeroed, void 
         m[c].n_send_lo = m[c].n_send_hi = m[c].n_recv_lo = m[c].n_recv_hi = n;
     }
     int nm = 4;
+    if (sl->rho_exchange == 2) {    // my own jx deposit on my last node plane -> the right neighbour (see k_fold_all)
+        m[nm].send_lo = nullptr; m[nm].recv_hi = nullptr; m[nm].n_send_lo = m[nm].n_recv_hi = 0;
+        m[nm].send_hi = g->jx + (long)(g->ng + g->nx - 1) * plane;
+        m[nm].recv_lo = sl->jx_left_plane;
+        m[nm].n_send_hi = m[nm].n_recv_lo = plane;
+        nm++;
+    }
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
         const lpa_step_migrate *mg = &sp->mig;
@@ -259,7 +273,8 @@ static int slab_fold_unpack(const lpa_step_desc *d, void *st) {
     int32_t info[6];
     if (int e = lpa_comm_info(sl->comm, info)) return e;
     const bool has_left = info[3] >= 0, has_right = info[4] >= 0;
-    if (int e = lpai_fold_all(g, d->local_axes, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr, st)) return e;
+    if (int e = lpai_fold_all(g, d->local_axes, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr,
+                              has_left && sl->rho_exchange == 2 ? sl->jx_left_plane : nullptr, st)) return e;
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
         const lpa_step_migrate *mg = &sp->mig;
@@ -303,7 +318,9 @@ static int slab_rho(const lpa_step_desc *d, void *st) {
     int32_t info[6];
     if (int e = lpa_comm_info(sl->comm, info)) return e;
     const int split = (info[3] >= 0 ? 1 : 0) | (info[4] >= 0 ? 2 : 0);
-    return lpa_rho_continuity(&d->grid, d->dt, d->local_axes, split, info[3] >= 0 ? sl->jx_left_plane : nullptr, st);
+    // (rho_exchange 2: the fold left the neighbour's folded plane in my jx guard plane at node -1)
+    const double *left = sl->rho_exchange == 2 ? d->grid.jx + (long)(d->grid.ng - 1) * plane_of(&d->grid) : sl->jx_left_plane;
+    return lpa_rho_continuity(&d->grid, d->dt, d->local_axes, split, info[3] >= 0 ? left : nullptr, st);
 }
 
 extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage, void *stream) {
@@ -318,6 +335,10 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     const bool slab = d->slab && d->slab->comm;
     LPA_REQUIRE(!slab || !(d->local_axes & 1), "lpa_step: x is split over slabs, not periodic inside one");
     LPA_REQUIRE(!slab || !d->slab->rho_exchange || d->slab->jx_left_plane, "lpa_step: jx_left_plane missing");
+    LPA_REQUIRE(!local_b(d) || !(d->local_axes & 1), "lpa_step: LPA_STEP_B_EXT_* is for slabs split along x");
+    LPA_REQUIRE(!slab || !local_b(d) || d->slab->rho_exchange != 1, "lpa_step: without B messages the jx plane travels with J (rho_exchange 2)");
+    // the B guard stages of such a slab wrap the y / z guards of the x guard planes it advanced, too
+    const int b_wrap = d->local_axes | (local_b(d) ? 8 : 0);
     bool headers_zeroed = false, counters_zeroed = false, exchanged = false;
     // overlapped push + exchange: only when this call runs on through the fold and every store is tile ordered
     bool overlap = slab && d->slab->overlap_cols > 0 && first_stage <= LPA_STAGE_PUSH && last_stage >= LPA_STAGE_FOLD;
@@ -339,7 +360,7 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
         }
         case LPA_STAGE_B1:      // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
             e = step_fields(d, false, d->local_axes, stream);
-            if (!e && slab) e = slab_exchange_guards(d, 2, false, stream);
+            if (!e && slab && !local_b(d)) e = slab_exchange_guards(d, 2, false, stream);
             break;
         case LPA_STAGE_RESET: { // current_depositor.reset(): :980-981
             // (+ the per-step counters of the push that follows in the same call: one launch for both)
@@ -376,10 +397,10 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
                 if (!exchanged) e = slab_pack_exchange(d, headers_zeroed, stream);
                 if (!e) e = slab_fold_unpack(d, stream);
                 // (rho: with rho_exchange the jx plane rides with the B planes of LPA_STAGE_B2_GUARD and rho follows there)
-                if (!e && d->continuity && !d->slab->rho_exchange) e = slab_rho(d, stream);
+                if (!e && d->continuity && d->slab->rho_exchange != 1) e = slab_rho(d, stream);
                 break;
             }
-            e = lpai_fold_all(g, d->local_axes, nullptr, nullptr, stream);
+            e = lpai_fold_all(g, d->local_axes, nullptr, nullptr, nullptr, stream);
             if (!e && d->continuity) e = lpa_rho_continuity(g, d->dt, d->local_axes, 0, nullptr, stream);
             break;
         case LPA_STAGE_B2:      // update_bfield(dt / 2): :1098 (the '_laser' stage follows: :1101)
@@ -387,10 +408,10 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             e = step_fields(d, false, last_stage >= LPA_STAGE_B2_GUARD ? d->local_axes : 0, stream);
             break;
         case LPA_STAGE_B2_GUARD:    // sync_guard_fields(B): :1103-1108
-            if (first_stage > LPA_STAGE_B2) e = lpa_guard_wrap(g, 2, d->local_axes, stream);
-            if (!e && slab) {
-                e = slab_exchange_guards(d, 2, d->slab->rho_exchange != 0, stream);
-                if (!e && d->continuity && d->slab->rho_exchange) e = slab_rho(d, stream);
+            if (first_stage > LPA_STAGE_B2) e = lpa_guard_wrap(g, 2, b_wrap, stream);
+            if (!e && slab && !local_b(d)) {
+                e = slab_exchange_guards(d, 2, d->slab->rho_exchange == 1, stream);
+                if (!e && d->continuity && d->slab->rho_exchange == 1) e = slab_rho(d, stream);
             }
             break;
         }

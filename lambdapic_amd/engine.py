@@ -35,14 +35,30 @@ from .rho import RhoContinuityMixin
 from .step import FusedStepMixin
 
 
+def psi_ptr(layer, key):
+    """device address of a CPML layer's psi array as the kernels index it: row 0 = the slab's x node 0.  The arrays of
+    the y / z layers carry ``xpad`` extra x rows in front (and behind): a slab with neighbours advances B -- and with it the
+    B psi of those layers -- on its x guard planes too (lpa_step, LPA_STEP_B_EXT_*)"""
+    t = layer[key]
+    return t.data_ptr() + 8 * layer.get("xpad", 0) * layer.get("row", 0)
+
+
+def psi_rows(layer, key, guards=False):
+    """psi array of a y / z layer as [x rows][...]: the nx rows of the slab's nodes, or (``guards``) with the xpad guard rows"""
+    pad = layer.get("xpad", 0)
+    v = layer[key].view(-1, layer["row"])
+    return v if guards or not pad else v[pad:v.shape[0] - pad]
+
+
 class DevicePML2D:
     """CPML coefficients and psi arrays of one rank's slab (reference: per-patch ``PML`` objects,
     `core/boundary/cpml.py:23-340`; slab mapping as in oracle/cpml.py).  Host builds the per-axis
-    kappa / sigma / a profiles; bcoeff / ccoeff_d (`cpml.py:537-538`) are cached per dt."""
+    kappa / sigma / a profiles; bcoeff / ccoeff_d (`cpml.py:537-538`) are cached per dt.  psi arrays are compact: x layers
+    [layer][ny], y layers [xpad + nx + xpad][layer] (``psi_ptr`` / ``psi_rows``)."""
 
-    def __init__(self, nx, ny, dx, dy, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7):
+    def __init__(self, nx, ny, dx, dy, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7, xpad=0):
         self.nx, self.ny, self.dx, self.dy, self.t = nx, ny, dx, dy, int(thickness)
-        self.sides, self.device = set(sides), device
+        self.sides, self.device, self.xpad = set(sides), device, int(xpad)
         m, ma = 3, 1
         smax = sigma_max * constants.C_LIGHT * 0.8 * (m + 1.0) / dx      # cpml.py:60 (dx for every axis)
         self.host = {}
@@ -69,7 +85,7 @@ class DevicePML2D:
         # pml_boundary: simulation.py:455-463)
         self.layers = []
         for fld in ("e", "b"):
-            for axis, ax, n, nt in ((0, "x", nx, ny), (1, "y", ny, nx)):
+            for axis, ax, n, nt in ((0, "x", nx, ny), (1, "y", ny, nx + 2 * self.xpad)):
                 rng = []
                 if ax + "min" in self.sides:
                     rng.append((0, self.t))
@@ -78,7 +94,8 @@ class DevicePML2D:
                 for s0, s1 in rng:
                     z = lambda: torch.zeros((s1 - s0) * nt, dtype=torch.float64, device=device)
                     self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
-                                            psi_a=z(), psi_b=z()))
+                                            psi_a=z(), psi_b=z(), xpad=self.xpad if axis else 0,
+                                            row=(s1 - s0) if axis else ny))
         self._coef = {}
 
     def __getstate__(self):
@@ -154,7 +171,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if bc["xmax"] == "pml" and self.comm.rank == self.comm.size - 1:
             sides.append("xmax")
         self.pml = DevicePML2D(self.nx, self.ny, self.dx, self.dy, sides, self.cpml_thickness,
-                               self.device) if sides else None
+                               self.device, xpad=self.ng) if sides else None
         # particle absorption at open (PML) faces: the owner's bounds are pulled in by the layer
         # thickness (core/patch/patch.py:105-148) and a particle beyond them has no neighbour to go to
         self.absorb = 0
@@ -362,10 +379,10 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                         continue
                     if ly["start"] == 0:
                         d.lo0, d.lo1 = ly["start"], ly["stop"]
-                        d.psi_a_lo, d.psi_b_lo = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                        d.psi_a_lo, d.psi_b_lo = psi_ptr(ly, "psi_a"), psi_ptr(ly, "psi_b")
                     else:
                         d.hi0, d.hi1 = ly["start"], ly["stop"]
-                        d.psi_a_hi, d.psi_b_hi = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                        d.psi_a_hi, d.psi_b_hi = psi_ptr(ly, "psi_a"), psi_ptr(ly, "psi_b")
                 out.append(d)
             if len(self._axes) > 16:
                 self._axes.clear()
@@ -378,8 +395,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                 continue
             b, cc = self.pml.coef(ly["key"], dt, self.dx if ly["axis"] == 0 else self.dy)
             check(self.L.lpa_cpml_psi_2d(self._g(), int(efield), ly["axis"], ly["start"], ly["stop"], dt,
-                                         b.data_ptr(), cc.data_ptr(), ly["psi_a"].data_ptr(),
-                                         ly["psi_b"].data_ptr(), self.stream), "lpa_cpml_psi_2d")
+                                         b.data_ptr(), cc.data_ptr(), psi_ptr(ly, "psi_a"),
+                                         psi_ptr(ly, "psi_b"), self.stream), "lpa_cpml_psi_2d")
 
     # ---- laser injection (Laser.__call__ at stage '_laser', callback/laser.py:109-137) -------------
     def laser_inject(self, ey_source, ez_source, dt):
@@ -711,7 +728,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         # (+ how far ahead of its position the sort may have binned a particle: one that sits at the face and moves inward
         # is filed that much further in)
         ahead = max([getattr(sp, "sort_ahead_used", 0.0) for sp in self.species] + [0.0]) * constants.C_LIGHT / self.dx
-        drift = constants.C_LIGHT * dt / self.dx * age + 4.0 + ahead     # + the 3 nodes a deposit window reaches, + 1
+        drift = constants.C_LIGHT * dt / self.dx * age + 5.0 + ahead     # + the 3 nodes a deposit window reaches, + 1, + 1 (the
+        # last node plane's own jx travels with the guard planes: rho_exchange 2)
         cols = int(np.ceil(drift / _lib.LPA_TILE_X))
         return cols if 2 * cols < self.nx // _lib.LPA_TILE_X else 0
 
@@ -840,6 +858,9 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     leaver_lists = True      # native slab steps: the push kernels report the leavers (lpa_push_params.leavers)
 
+    def n_x_local(self):
+        return self.nx
+
     def _slab_fill(self, slab):
         """the slab section of an lpa_step descriptor (step.py); returns what must stay alive until the launches ran"""
         slab.xlo, slab.xhi = self._owner_bounds_x()
@@ -847,7 +868,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         slab.migrate_capacity = self.migrate_capacity
         h = self._halo_views(4 * self.ng * self.grid.NY)
         slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
-        slab.rho_exchange = int(self.rho_continuity and self._rho_available())
+        # (2: the jx plane of the continuity update is formed from what travels with J -- steps without B messages)
+        slab.rho_exchange = int(self.rho_continuity and self._rho_available()) * (2 if self.local_b() else 1)
         if slab.rho_exchange:
             self._jx_plane_bufs()
             slab.jx_left_plane = self._jx_plane.data_ptr()
@@ -927,7 +949,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         sides = [s_ for s_ in old.sides if s_[0] != "x"]
         if len(sides) == len(old.sides):
             return
-        new = DevicePML2D(self.nx, self.ny, self.dx, self.dy, sides, self.cpml_thickness, self.device) if sides else None
+        new = DevicePML2D(self.nx, self.ny, self.dx, self.dy, sides, self.cpml_thickness, self.device,
+                          xpad=old.xpad) if sides else None
         if new is not None:      # the y layers keep their psi history
             keep = {(l["e"], l["axis"], l["start"]): l for l in old.layers}
             for l in new.layers:
@@ -965,14 +988,14 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                 else:
                     self.comm.exchange(one(), send, recv, one())
 
-        # ---- what leaves through the trailing face: n + ng interior columns next to it and n psi rows
+        # ---- what leaves through the trailing face: n + ng interior columns next to it, and the same rows of the y layers'
+        # psi arrays (they carry x guard rows like the fields: psi_rows)
         cols = slice(ng, ng + n + ng) if fwd else slice(nx - n, nx + ng)
-        rows = slice(0, n) if fwd else slice(nx - n, nx)
+        assert all(l["xpad"] == ng for l in ylayers)
         parts = [g.buf[:, cols].reshape(-1)]
         for l in ylayers:
-            nl = l["stop"] - l["start"]
             for k in ("psi_a", "psi_b"):
-                parts.append(l[k].view(nx, nl)[rows].reshape(-1))
+                parts.append(psi_rows(l, k, guards=True)[cols].reshape(-1))
         send = torch.cat(parts)
         recv = torch.zeros_like(send)          # stays zero on the leading rank: fresh columns
         to_trailing(send, recv)
@@ -985,16 +1008,16 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             g.buf[:, :n + ng] = recv[:nf].view(10, n + ng, g.NY)
         off = nf
         for l in ylayers:
-            nl = l["stop"] - l["start"]
+            nl = l["row"]
             for k in ("psi_a", "psi_b"):
-                v = l[k].view(nx, nl)
+                v = psi_rows(l, k, guards=True)          # [NX][nl]: shifted exactly like the field columns
                 if fwd:
-                    v[: nx - n] = v[n:].clone()
-                    v[nx - n:] = recv[off:off + n * nl].view(n, nl)
+                    v[:keep] = v[n:n + keep].clone()
+                    v[keep:] = recv[off:off + (n + ng) * nl].view(n + ng, nl)
                 else:
-                    v[n:] = v[: nx - n].clone()
-                    v[:n] = recv[off:off + n * nl].view(n, nl)
-                off += n * nl
+                    v[NX - keep:] = v[NX - keep - n:NX - n].clone()
+                    v[:n + ng] = recv[off:off + (n + ng) * nl].view(n + ng, nl)
+                off += (n + ng) * nl
         shift = (n if fwd else -n) * self.dx
         self.x0_global += shift
         self.x0 += shift
@@ -1153,27 +1176,32 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
     def _step_segments(self, dt, defer_e2=False, laser=None):
         """a slab rank whose faces travel through torch.distributed: the kernels between two exchanges are enqueued by one
         ``lpa_step`` sub-range each, Python moves the faces in between (E1 | xchg | B1 | xchg | reset + push | J, rho and
-        leavers | B2 | xchg + the jx plane of rho | E2 | xchg) -- four or five message rounds per step"""
-        S, E, B = _lib, ("ex", "ey", "ez"), ("bx", "by", "bz")
-        st = self.stream
+        leavers | B2 | xchg + the jx plane of rho | E2 | xchg) -- four or five message rounds per step; with ``local_b``
+        (E1 | xchg | B1 + reset + push | J, rho and leavers | the jx plane of rho | B2 + E2 | xchg): three or four"""
+        S = _lib
+        local_b = self.local_b()        # the B sweeps advance the x guard planes themselves: no B message (step.py)
         self.step_stages(dt, S.LPA_STAGE_E1, S.LPA_STAGE_E1)       # (E half step + the local guard wrap)
         self._exchange_guards(1)
-        self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
-        self._exchange_guards(2)
-        self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)  # (sorts when due, decides the rho mode)
-        self.defer_rho = True
+        if local_b:
+            self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_PUSH)
+        else:
+            self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
+            self._exchange_guards(2)
+            self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)  # (sorts when due, decides the rho mode)
+        self.defer_rho = not local_b    # (the jx plane rides with the B planes that follow -- or travels alone)
         try:
             self.sync_currents_and_particles()
         finally:
             self.defer_rho = False
         if laser is None:
-            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2_GUARD)
+            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_E2 if local_b else S.LPA_STAGE_B2_GUARD, defer_e2 and local_b)
         else:
             self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
             laser(self, dt)
-            self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
-        self._exchange_guards(2)                                    # (+ the jx plane; completes rho)
-        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)      # (deferred: nothing is launched, the next E1 doubles)
+            self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_E2 if local_b else S.LPA_STAGE_B2_GUARD, defer_e2 and local_b)
+        if not local_b:
+            self._exchange_guards(2)                                    # (+ the jx plane; completes rho)
+            self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)  # (deferred: nothing is launched, the next E1 doubles)
         if not defer_e2:
             self._exchange_guards(1)
 

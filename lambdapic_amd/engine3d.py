@@ -24,7 +24,7 @@ from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import restore_device, to_host
 from .dist import SlabComm, exchange_faces
-from .engine import PicEngine2D
+from .engine import PicEngine2D, psi_ptr, psi_rows
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 from .rho import RhoContinuityMixin
 from .step import FusedStepMixin
@@ -41,11 +41,12 @@ SIDES3 = ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")
 class DevicePML3D:
     """CPML coefficients and psi arrays of one rank's 3-D slab (reference: per-patch ``PML`` objects,
     `core/boundary/cpml.py:23-340`; slab mapping as in oracle/cpml.py:SlabPML3D).  psi arrays are compact
-    (axis 0: [layer][ny][nz], axis 1: [nx][layer][nz], axis 2: [nx][ny][layer])."""
+    (axis 0: [layer][ny][nz], axis 1: [nx][layer][nz], axis 2: [nx][ny][layer]; the y / z layers' arrays carry ``xpad``
+    extra x rows in front and behind, see ``engine.psi_ptr``)."""
 
-    def __init__(self, n, d, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7):
+    def __init__(self, n, d, sides, thickness, device, kappa_max=20.0, a_max=0.15, sigma_max=0.7, xpad=0):
         self.n, self.d, self.t = tuple(n), tuple(d), int(thickness)
-        self.sides, self.device = set(sides), device
+        self.sides, self.device, self.xpad = set(sides), device, int(xpad)
         m, ma = 3, 1
         smax = sigma_max * constants.C_LIGHT * 0.8 * (m + 1.0) / d[0]      # cpml.py:60 (dx for every axis)
         self.host = {}
@@ -78,10 +79,12 @@ class DevicePML3D:
                 if ax + "max" in self.sides:
                     rng.append((nn - self.t, nn) if fld == "e" else (nn - self.t - 1, nn - 1))
                 for s0, s1 in rng:
-                    cells = (s1 - s0) * int(np.prod([v for k, v in enumerate(self.n) if k != axis]))
+                    row = (s1 - s0) * int(np.prod([v for k, v in enumerate(self.n) if k not in (axis, 0)]))   # per x row
+                    cells = row * (self.n[0] + 2 * self.xpad) if axis else (s1 - s0) * self.n[1] * self.n[2]
                     z = lambda: torch.zeros(cells, dtype=torch.float64, device=device)
                     self.layers.append(dict(e=fld == "e", axis=axis, key=fld + ax, start=s0, stop=s1,
-                                            psi_a=z(), psi_b=z()))
+                                            psi_a=z(), psi_b=z(), xpad=self.xpad if axis else 0,
+                                            row=row if axis else self.n[1] * self.n[2]))
         self._coef = {}
 
     def __getstate__(self):
@@ -172,7 +175,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             sides.append("xmin")
         if bc["xmax"] == "pml" and self.comm.rank == self.comm.size - 1:
             sides.append("xmax")
-        self.pml = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device) if sides else None
+        self.pml = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device, xpad=self.ng) if sides else None
         # particle absorption at open faces: bounds pulled in by the layer thickness (patch.py:105-148)
         self.absorb = 0
         self.alo, self.ahi = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
@@ -586,6 +589,9 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     leaver_lists = True
 
+    def n_x_local(self):
+        return self.n[0]
+
     def _slab_fill(self, slab):
         """the slab section of an lpa_step descriptor (step.py)"""
         slab.xlo, slab.xhi = self._owner_bounds_x()
@@ -593,7 +599,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         slab.migrate_capacity = self.migrate_capacity
         h = self._halo_views(4)
         slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
-        slab.rho_exchange = int(self.rho_continuity and self._rho_available())
+        slab.rho_exchange = int(self.rho_continuity and self._rho_available()) * (2 if self.local_b() else 1)
         if slab.rho_exchange:
             self._jx_plane_bufs()
             slab.jx_left_plane = self._jx_plane.data_ptr()
@@ -725,10 +731,10 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                         continue
                     if ly["start"] == 0:
                         d.lo0, d.lo1 = ly["start"], ly["stop"]
-                        d.psi_a_lo, d.psi_b_lo = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                        d.psi_a_lo, d.psi_b_lo = psi_ptr(ly, "psi_a"), psi_ptr(ly, "psi_b")
                     else:
                         d.hi0, d.hi1 = ly["start"], ly["stop"]
-                        d.psi_a_hi, d.psi_b_hi = ly["psi_a"].data_ptr(), ly["psi_b"].data_ptr()
+                        d.psi_a_hi, d.psi_b_hi = psi_ptr(ly, "psi_a"), psi_ptr(ly, "psi_b")
                 out.append(d)
             if len(self._axes) > 16:
                 self._axes.clear()
@@ -741,8 +747,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                 continue
             b, cc = self.pml.coef(ly["key"], dt, self.d[ly["axis"]])
             check(self.L.lpa_cpml_psi_3d(self._g(), int(efield), ly["axis"], ly["start"], ly["stop"], dt,
-                                         b.data_ptr(), cc.data_ptr(), ly["psi_a"].data_ptr(),
-                                         ly["psi_b"].data_ptr(), self.stream), "lpa_cpml_psi_3d")
+                                         b.data_ptr(), cc.data_ptr(), psi_ptr(ly, "psi_a"),
+                                         psi_ptr(ly, "psi_b"), self.stream), "lpa_cpml_psi_3d")
 
     def laser_inject(self, ey_source, ez_source, dt):
         """``ey_source, ez_source``: [ny][nz] source fields on the x-min boundary at the current time
@@ -780,7 +786,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         sides = [s_ for s_ in old.sides if s_[0] != "x"]
         if len(sides) == len(old.sides):
             return
-        new = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device) if sides else None
+        new = DevicePML3D(self.n, self.d, sides, self.cpml_thickness, self.device, xpad=old.xpad) if sides else None
         if new is not None:      # the y / z layers keep their psi history
             keep = {(l["e"], l["axis"], l["start"]): l for l in old.layers}
             for l in new.layers:
@@ -807,8 +813,8 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         lay = [l for l in self.pml.layers if l["axis"] != 0] if self.pml is not None else []
         one = lambda: torch.zeros(1, dtype=torch.float64, device=self.device)
 
-        def rows(l, k):          # psi array of a y / z layer as [nx][...]
-            return l[k].view(nx, -1)
+        def rows(l, k):          # psi array of a y / z layer as [NX][...]: x guard rows included, shifted like the fields
+            return psi_rows(l, k, guards=True)
 
         def to_trailing(send, recv):
             if self.comm.size > 1:
@@ -818,11 +824,11 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                     self.comm.exchange(one(), send, recv, one())
 
         cols = slice(ng, ng + n + ng) if fwd else slice(nx - n, nx + ng)
-        prow = slice(0, n) if fwd else slice(nx - n, nx)
+        assert all(l["xpad"] == ng for l in lay)
         parts = [self.buf[:, cols].reshape(-1)]
         for l in lay:
             for k in ("psi_a", "psi_b"):
-                parts.append(rows(l, k)[prow].reshape(-1))
+                parts.append(rows(l, k)[cols].reshape(-1))
         send = torch.cat(parts)
         recv = torch.zeros_like(send)
         to_trailing(send, recv)
@@ -840,12 +846,12 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
                 v = rows(l, k)
                 w = v.shape[1]
                 if fwd:
-                    v[: nx - n] = v[n:].clone()
-                    v[nx - n:] = recv[off:off + n * w].view(n, w)
+                    v[:keep] = v[n:n + keep].clone()
+                    v[keep:] = recv[off:off + (n + ng) * w].view(n + ng, w)
                 else:
-                    v[n:] = v[: nx - n].clone()
-                    v[:n] = recv[off:off + n * w].view(n, w)
-                off += n * w
+                    v[NX - keep:] = v[NX - keep - n:NX - n].clone()
+                    v[:n + ng] = recv[off:off + (n + ng) * w].view(n + ng, w)
+                off += (n + ng) * w
         shift = (n if fwd else -n) * self.d[0]
         self.x0 += shift
         self.c.x0 = self.x0
@@ -958,7 +964,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         """see PicEngine2D.edge_columns (the sort, when due, runs inside the edge pass: age 0 then)"""
         age = max([0 if sp["since"] >= self.sort_interval else sp["since"] for sp in self.species] + [0]) + 1
         ahead = max([sp.get("sort_ahead_used", 0.0) for sp in self.species] + [0.0]) * constants.C_LIGHT / self.d[0]
-        drift = constants.C_LIGHT * dt / self.d[0] * age + 4.0 + ahead   # + the 3 nodes a deposit window reaches, + 1; + the sort's look-ahead
+        drift = constants.C_LIGHT * dt / self.d[0] * age + 5.0 + ahead   # + the 3 nodes a deposit window reaches, + 1, + 1 (2-D twin); + the sort's look-ahead
         cols = int(np.ceil(drift / _lib.LPA_TILE3_X))
         return cols if 2 * cols < self.n[0] // _lib.LPA_TILE3_X else 0
 
@@ -1068,24 +1074,29 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
     def _step_segments(self, dt, laser=None, defer_e2=False):
         """see PicEngine2D._step_segments: sub-ranges of lpa_step between the exchanges torch.distributed carries"""
         S = _lib
+        local_b = self.local_b()
         self.step_stages(dt, S.LPA_STAGE_E1, S.LPA_STAGE_E1)
         self._exchange_guards(1)
-        self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
-        self._exchange_guards(2)
-        self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)
-        self.defer_rho = True
+        if local_b:
+            self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_PUSH)
+        else:
+            self.step_stages(dt, S.LPA_STAGE_B1, S.LPA_STAGE_B1)
+            self._exchange_guards(2)
+            self.step_stages(dt, S.LPA_STAGE_RESET, S.LPA_STAGE_PUSH)
+        self.defer_rho = not local_b
         try:
             self.sync_currents_and_particles()
         finally:
             self.defer_rho = False
         if laser is None:
-            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2_GUARD)
+            self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_E2 if local_b else S.LPA_STAGE_B2_GUARD, defer_e2 and local_b)
         else:
             self.step_stages(dt, S.LPA_STAGE_B2, S.LPA_STAGE_B2)
             laser(self, dt)
-            self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_B2_GUARD)
-        self._exchange_guards(2)
-        self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)      # (deferred: nothing is launched, the next E1 doubles)
+            self.step_stages(dt, S.LPA_STAGE_B2_GUARD, S.LPA_STAGE_E2 if local_b else S.LPA_STAGE_B2_GUARD, defer_e2 and local_b)
+        if not local_b:
+            self._exchange_guards(2)
+            self.step_stages(dt, S.LPA_STAGE_E2, S.LPA_STAGE_E2, defer_e2)  # (deferred: nothing is launched, the next E1 doubles)
         if not defer_e2:
             self._exchange_guards(1)
 

@@ -7,9 +7,10 @@ cost per launch is the HIP launch itself.
 Slab ranks (``comm.size > 1``):
 
 * with the library's own transport (``SlabComm.attach_rccl``, ``LoopbackComm``) the descriptor carries a slab section and
-  the SAME single call also moves the x faces (ncclSend / ncclRecv groups issued from C on the step's stream): four message
-  rounds per step -- B1 | J + rho + every species' leavers | B2 + the jx plane of the continuity update | E (E2 of this step
-  and E1 of the next when the caller runs steps back to back, ``defer_e2``);
+  the SAME single call also moves the x faces (ncclSend / ncclRecv groups issued from C on the step's stream): two message
+  rounds per step -- J + rho + every species' leavers | E (E2 of this step and E1 of the next when the caller runs steps
+  back to back, ``defer_e2``); B does not travel (``local_b_guards``; four rounds without it: + B1, B2 with the jx plane of
+  the continuity update);
 * without it (gloo rehearsals, ranks sharing a GPU in the tests, torch's own nccl group) the engines call ``step_stages``
   for the ranges between two exchanges and move the faces from Python (engines: ``_step_segments``).
 
@@ -47,6 +48,22 @@ class FusedStepMixin:
             self.sync_guard_fields(("ex", "ey", "ez") if self.dim == 2 else 1)
     fuse_species = True        # 3-D: every tile-ordered species in ONE launch (lpa_push_deposit_tiled_multi_3d)
 
+    # Slab ranks: the B half steps of ``lpa_step`` advance the x guard planes at the faces with a neighbour themselves (ng
+    # planes low, ng - 1 high: a B update reads E at its node and one node up, and the E guard planes are current after
+    # every E guard stage) -- the values the neighbour computes for its interior, bit for bit -- so B never travels: two
+    # message rounds per step (E | J + rho + particles) instead of four.  What it takes: psi rows for the x guard planes in
+    # the y / z CPML layers (``psi_ptr``), all ng B guard planes current whenever B was changed outside lpa_step (initial
+    # fields, window shifts and ``sync_guard_fields`` leave them so), no injection within ng + 1 nodes of a shared face.
+    local_b_guards = True
+    _b_guards_current = False
+
+    def local_b(self):
+        if not (self.local_b_guards and self.comm.size > 1 and self.can_fuse()):
+            return False
+        # (the antenna of a laser sits cpml_thickness + 2 nodes inside the rank that owns the x-min layer: clear of its
+        # high face by more than the guard)
+        return self.n_x_local() >= getattr(self, "cpml_thickness", 0) + 2 + 2 * self.ng + 2
+
     def can_fuse(self):
         return self.fused_step and (self.pml is None or self.fused_cpml)
 
@@ -69,6 +86,11 @@ class FusedStepMixin:
         native = self.native_slab()
         if self.comm.size > 1 and not native and first <= _lib.LPA_STAGE_FOLD <= last:
             raise _lib.LpaError("slab ranks without a native transport fold their currents from Python (sync_currents)")
+        if first <= _lib.LPA_STAGE_B1 and not self._b_guards_current and self.local_b():
+            # once: whatever wrote the initial B (a test, a loader) may have left the x guard planes behind -- from here on
+            # the B sweeps carry them along
+            self._b_guards_current = True
+            self.sync_guard_fields(("bx", "by", "bz") if self.dim == 2 else 2)
         self._dt_hint = dt        # (the first sort of a store sizes its sort interval from the particles' speed)
         d = _lib.lpa_step_desc()
         d.grid = self._grid_struct()
@@ -80,6 +102,8 @@ class FusedStepMixin:
             d.flags |= _lib.LPA_STEP_DEFER_E2
         if first <= _lib.LPA_STAGE_E1 and self._e2_pending:
             d.flags |= _lib.LPA_STEP_E1_DOUBLE
+        if self.local_b():
+            d.flags |= (_lib.LPA_STEP_B_EXT_LO if self.comm.has_left else 0) | (_lib.LPA_STEP_B_EXT_HI if self.comm.has_right else 0)
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):

@@ -1,8 +1,10 @@
 """The slab path with the library's OWN transport (csrc/lpa_comm.hip) -- whole steps, exchanges included, enqueued by one
 ``lpa_step`` call -- on one GPU: a slab that is rank 0 of a periodic 2-slab ring whose other slab is its translated copy
 (``LoopbackComm``) must reproduce one half of a single-slab run of the doubled periodic box.  Every kernel of the N > 1
-path runs (E / B planes straight from the arrays, J / rho fold, leaver pack, arrival unpack with free slots, arrival area,
-the jx plane of the continuity update riding with the B planes); the wire is a copy kernel (``loopback``), a one-rank RCCL
+path runs (E planes straight from the arrays, B advanced on the x guard planes by the sweeps themselves -- or, with
+``local_b_guards`` off, exchanged like E --, J / rho fold, leaver pack, arrival unpack with free slots, arrival area, the jx
+plane of the continuity update formed from what travels with J -- or riding with the B planes); the wire is a copy kernel
+(``loopback``), a one-rank RCCL
 communicator sending to itself (``rccl``: real ncclSend / ncclRecv groups) or Python-side copies between ``lpa_step``
 sub-ranges (``python``: the path torch.distributed transports take).  Tolerance 1e-10: summation order only."""
 import ctypes as C
@@ -80,13 +82,14 @@ def _problem2d():
     return dx, dy, dt, x, y, u, w
 
 
-def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True, overlap=False):
+def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True, overlap=False, local_b=True):
     from lambdapic_amd.engine import PicEngine2D
     dx, dy, dt, x, y, u, w = _problem2d()
     eng = PicEngine2D(nx_cells, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
                       migrate_capacity=4096)
     eng.rho_continuity = rho
     eng.overlap = overlap
+    eng.local_b_guards = local_b
     n = x.size * copies
     eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=2 * n + 20000)
     s = eng.species[0].cset
@@ -125,20 +128,33 @@ def _close(a, b, tol=1e-10):
     return np.max(np.abs(a - b)) / scale < tol
 
 
+def _rows(eng, a, nx):
+    """x rows of field ``a`` a slab must share with the doubled box: its interior; for E and B also the guard planes (the
+    neighbour's edge) -- all of them, except that a slab advancing B on its guard planes itself keeps ng - 1 high ones"""
+    if a in ("rho", "jx"):
+        return 3, 3 + nx
+    return 0, nx + 6 - (1 if a[0] == "b" and eng.local_b() else 0)
+
+
+@pytest.mark.parametrize("local_b", [True, False])
 @pytest.mark.parametrize("transport", ["loopback", "rccl", "python"])
-def test_mirrored_slab_is_half_of_the_doubled_box_2d(doubled2d, transport):
+def test_mirrored_slab_is_half_of_the_doubled_box_2d(doubled2d, transport, local_b):
     tr2, f2 = doubled2d
     comm = _comm(transport, NX * _problem2d()[0], 4096)
-    tr, f, eng = _engine2d(NX, comm, 1)
-    assert eng.one_call_step() == (transport != "python")
+    tr, f, eng = _engine2d(NX, comm, 1, local_b=local_b)
+    assert eng.one_call_step() == (transport != "python") and eng.local_b() == local_b
     assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])                       # nobody lost, nobody doubled
     for k in range(3):
         assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
     for a in f:
         # interior of the slab + its x guard planes (E / B: the neighbour's edge) == the doubled box's left half
-        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        lo, hi = _rows(eng, a, NX)
         assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
     assert eng.rho_steps["continuity"] > eng.rho_steps["anchor"] > 0
+    if local_b and transport != "python":
+        # the jx guard plane at node -1 holds the left neighbour's folded jx at its last node (what the continuity update
+        # of node 0 reads): in the mirrored ring that neighbour's last node is the doubled box's node 2 NX - 1
+        assert _close(f["jx"][2, :], f2["jx"][3 + 2 * NX - 1, :])
 
 
 @pytest.mark.parametrize("overlap", [False, True])
@@ -160,7 +176,7 @@ def test_per_stage_path_over_the_native_transport_2d(doubled2d, overlap):
     for k in range(3):
         assert _close(2 * tr[:, k], tr2[:, k]), k
     for a in f:
-        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        lo, hi = _rows(eng, a, NX)
         assert _close(f[a][lo:hi], f2[a][lo:hi]), a
 
 
@@ -176,7 +192,7 @@ def test_overlapped_mirrored_slab_2d(doubled2d, transport):
     for k in range(3):
         assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
     for a in f:
-        lo, hi = (3, 3 + NX) if a in ("rho", "jx") else (0, NX + 6)
+        lo, hi = _rows(eng, a, NX)
         assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
 
 
@@ -215,7 +231,7 @@ def test_mirrored_slab_with_deposited_rho(doubled2d):
 N3 = (32, 16, 32)
 
 
-def _engine3d(nx_cells, comm, copies, nsteps=12, overlap=False):
+def _engine3d(nx_cells, comm, copies, nsteps=12, overlap=False, local_b=True):
     from lambdapic_amd import constants
     from lambdapic_amd.engine3d import PicEngine3D
     lam = 0.8e-6
@@ -231,6 +247,7 @@ def _engine3d(nx_cells, comm, copies, nsteps=12, overlap=False):
     u = rng.normal(size=(3, n)) * 0.3
     eng = PicEngine3D(nx_cells, N3[1], N3[2], *d, 3, sort_interval=5, comm=comm, migrate_capacity=8192)
     eng.overlap = overlap
+    eng.local_b_guards = local_b
     ntot = n * copies
     data = torch.full((8, 2 * ntot + eng.arrival_area() + 1024), float("nan"), dtype=torch.float64, device="cuda:0")
     cat = lambda a: torch.from_numpy(np.concatenate([a] * copies)).cuda()
@@ -256,21 +273,23 @@ def doubled3d():
     return tr, f
 
 
-@pytest.mark.parametrize("transport,overlap", [("loopback", False), ("rccl", False), ("python", False), ("loopback", True),
-                                               ("rccl", True)])
-def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overlap):
+@pytest.mark.parametrize("transport,overlap,local_b", [("loopback", False, True), ("rccl", False, True), ("python", False, True),
+                                                       ("loopback", True, True), ("rccl", True, True),
+                                                       ("loopback", False, False), ("python", False, False),
+                                                       ("loopback", True, False)])
+def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overlap, local_b):
     tr2, f2 = doubled3d
     lam = 0.8e-6
     comm = _comm(transport, N3[0] * lam / 20, 8192)
-    tr, f, eng, d = _engine3d(N3[0], comm, 1, overlap=overlap)
-    assert eng.one_call_step() == (transport != "python")
+    tr, f, eng, d = _engine3d(N3[0], comm, 1, overlap=overlap, local_b=local_b)
+    assert eng.one_call_step() == (transport != "python") and eng.local_b() == local_b
     if overlap:
         assert eng.edge_columns(0.95 / (CL * np.sqrt(sum(v ** -2 for v in d)))) > 0
     assert np.array_equal(tr[:, 3] * 2, tr2[:, 3])
     for k in range(3):
         assert _close(2 * tr[:, k], tr2[:, k]), (transport, k)
     for a in f:
-        lo, hi = (3, 3 + N3[0]) if a == "rho" else (0, N3[0] + 6)
+        lo, hi = _rows(eng, a, N3[0])
         assert _close(f[a][lo:hi], f2[a][lo:hi]), (transport, a)
 
 
