@@ -189,10 +189,12 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         self._ws = {}
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
-        # hide the J / rho guard exchange behind the interior tiles?  Off by default in 2-D: without a wire the
-        # split step costs 2.45 ms against 2.40 ms unsplit on C2 (tools/bench_mirror.py), so it only pays when a
-        # 100 KB face message takes longer than ~0.05 ms; the 3-D engine (6.6 MB per face) keeps it on
-        self.overlap = False
+        # hide the J / rho + particle exchange behind the interior tiles?  None = decide per step (``overlap``): the split
+        # costs ~20 us (an edge launch of few tiles) and hides one message round of 25-50 us of RCCL time plus the
+        # pack: it pays on big slabs over a real wire (a C2-sized slab, one-rank RCCL communicator: 2.049 -> 2.014-2.025 ms
+        # per step) and loses on small ones (C4 / 8: 0.297 -> 0.303-0.305; without a wire 0.234 -> 0.255); the 3-D engine
+        # (6.6 MB per face) keeps it on
+        self._overlap = None
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.defer_crossers = True
         # in-kernel cell-index sort (lpa_tiling.slot_class): re-seat the particles whose y-class changed, every step.
@@ -860,6 +862,19 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def n_x_local(self):
         return self.nx
+
+    OVERLAP_MIN_PARTICLES = 1 << 25
+
+    @property
+    def overlap(self):
+        if self._overlap is not None:
+            return self._overlap
+        return (self.comm.size > 1 and self.comm.native is not None and self.comm.native_kind == _lib.LPA_COMM_RCCL and
+                sum(sp.n for sp in self.species) >= self.OVERLAP_MIN_PARTICLES)
+
+    @overlap.setter
+    def overlap(self, v):
+        self._overlap = None if v is None else bool(v)
 
     def _slab_fill(self, slab):
         """the slab section of an lpa_step descriptor (step.py); returns what must stay alive until the launches ran"""

@@ -26,6 +26,7 @@ ap.add_argument("--transport", default="loopback", choices=["loopback", "rccl", 
                      "one lpa_step call); rccl: the same through a one-rank RCCL communicator sending to itself (real "
                      "ncclSend / ncclRecv groups); python: the faces moved from Python between lpa_step sub-ranges")
 ap.add_argument("--run-steps", action="store_true", help="engine.run_steps: E guards once per step (deferred E2 guards)")
+ap.add_argument("--b-messages", action="store_true", help="the B guard planes travel (local_b_guards off): four message rounds per step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
@@ -35,6 +36,7 @@ comm = MirrorComm(a.nx * dx, 32768) if a.transport == "python" else LoopbackComm
 eng, dt, n = bench.build_engine(a, comm, dev)
 assert eng.migrate_capacity == 32768
 eng.overlap = a.overlap
+eng.local_b_guards = not a.b_messages
 for _ in range(a.warmup):
     eng.step(dt)
 eng.kernel_events = []
@@ -52,7 +54,7 @@ print("counters [overflow, arrival cursor, overflow edge, surplus, leavers]:", w
       "fs" , None if ws0.get("fs") is None else (ws0["fs"].edge_cols, int(ws0["fs_count"].sum().item()), int(ws0["fs_count"].max().item())), file=sys.stderr)
 d = eng.diagnostics()
 w = float(eng.species[0].cset.arr("w")[0].item())
-print(json.dumps({"what": f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", overlapped" if a.overlap else "") +
+print(json.dumps({"what": f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", B messages" if a.b_messages else "") + (", overlapped" if a.overlap else "") +
                           (", run_steps" if a.run_steps else ""), "ms_per_step": 1e3 * el / a.steps,
                   "particle_updates_per_s_per_gpu": n * a.steps / el, "k1_edge_plus_interior_ms": k_ms,
                   "alive": d["nalive"][0], "particles": n,

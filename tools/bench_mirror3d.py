@@ -16,6 +16,7 @@ ap.add_argument("--overlap", action="store_true"); ap.add_argument("--single", a
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--transport", default="loopback", choices=["loopback", "rccl", "python"])   # see bench_mirror.py
 ap.add_argument("--run-steps", action="store_true")
+ap.add_argument("--b-messages", action="store_true", help="the B guard planes travel (local_b_guards off): four message rounds per step")
 a = ap.parse_args(argv)
 nx, ny, nz, ppc = 64, 256, 256, 8
 lam = 0.8e-6
@@ -26,6 +27,7 @@ comm = None if a.single else (MirrorComm(nx * dx, 262144) if a.transport == "pyt
                               LoopbackComm(nx * dx, 2, rccl=a.transport == "rccl"))
 eng = PicEngine3D(nx, ny, nz, dx, dy, dz, 3, sort_interval=10, comm=comm, migrate_capacity=262144)
 eng.overlap = a.overlap
+eng.local_b_guards = not a.b_messages
 n = nx * ny * nz * ppc
 dev = eng.device
 g = torch.Generator(device=dev).manual_seed(1)
@@ -52,6 +54,6 @@ else:
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = eng.diagnostics()
 print(json.dumps({"what": "3-D, " + ("single slab" if a.single else f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", run_steps" if a.run_steps else "") +
-                                      (", overlapped" if a.overlap else ", in line")),
+                                      (", B messages" if a.b_messages else "") + (", overlapped" if a.overlap else ", in line")),
                   "ms_per_step": 1e3 * el / a.steps, "alive": d["nalive"][0], "particles": n,
                   "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * 1.742e27 * dx * dy * dz / ppc * -constants.E_CHARGE) - 1)}))
