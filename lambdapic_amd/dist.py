@@ -241,14 +241,17 @@ class SlabComm:
                          device="cpu" if on_host else torch.cuda.current_device())
         return float(self.allreduce_sum(t)[0]) > 0.0
 
-    def allmin(self, value: float) -> float:
-        """minimum over the ranks (one small all-reduce on the control group; every rank must call it in the same step)"""
-        if self.size == 1:
-            return float(value)
-        on_host = dist.get_backend(self.group) == "gloo"
-        t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if on_host else torch.cuda.current_device())
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return float(t[0])
+    def allmin(self, value):
+        """minimum over the ranks of a number, or element-wise of a list of numbers (one small all-reduce on the control
+        group; every rank must call it in the same step)"""
+        vec = isinstance(value, (list, tuple))
+        vals = [float(v) for v in value] if vec else [float(value)]
+        if self.size > 1 and dist.is_initialized():       # (no process group: one process plays every slab -- tests, loopbacks)
+            on_host = dist.get_backend(self.group) == "gloo"
+            t = torch.tensor(vals, dtype=torch.float64, device="cpu" if on_host else torch.cuda.current_device())
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            vals = t.tolist()
+        return vals if vec else vals[0]
 
     def reduce_diagnostics(self, d: dict) -> dict:
         """sum a diagnostics() dict (floats, ints and lists of them) over the ranks: one all-reduce"""
@@ -313,7 +316,7 @@ class LoopbackComm(SlabComm):
         return bool(flag)
 
     def allmin(self, value):
-        return float(value)
+        return [float(v) for v in value] if isinstance(value, (list, tuple)) else float(value)
 
     def allreduce_sum(self, t):
         return t
@@ -350,3 +353,77 @@ def exchange_faces(comm: SlabComm, pack, unpack, bufs, pack2=None, unpack2=None)
         unpack(0, bufs["r_lo"])
     if got_hi:
         unpack(1, bufs["r_hi"])
+
+
+class MigrateWindowMixin:
+    """How much of a particle face message travels.  The message is fixed-size (the receiver posts its receive before it
+    can know the count, which rides in band): ``1 + LPA_MIG_NATTR * capacity`` doubles per species and face -- 2.4 MB at
+    the default capacity of 32 768, 19 MB at the 262 144 a C5 slab is given, for a few thousand leavers per step.  On a
+    wire that is the largest message of the step by far, so the engines send only a WINDOW of it: the first
+    ``migrate_window`` slots (the SoA stride of the message is the window, so the used part is a prefix of the buffer).
+    The window is retuned where the slab chain agrees on its sort clock anyway (``_tick_chain_clock``: every rank sorted in
+    this step, one small all-reduce): MARGIN x the largest count any rank saw in its four headers at its sort (the host
+    is synchronised there), a power of two, at least MIN, at most the capacity; it grows at once and shrinks by a factor of
+    two per retune at most.  A step whose leavers exceed the window is not an error below the full capacity: a leaver that
+    did not fit stays where it is (it deposits through the guard planes like any particle just outside the slab) and is
+    offered again in the next step; the surplus counter makes every rank return to the full capacity at the next retune.
+    (needs from the engine: ``migrate_capacity``, ``comm``)"""
+
+    adaptive_migrate_window = True
+    MIGRATE_WINDOW_MIN = 8192
+    MIGRATE_WINDOW_MARGIN = 4
+    _mig_window = None
+    _mig_seen = 0
+    _mig_grow = False
+    _mig_forgive = False
+
+    @property
+    def migrate_window(self) -> int:
+        w = self._mig_window
+        return self.migrate_capacity if (w is None or not self.adaptive_migrate_window) else min(int(w), self.migrate_capacity)
+
+    def _mig_views(self, m):
+        """the travelling part of a species' four message buffers"""
+        from ._lib import LPA_MIG_NATTR
+        n = 1 + LPA_MIG_NATTR * self.migrate_window
+        return m if n >= m["s_lo"].numel() else {k: v[:n] for k, v in m.items()}
+
+    def _mig_sample(self, m):
+        """at a sort (the host is synchronised): the counts of the last step's four messages"""
+        if self.adaptive_migrate_window and self.comm.size > 1 and m is not None:
+            h = torch.stack([m[k][0] for k in ("s_lo", "s_hi", "r_lo", "r_hi")]).view(torch.int64).tolist()
+            self._mig_seen = max(self._mig_seen, *[int(v) for v in h])
+
+    def _mig_surplus(self, surplus) -> bool:
+        """leavers did not fit the window: True = handled (back to the full capacity at the next retune), False = the
+        caller raises (they did not fit the full capacity).  The device counters run from sort to sort: what they hold
+        after a retune has widened the window was counted against the narrower one (``_mig_forgive``: until the retune
+        after the sorts that zero them)"""
+        if surplus > 0 and self.adaptive_migrate_window:
+            if self.migrate_window < self.migrate_capacity:
+                if not self._mig_grow:
+                    import warnings
+                    warnings.warn(f"{surplus} leaver-steps did not fit the message window of {self.migrate_window} slots: they "
+                                  f"wait outside the slab; the window returns to migrate_capacity={self.migrate_capacity} at "
+                                  "the next sort", RuntimeWarning, stacklevel=3)
+                self._mig_grow = True
+                return True
+            return self._mig_forgive
+        return False
+
+    def _mig_request(self):
+        """what this rank asks the next window to hold (None: not adaptive)"""
+        if not self.adaptive_migrate_window:
+            return None
+        seen = self.migrate_capacity if self._mig_grow else self._mig_seen
+        self._mig_seen, self._mig_grow, self._mig_forgive = 0, False, False
+        return float(seen)
+
+    def _mig_apply(self, seen):
+        """``seen``: the largest request over the ranks -- every rank computes the same window"""
+        want = max(self.MIGRATE_WINDOW_MIN, int(self.MIGRATE_WINDOW_MARGIN * seen))
+        want = min(1 << max(want - 1, 1).bit_length(), self.migrate_capacity)
+        new = max(want, min(self.migrate_window // 2, self.migrate_capacity))
+        if new > self.migrate_window:
+            self._mig_forgive = True
+        self._mig_window = new

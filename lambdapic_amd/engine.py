@@ -30,7 +30,7 @@ import torch
 from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import DeviceGrid2D, DeviceParticles, current_stream_ptr, restore_device, to_host
-from .dist import SlabComm, exchange_faces
+from .dist import MigrateWindowMixin, SlabComm, exchange_faces
 from .rho import RhoContinuityMixin
 from .step import FusedStepMixin
 
@@ -128,7 +128,7 @@ class DevicePML2D:
         return self._coef[k]
 
 
-class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
+class PicEngine2D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
     dim = 2
 
     def __init__(self, nx, ny, dx, dy, n_guard=3, device="cuda:0", comm: SlabComm | None = None,
@@ -571,6 +571,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         n_live, deepest, tail, _, _ = _lib.sort_result(self.L, ws["sort"], True)    # sync point (once per sort_interval steps)
         cnts = ws["counters"].tolist()
         arrivals, surplus = cnts[1], cnts[3]
+        self._mig_sample(ws["mig"])      # (the counts of the last step's face messages: dist.MigrateWindowMixin)
         if _again:
             pass                                                     # (the controller saw the first pass)
         elif sp.tiling is not None:
@@ -579,7 +580,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             self._first_sort_interval(sp, src, ("ux", "uy"), (self.dx, self.dy), _lib.LPA_TILE_MARGIN)
         if arrivals > ws["area"]:
             raise _lib.LpaError(f"arrival area overflow: {arrivals} > {ws['area']} (raise migrate_capacity)")
-        if surplus > 0:
+        if surplus > 0 and not self._mig_surplus(surplus):
             raise _lib.LpaError(self._surplus_message(surplus))
         sp.cur = 1 - sp.cur
         sp.n_sorted = n_live
@@ -821,7 +822,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         if self.comm.size == 1:
             return
         m, fs = self._mig_pack(ispec)
-        self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
+        v = self._mig_views(m)
+        self.comm.exchange(v["s_lo"], v["s_hi"], v["r_lo"], v["r_hi"])
         self._mig_unpack(ispec, m, fs)
 
     def _owner_bounds_x(self):
@@ -880,7 +882,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         """the slab section of an lpa_step descriptor (step.py); returns what must stay alive until the launches ran"""
         slab.xlo, slab.xhi = self._owner_bounds_x()
         slab.shift_lo, slab.shift_hi = self.comm.arrival_shift(self.Lx)
-        slab.migrate_capacity = self.migrate_capacity
+        slab.migrate_capacity = self.migrate_window       # (the message and its SoA stride: what travels of the buffers)
         h = self._halo_views(4 * self.ng * self.grid.NY)
         slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
         # (2: the jx plane of the continuity update is formed from what travels with J -- steps without B messages)
@@ -897,7 +899,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
         """leavers of species ``ispec`` into its two face messages; returns (buffers, free-slot stacks)"""
         sp = self.species[ispec]
         mig = self._slab_species(sp, pushed=True)
-        ws, cap, st = self._sort_ws(sp), self.migrate_capacity, self.stream
+        ws, cap, st = self._sort_ws(sp), self.migrate_window, self.stream
         m, cols, fs = mig["bufs"], mig["cols"], mig["fs"]
         pc = sp.cset.cstruct(sp.n)
         xlo, xhi = self._owner_bounds_x()
@@ -918,7 +920,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
 
     def _mig_unpack(self, ispec, m, fs):
         sp = self.species[ispec]
-        ws, cap, st = self._sort_ws(sp), self.migrate_capacity, self.stream
+        ws, cap, st = self._sort_ws(sp), self.migrate_window, self.stream
         pc = sp.cset.cstruct(sp.n)
         cur = ws["counters"][1:2].data_ptr()
         # arrivals through my low face come from the left neighbour; at the global low edge they
@@ -946,14 +948,15 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
                                                     h["s_hi"] if self.comm.has_right else None)
         packed = [self._mig_pack(i) for i in range(len(self.species)) if self.species[i].n]
         idx = [i for i in range(len(self.species)) if self.species[i].n]
+        views = [self._mig_views(m) for m, _ in packed]
         self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])] +
-                                [(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"]) for m, _ in packed])
+                                [(v["s_lo"], v["s_hi"], v["r_lo"], v["r_hi"]) for v in views])
         self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if self.comm.has_left else None,
                                                   h["r_hi"] if self.comm.has_right else None)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
-        self._finish_rho()
-        for i, (m, fs) in zip(idx, packed):
+        for i, (m, fs) in zip(idx, packed):     # (before the fold closes: its clock tick may retune the message window)
             self._mig_unpack(i, m, fs)
+        self._finish_rho()
 
     # ---- moving window (MovingWindow callback, callback/utils.py:471-648) ---------------------------
     def remove_x_pml(self):
@@ -1245,7 +1248,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin):
             ws = self._ws.get(id(sp))
             if ws is not None and self.comm.size > 1:
                 surplus = int(ws["counters"][3].item())
-                if surplus > 0:
+                if surplus > 0 and not self._mig_surplus(surplus):
                     raise _lib.LpaError(self._surplus_message(surplus))
 
     # ---- diagnostics ------------------------------------------------------------------------------

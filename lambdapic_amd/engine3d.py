@@ -23,7 +23,7 @@ import torch
 from . import _lib, constants
 from ._lib import LPA_MIG_NATTR, check, lib
 from .device import restore_device, to_host
-from .dist import SlabComm, exchange_faces
+from .dist import MigrateWindowMixin, SlabComm, exchange_faces
 from .engine import PicEngine2D, psi_ptr, psi_rows
 from .fields import FIELD_ATTRS, from_device_layout, to_device_layout
 from .rho import RhoContinuityMixin
@@ -117,7 +117,7 @@ class DevicePML3D:
         return self._coef[k]
 
 
-class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
+class PicEngine3D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
     dim = 3
     DEFAULT_ORDER = _lib.LPA_ORDER_STRIPED   # the in-tile order new engines sort to (LPA_ORDER_*)
 
@@ -443,6 +443,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         n_live, deepest, tail, sp["tiles_in_use"], sp["n_blocks"] = _lib.sort_result(self.L, ws["sort"], True)
         area = self.arrival_area()
         cnts = ws["counters"].tolist()
+        self._mig_sample(ws["mig"])      # (the counts of the last step's face messages: dist.MigrateWindowMixin)
         if _again:
             pass
         elif sp["tiling"] is not None:
@@ -451,7 +452,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
             self._first_sort_interval(sp)
         if cnts[1] > area:
             raise _lib.LpaError("arrival area overflow (raise migrate_capacity)")
-        if cnts[3] > 0:
+        if cnts[3] > 0 and not self._mig_surplus(cnts[3]):
             raise _lib.LpaError(self._surplus_message(cnts[3]))
         if n_live + area > cap:
             raise _lib.LpaError(f"particle capacity {cap} < live {n_live} + arrival area {area}")
@@ -596,7 +597,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         """the slab section of an lpa_step descriptor (step.py)"""
         slab.xlo, slab.xhi = self._owner_bounds_x()
         slab.shift_lo, slab.shift_hi = self.comm.arrival_shift(self.Lbox[0])
-        slab.migrate_capacity = self.migrate_capacity
+        slab.migrate_capacity = self.migrate_window       # (the message and its SoA stride: what travels of the buffers)
         h = self._halo_views(4)
         slab.cur_r_lo, slab.cur_r_hi = h["r_lo"].data_ptr(), h["r_hi"].data_ptr()
         slab.rho_exchange = int(self.rho_continuity and self._rho_available()) * (2 if self.local_b() else 1)
@@ -611,7 +612,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         """leavers of species ``i`` into its two face messages (count in band); returns the bookkeeping dict"""
         sp = self.species[i]
         mig = self._slab_species(sp, pushed=True)
-        m, cap, st, cols, fs = mig["bufs"], self.migrate_capacity, self.stream, mig["cols"], mig["fs"]
+        m, cap, st, cols, fs = mig["bufs"], self.migrate_window, self.stream, mig["cols"], mig["fs"]
         xlo, xhi = self._owner_bounds_x()
         surplus = mig["surplus"].data_ptr()     # leavers beyond migrate_capacity (checked at the next sort)
         if cols:   # only the edge tile columns + loose particles
@@ -626,7 +627,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
 
     def _mig_unpack(self, i, mig):
         sp = self.species[i]
-        m, cap, st, fs = mig["bufs"], self.migrate_capacity, self.stream, mig["fs"]
+        m, cap, st, fs = mig["bufs"], self.migrate_window, self.stream, mig["fs"]
         cur, area = mig["cursor"].data_ptr(), mig["area"]
         if not self.comm.has_left:
             m["r_lo"][:1].zero_()    # open face: nothing arrives
@@ -647,7 +648,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         if self.comm.size == 1:
             return
         mig = self._mig_pack(i)
-        m = mig["bufs"]
+        m = self._mig_views(mig["bufs"])
         self.comm.exchange(m["s_lo"], m["s_hi"], m["r_lo"], m["r_hi"])
         self._mig_unpack(i, mig)
 
@@ -661,12 +662,12 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         self._faces(_lib.LPA_HALO_PACK_CURRENT)(h["s_lo"] if left else None, h["s_hi"] if right else None)
         packed = [self._mig_pack(i) for i in range(len(self.species))]
         self.comm.exchange_many([(h["s_lo"], h["s_hi"], h["r_lo"], h["r_hi"])] +
-                                [tuple(mg["bufs"][k] for k in ("s_lo", "s_hi", "r_lo", "r_hi")) for mg in packed])
+                                [tuple(self._mig_views(mg["bufs"])[k] for k in ("s_lo", "s_hi", "r_lo", "r_hi")) for mg in packed])
         self._faces(_lib.LPA_HALO_UNPACK_CURRENT)(h["r_lo"] if left else None, h["r_hi"] if right else None)
         check(self.L.lpa_current_fold(self._g(), self.local_axes, self.stream), "lpa_current_fold")
-        self._finish_rho()
-        for i, mg in enumerate(packed):
+        for i, mg in enumerate(packed):         # (before the fold closes: its clock tick may retune the message window)
             self._mig_unpack(i, mg)
+        self._finish_rho()
 
     def _exchange_guards(self, which, h=None):
         """the slab-to-slab half of sync_guard_fields (the local wrap has run): pack, exchange, unpack"""
@@ -1107,7 +1108,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin):
         for sp in self.species:
             if sp["ws"] is not None and self.comm.size > 1:
                 surplus = int(sp["ws"]["counters"][3].item())
-                if surplus > 0:
+                if surplus > 0 and not self._mig_surplus(surplus):
                     raise _lib.LpaError(self._surplus_message(surplus))
 
     def diagnostics(self, reduce=False):

@@ -106,9 +106,19 @@ class RhoContinuityMixin:
         for (one scalar all-reduce per sort step; the host is synchronised by the sorts' read-backs anyway)."""
         if self.comm.size > 1:
             due = self._chain_clock >= self._chain_interval()
-            if due and getattr(self, "overflow_sort_fraction", 0) > 0:
-                mine = [self._species_sort_interval(sp) for sp in self.species]
-                self._chain_interval_now = self.comm.allmin(min([self.sort_interval] + [m for m in mine if m is not None]))
+            if due:
+                # the one collective of the sort clock: the interval the overflow lists ask for and -- the same all-reduce --
+                # the particle-message window the next steps send (dist.MigrateWindowMixin)
+                adapt = getattr(self, "overflow_sort_fraction", 0) > 0
+                window = self._mig_request() if hasattr(self, "_mig_request") else None
+                if adapt or window is not None:
+                    mine = [self._species_sort_interval(sp) for sp in self.species] if adapt else []
+                    got = self.comm.allmin([min([self.sort_interval] + [m for m in mine if m is not None]),
+                                            -(window or 0.0)])
+                    if adapt:
+                        self._chain_interval_now = got[0]
+                    if window is not None:
+                        self._mig_apply(-got[1])
             self._chain_clock = 1 if due else self._chain_clock + 1
 
     def _species_sort_interval(self, sp):

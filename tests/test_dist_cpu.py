@@ -16,11 +16,20 @@ NG = 3
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    # below the kernel's ephemeral range (32768-60999): an outgoing gloo connection of an earlier test cannot sit on it
+    # (a port taken from bind(0) was, once in a few hundred launches, in use again by the time the store listened)
+    import random
+    for _ in range(200):
+        p = random.randrange(20000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return p
+    raise RuntimeError("no free port")
 
 
 def _worker(rank, world, port, nx_loc, ny, q):

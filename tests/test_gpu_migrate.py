@@ -19,15 +19,15 @@ class _Mirror(SlabComm):
     def __init__(self, slab_width, cap):
         super().__init__(None, periodic=True, single=True)
         self.size, self.rank, self.left, self.right = 2, 0, 1, 1
-        self.shift, self.cap, self.numel = float(slab_width), cap, 1 + LPA_MIG_NATTR * cap
+        self.shift = float(slab_width)
 
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
         recv_lo.copy_(send_hi)
         recv_hi.copy_(send_lo)
-        if send_lo.numel() == self.numel:       # particle message: the neighbour lives one slab further
-            recv_lo[1:1 + self.cap] += self.shift
-            recv_hi[1:1 + self.cap] += self.shift
         return []
+
+    def arrival_shift(self, box_length):        # the neighbour is this slab's copy one slab further
+        return -self.shift, self.shift
 
     def exchange_many(self, sets):
         for s_ in sets:

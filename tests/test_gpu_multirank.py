@@ -20,11 +20,20 @@ NXG, NY, PPC, NSTEPS = 96, 64, 6, 24
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    # below the kernel's ephemeral range (32768-60999): an outgoing gloo connection of an earlier test cannot sit on it
+    # (a port taken from bind(0) was, once in a few hundred launches, in use again by the time the store listened)
+    import random
+    for _ in range(200):
+        p = random.randrange(20000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return p
+    raise RuntimeError("no free port")
 
 
 def _problem():

@@ -230,3 +230,50 @@ def test_bench_watchdog_prints_what_it_has_and_exits_nonzero():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] == 1.0 and line["extra"] == [{"workload": "leg c4", "value": None, "error": "timeout"}]
     assert "exceeded its time budget" in r.stderr
+
+
+def test_particle_message_window_follows_the_counts():
+    """dist.MigrateWindowMixin: the part of the fixed-size particle face message that travels -- MARGIN x the largest
+    count the ranks saw, a power of two between MIN and the capacity; grows at once, halves at most per retune; a step
+    that overflowed the window sends every rank back to the full capacity instead of raising"""
+    from lambdapic_amd.dist import MigrateWindowMixin, SlabComm
+
+    class Eng(MigrateWindowMixin):
+        migrate_capacity = 262144
+        comm = SlabComm(None, periodic=True)
+
+    e = Eng()
+    assert e.migrate_window == 262144                      # nothing known yet: the whole buffer
+    e._mig_seen = 5000
+    assert e._mig_request() == 5000.0 and e._mig_seen == 0
+    e._mig_apply(5000.0)
+    assert e.migrate_window == 131072                      # wants 32 768 (4 x 5000 -> next power of two), halves per retune
+    e._mig_apply(5000.0)
+    e._mig_apply(5000.0)
+    assert e.migrate_window == 32768
+    e._mig_apply(0.0)
+    e._mig_apply(0.0)
+    e._mig_apply(0.0)
+    assert e.migrate_window == 8192 == Eng.MIGRATE_WINDOW_MIN
+    e._mig_apply(40000.0)
+    assert e.migrate_window == 262144                      # grows at once (4 x 40 000 -> 262 144 = the capacity)
+    e._mig_apply(100.0)
+    assert e.migrate_window == 131072
+    # an overflow of the window is handled, one of the full capacity is the caller's to raise
+    assert e._mig_surplus(3) and e._mig_request() == 262144.0
+    e._mig_apply(262144.0)
+    # (the counters run from sort to sort: what they hold right after the widening was counted against the narrow window)
+    assert e.migrate_window == 262144 and e._mig_surplus(3)
+    assert e._mig_request() == 0.0 and not e._mig_surplus(3)        # one retune later an overflow is the capacity's
+    assert not e._mig_surplus(0)
+    # the travelling part of the buffers is a prefix: header + NATTR attributes x window
+    import torch
+    from lambdapic_amd._lib import LPA_MIG_NATTR
+    e._mig_apply(0.0)
+    m = {k: torch.zeros(1 + LPA_MIG_NATTR * 262144, dtype=torch.float64) for k in ("s_lo", "s_hi", "r_lo", "r_hi")}
+    v = e._mig_views(m)
+    assert all(t.numel() == 1 + LPA_MIG_NATTR * 131072 and t.data_ptr() == m[k].data_ptr() for k, t in v.items())
+    e.adaptive_migrate_window = False
+    assert e.migrate_window == 262144 and e._mig_request() is None and e._mig_views(m) is m
+    # allmin of a list: element-wise (one all-reduce carries the sort interval and the window request)
+    assert SlabComm(None, periodic=True).allmin([3, -7.5]) == [3.0, -7.5] and SlabComm(None, periodic=True).allmin(4) == 4.0

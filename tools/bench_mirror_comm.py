@@ -11,16 +11,15 @@ class MirrorComm(SlabComm):
         self.size, self.rank, self.left, self.right = 2, 0, 1, 1
         self.shift = float(slab_width)
         self.Lx = 2 * self.shift
-        self.mig_numel = 1 + LPA_MIG_NATTR * migrate_capacity
-        self.cap = migrate_capacity
 
     def exchange(self, send_lo, send_hi, recv_lo, recv_hi, wait=True):
         recv_lo.copy_(send_hi)          # the left neighbour's high face == my own high face
         recv_hi.copy_(send_lo)
-        if send_lo.numel() == self.mig_numel:      # particle message: the neighbour lives one slab further
-            recv_lo[1:1 + self.cap] += self.shift
-            recv_hi[1:1 + self.cap] += self.shift
         return []
+
+    def arrival_shift(self, box_length):
+        # the neighbour is this slab's copy one slab width further (LoopbackComm.arrival_shift)
+        return -self.shift, self.shift
 
     def exchange_many(self, sets):
         for s_ in sets:
@@ -28,7 +27,7 @@ class MirrorComm(SlabComm):
         return []
 
     def allmin(self, v):
-        return float(v)
+        return [float(x) for x in v] if isinstance(v, (list, tuple)) else float(v)
 
     def any(self, flag):
         return bool(flag)
