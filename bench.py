@@ -559,7 +559,7 @@ def leg_c2_strong(args, comm, device, steps, warm):
                        f"of {nx_loc}x1024 (fixed problem size)",
            "scaling": "strong", "value": n_tot * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
            "steps": steps, "alive_per_rank": _gather(eng.diagnostics()["nalive"][0]), "charge_rel_err": charge_err,
-           "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+           "rho": eng.rho_mode(), "overlap": bool(eng.overlap), "particle_message_window": [eng.migrate_window, eng.migrate_capacity],
            "one_call_step": eng.one_call_step(), "e_half_steps": "merged across the step boundary (engine.run_steps)",
            "roofline": _k1_roofline(eng, steps, BYTES_PER_PARTICLE * n_local + GATHER_SCATTER_BYTES_PER_CELL * nx_loc * 1024,
                                     "k_push_deposit_tiled_2d")}
@@ -635,7 +635,7 @@ def leg_c4(args, comm, device, steps, warm, make_comm):
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_2d(eng)[2]), "window_shifts": shifts[0],
             "ledger": {"initial": int(n_init), "dropped": int(dropped), "injected": int(injected), "final": int(n_end)},
             "charge_rel_err": err, "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(),
-            "overlap": bool(eng.overlap), "one_call_step": eng.one_call_step(), "roofline": roof})
+            "overlap": bool(eng.overlap), "particle_message_window": [eng.migrate_window, eng.migrate_capacity], "one_call_step": eng.one_call_step(), "roofline": roof})
 
 
 def _closing(chain, result):
@@ -685,7 +685,7 @@ def leg_c5(args, comm, device, steps, warm, make_comm):
                         f"x-slabs of {nxl}x256x256 (Simulation3D stage loop)",
             "scaling": "strong", "value": alive * steps / el, "unit": "particle-updates/s", "ms_per_step": 1e3 * el / steps,
             "steps": steps, "alive": int(alive), "alive_per_rank": _gather(_live_3d(eng)[2]), "charge_rel_err": err,
-            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap),
+            "absorbed_in_checked_step": absorbed, "rho": eng.rho_mode(), "overlap": bool(eng.overlap), "particle_message_window": [eng.migrate_window, eng.migrate_capacity],
             "one_call_step": eng.one_call_step(), "roofline": roof})
 
 
@@ -953,6 +953,9 @@ def main():
                    "particles_per_gpu": n_local, "alive_rank0": alive,
                    "decomposition": f"{comm.size} x-slabs" if comm.size > 1 else "single slab",
                    "comm": comm_note, "world": world, "rccl_version": rccl_version,
+                   "message_rounds_per_step": (2 if eng.local_b() else 4) if comm.size > 1 else 0,
+                   "particle_message_window": [eng.migrate_window, eng.migrate_capacity] if comm.size > 1 else None,
+                   "overlap": bool(eng.overlap),
                    "e_half_steps": "engine.run_steps: the second E half step of a step and the first of the next are one "
                                    "sweep (two sequential updates per cell) + one guard stage; the last step is a plain one"
                                    if run_steps else "two sweeps, two guard stages per step (engine.step)",

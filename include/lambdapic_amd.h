@@ -677,7 +677,10 @@ typedef struct {
     lpa_comm *comm;             /* NULL: the caller exchanges between sub-ranges */
     double xlo, xhi;            /* a particle with x < xlo / x > xhi leaves through the low / high face */
     double shift_lo, shift_hi;  /* added to x of what arrives through the low / high face (periodic wrap at the box ends) */
-    int64_t migrate_capacity;
+    int64_t migrate_capacity;   /* slots per particle face message = its SoA stride: 1 + LPA_MIG_NATTR * migrate_capacity doubles
+                                   travel per species and face.  May be less than the buffers hold (the engines send a
+                                   window sized from the counts they saw: dist.MigrateWindowMixin); both neighbours must use
+                                   the same value in the same step */
     double *cur_r_lo, *cur_r_hi;    /* 4 * ng * plane doubles each: the neighbours' J / rho guard planes */
     double *jx_left_plane;          /* plane doubles (continuity steps: the left neighbour's folded jx at its node nx-1) */
     int32_t rho_exchange;           /* every step, all ranks alike -- 1: the left neighbour's folded jx plane travels with the

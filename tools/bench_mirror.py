@@ -57,5 +57,5 @@ w = float(eng.species[0].cset.arr("w")[0].item())
 print(json.dumps({"what": f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", B messages" if a.b_messages else "") + (", overlapped" if a.overlap else "") +
                           (", run_steps" if a.run_steps else ""), "ms_per_step": 1e3 * el / a.steps,
                   "particle_updates_per_s_per_gpu": n * a.steps / el, "k1_edge_plus_interior_ms": k_ms,
-                  "alive": d["nalive"][0], "particles": n,
+                  "alive": d["nalive"][0], "particles": n, "message_window": eng.migrate_window,
                   "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * w * -1.602176634e-19) - 1)}))

@@ -55,5 +55,5 @@ torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = eng.diagnostics()
 print(json.dumps({"what": "3-D, " + ("single slab" if a.single else f"rank 0 of a mirrored 2-slab ring, transport {a.transport}" + (", run_steps" if a.run_steps else "") +
                                       (", B messages" if a.b_messages else "") + (", overlapped" if a.overlap else ", in line")),
-                  "ms_per_step": 1e3 * el / a.steps, "alive": d["nalive"][0], "particles": n,
+                  "ms_per_step": 1e3 * el / a.steps, "alive": d["nalive"][0], "particles": n, "message_window": eng.migrate_window,
                   "charge_rel_err": abs(d["charge"] / (d["nalive"][0] * 1.742e27 * dx * dy * dz / ppc * -constants.E_CHARGE) - 1)}))
