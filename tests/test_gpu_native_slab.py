@@ -82,14 +82,23 @@ def _problem2d():
     return dx, dy, dt, x, y, u, w
 
 
-def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True, overlap=False, local_b=True):
+def _engine2d(nx_cells, comm, copies, run_steps=False, rho=True, overlap=False, local_b=True, ypml=False):
     from lambdapic_amd.engine import PicEngine2D
     dx, dy, dt, x, y, u, w = _problem2d()
+    bc = {"xmin": "periodic", "xmax": "periodic", "ymin": "pml", "ymax": "pml"} if ypml else None
     eng = PicEngine2D(nx_cells, NY, dx, dy, device="cuda:0", comm=comm, sort_interval=5, block_particles=1024,
-                      migrate_capacity=4096)
+                      migrate_capacity=4096, boundary_conditions=bc, cpml_thickness=6)
     eng.rho_continuity = rho
     eng.overlap = overlap
     eng.local_b_guards = local_b
+    if ypml:
+        # a field blob per slab copy that reaches the y layers within the run (their psi recursions run on the slab AND,
+        # for B, on its x guard planes)
+        ii, jj = np.meshgrid(np.arange(NX) - NX / 2, np.arange(NY) - NY / 2, indexing="ij")
+        blob = np.tile(np.exp(-(ii ** 2 + jj ** 2) / 150.0), (nx_cells // NX, 1))
+        for a, amp in (("ez", 2e11), ("ey", 1e11), ("by", 500.0), ("bz", -300.0)):
+            eng.grid.view(a)[3:3 + nx_cells, 3:3 + NY] = torch.from_numpy(amp * blob).cuda()
+        eng.sync_guard_fields(("ex", "ey", "ez", "bx", "by", "bz"))
     n = x.size * copies
     eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=2 * n + 20000)
     s = eng.species[0].cset
@@ -423,3 +432,28 @@ def test_an_overflowing_window_is_not_an_error(doubled2d, monkeypatch):
         for _ in range(12):
             small.step(dt)
         small.diagnostics()
+
+
+# ---- CPML layers on the local axis of a slab ring: the y layers' B psi runs on the x guard planes too -------------------------
+@pytest.mark.parametrize("transport,local_b", [("loopback", True), ("rccl", True), ("python", True), ("loopback", False)])
+def test_mirrored_slab_with_y_layers(transport, local_b):
+    from lambdapic_amd.engine import psi_rows
+    tr2, f2, eng2 = _engine2d(2 * NX, None, 2, ypml=True)
+    comm = _comm(transport, NX * _problem2d()[0], 4096)
+    tr, f, eng = _engine2d(NX, comm, 1, local_b=local_b, ypml=True)
+    assert eng.local_b() == local_b and eng.pml is not None and len(eng.pml.layers) == 4
+    assert np.array_equal(tr[:, 3] * 2, tr2[:, 3]) and tr[-1, 3] < tr[0, 3]       # (the y layers absorb: some are gone)
+    for k in range(3):
+        assert _close(2 * tr[:, k], tr2[:, k], 1e-9), (transport, k)
+    for a in f:
+        lo, hi = _rows(eng, a, NX)
+        assert _close(f[a][lo:hi], f2[a][lo:hi], 1e-9), (transport, a)
+    # psi of the y layers: the slab's rows == the doubled box's left half; with B at home also the x guard rows of the
+    # B layers (low: all ng, high: ng - 1) == the neighbouring rows of the doubled box
+    for ly, ly2 in zip(eng.pml.layers, eng2.pml.layers):
+        for k in ("psi_a", "psi_b"):
+            a, b = psi_rows(ly, k, guards=True).cpu().numpy(), psi_rows(ly2, k, guards=True).cpu().numpy()
+            assert np.abs(b).max() > 0
+            assert _close(a[3:3 + NX], b[3:3 + NX], 1e-9), (ly["key"], k)
+            if local_b and not ly["e"]:
+                assert _close(a[3 + NX:3 + NX + 2], b[3 + NX:3 + NX + 2], 1e-9) and _close(a[0:3], b[2 * NX:2 * NX + 3], 1e-9)
