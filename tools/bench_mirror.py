@@ -26,6 +26,7 @@ ap.add_argument("--transport", default="loopback", choices=["loopback", "rccl", 
                      "one lpa_step call); rccl: the same through a one-rank RCCL communicator sending to itself (real "
                      "ncclSend / ncclRecv groups); python: the faces moved from Python between lpa_step sub-ranges")
 ap.add_argument("--run-steps", action="store_true", help="engine.run_steps: E guards once per step (deferred E2 guards)")
+ap.add_argument("--uth", type=float, default=0.0442, help="thermal momentum spread (C2: 0.0442 = 1 keV; hotter: more leavers per step)")
 ap.add_argument("--b-messages", action="store_true", help="the B guard planes travel (local_b_guards off): four message rounds per step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
