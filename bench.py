@@ -722,6 +722,8 @@ class Watchdog:
                     out = dict(self.partial)
                     out.setdefault("extra", []).append({"workload": label, "value": None, "error": "timeout"})
                     print(json.dumps(out), flush=True)
+                if self.rank != 0:
+                    time.sleep(3.0)      # (rank 0's own watchdog gets to print its line before the launcher tears the job down)
                 os._exit(3)
 
 
