@@ -737,6 +737,11 @@ typedef struct {
  * guard planes current, as lpa_halo_faces / a shift do. */
 #define LPA_STEP_B_EXT_LO 8
 #define LPA_STEP_B_EXT_HI 16
+/* LPA_STEP_E_ROUND_IN_LINE: an overlapped slab step (lpa_step_slab.overlap_cols > 0, LPA_STEP_B_EXT_*) that starts at
+ * LPA_STAGE_E1 sends its E guard planes on the communicator's second stream too, followed there by the rows of the B half
+ * step that read them, beside the rest of that sweep, the reset and the interior tiles on the caller's stream: BOTH message
+ * rounds of the step are hidden behind the interior push.  This flag keeps the E round on the caller's stream (A/B). */
+#define LPA_STEP_E_ROUND_IN_LINE 32
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

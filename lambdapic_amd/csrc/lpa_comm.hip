@@ -98,23 +98,26 @@ struct lpa_comm {
     int kind, rank, size, left, right, periodic, version;
     NcclComm nccl;
     hipStream_t side = nullptr;          // second stream of the overlapped steps (lpa_step), created on first use
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
-// the communicator's second stream (high priority: what runs there goes first) and two events, created on first use
-int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done) {
+// the communicator's second stream (high priority: what runs there goes first) and its events, created on first use
+// (ev_early, may be NULL: a third event for a fork that precedes the ev_ready one)
+int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done, void **ev_early) {
     LPA_REQUIRE(c && side && ev_ready && ev_done, "lpai_comm_side: bad args");
     if (!c->side) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (hi = the numerically lowest = highest priority)
         if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev[2], hipEventDisableTiming) != hipSuccess) {
             lpa_set_error("lpa_comm: cannot create the side stream");
             return LPA_ERR_HIP;
         }
     }
     *side = c->side; *ev_ready = c->ev[0]; *ev_done = c->ev[1];
+    if (ev_early) *ev_early = c->ev[2];
     return LPA_OK;
 }
 
@@ -169,8 +172,7 @@ extern "C" int lpa_comm_destroy(lpa_comm *c) {
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
-        (void)hipEventDestroy(c->ev[0]);
-        (void)hipEventDestroy(c->ev[1]);
+        for (int k = 0; k < 3; k++) (void)hipEventDestroy(c->ev[k]);
     }
     delete c;
     return LPA_OK;

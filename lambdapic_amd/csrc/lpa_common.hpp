@@ -39,8 +39,10 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
 // one E / B half step with the periodic guard wrap of the axes in `wrap` fused into the sweep (lpa_fields.hip)
 // (`twice`: the E sweep applies two half steps in one pass -- see FDTD_TWICE in lpa_fields.hip; `ext_lo` / `ext_hi`: the
 // B sweep of a slab split along x also advances that many x guard planes at the low / high face -- FDTD_EXT_* there)
+// (`b_part`: 0 the whole sweep; 1 / 2: the B sweep in two launches -- nodes [0, nx - 1) / node nx - 1 + the guard planes:
+// the part that reads no E guard plane and the part that does, FDTD_B_* there)
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, int ext_lo, int ext_hi, void *stream);
+              int twice, int ext_lo, int ext_hi, int b_part, void *stream);
 // the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
 // [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
 int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
@@ -53,7 +55,7 @@ int lpai_push_deposit_rest_3d(const lpa_grid *g, const lpa_particles *p, const l
 // (`also`: one more array shaped like rho to zero, or NULL)
 int lpai_reset_step(const lpa_grid *g, int with_rho, double *also, uint32_t *const *words, int nwords, void *stream);
 // the communicator's second stream and two events (overlapped steps)
-int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done);
+int lpai_comm_side(lpa_comm *c, void **side, void **ev_ready, void **ev_done, void **ev_early = nullptr);
 // lpa_push_deposit_tiled_multi_3d restricted to the edge / interior tile columns (LPA_PART_*)
 int lpai_push_deposit_tiled_multi_part_3d(const lpa_grid *g, int32_t nspecies, const lpa_particles *const *p,
                                           const lpa_push_params *const *pp, const lpa_tiling *const *t,

@@ -58,8 +58,23 @@ constexpr int FDTD_TWICE = 256;
 // arithmetic on the same E values the neighbour slab performs on its interior -- and never has to travel: two of a slab
 // step's four message rounds are gone.  (psi arrays of the y / z CPML layers carry x guard rows for this, see the engines.)
 constexpr int FDTD_EXT_LO_SHIFT = 3, FDTD_EXT_HI_SHIFT = 5;
-__device__ __forceinline__ int fdtd_ext_lo(int wrap) { return (wrap >> FDTD_EXT_LO_SHIFT) & 3; }
-static int fdtd_ext_rows(int wrap) { return ((wrap >> FDTD_EXT_LO_SHIFT) & 3) + ((wrap >> FDTD_EXT_HI_SHIFT) & 3); }
+// bits 9 / 10: the B sweep in two parts (lpa_step, overlapped slab steps) -- FDTD_B_INTERIOR: nodes [0, nx - 1), the rows
+// that read no E guard plane; FDTD_B_EDGE: node nx - 1 (it reads E at node nx) and the x guard planes of FDTD_EXT_*: what has
+// to wait for the E guard planes, launched behind their exchange on the communicator's second stream while the first part,
+// the current reset and the interior tiles of the push run on the caller's
+constexpr int FDTD_B_INTERIOR = 512, FDTD_B_EDGE = 1024;
+// x node of a B sweep's block row `b`
+__device__ __forceinline__ int fdtd_b_row(int b, int wrap, int nx) {
+    const int lo = (wrap >> FDTD_EXT_LO_SHIFT) & 3;
+    if (wrap & FDTD_B_EDGE) return b < lo ? b - lo : nx - 1 + (b - lo);
+    return b - lo;
+}
+static int fdtd_b_rows(int wrap, int nx) {      // block rows of the launch
+    const int ext = ((wrap >> FDTD_EXT_LO_SHIFT) & 3) + ((wrap >> FDTD_EXT_HI_SHIFT) & 3);
+    if (wrap & FDTD_B_EDGE) return ext + 1;
+    if (wrap & FDTD_B_INTERIOR) return nx - 1;
+    return nx + ext;
+}
 
 // =====================================================================================================
 // FDTD.  Restates update_efield_2d / update_bfield_2d (core/maxwell/cpu.py:9-35) on the conventional
@@ -83,7 +98,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double 
 
 __global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = (int)blockIdx.y - fdtd_ext_lo(wrap);
+    int i = fdtd_b_row((int)blockIdx.y, wrap, g.nx);
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xp = c + g.NY, yp = c + 1;
@@ -113,7 +128,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double 
 
 __global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y, i = (int)blockIdx.z - fdtd_ext_lo(wrap);
+    int j = blockIdx.y, i = fdtd_b_row((int)blockIdx.z, wrap, g.nx);
     if (k >= g.nz) return;
     long sy = g.NZ, sx = (long)g.NY * g.NZ;
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
@@ -140,7 +155,7 @@ extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *st
 static int fdtd_b_2d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0), "lpa_fdtd_b_2d: bad grid");
     GridV v = make_gridv(g, 2);
-    dim3 grid((g->ny + 255) / 256, g->nx + fdtd_ext_rows(wrap));
+    dim3 grid((g->ny + 255) / 256, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_2d");
     return LPA_OK;
@@ -164,7 +179,7 @@ static int fdtd_b_3d(const lpa_grid *g, double dt, int wrap, void *stream) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0), "lpa_fdtd_b_3d: bad grid");
     LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_3d: nx, ny must be <= 65535");
     GridV v = make_gridv(g, 3);
-    dim3 grid((g->nz + 255) / 256, g->ny, g->nx + fdtd_ext_rows(wrap));
+    dim3 grid((g->nz + 255) / 256, g->ny, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_3d");
     return LPA_OK;
@@ -371,7 +386,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bf
 
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay, int wrap) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = (int)blockIdx.y - fdtd_ext_lo(wrap);
+    int i = fdtd_b_row((int)blockIdx.y, wrap, g.nx);
     if (j >= g.ny) return;
     long c = (long)(i + g.ng) * g.NY + (j + g.ng);
     long xp = c + g.NY, yp = c + 1;
@@ -427,7 +442,7 @@ static int fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axi
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
                 "lpa_fdtd_b_cpml_fused_2d: bad args");
     GridV v = make_gridv(g, 2);
-    dim3 grid((g->ny + 255) / 256, g->nx + fdtd_ext_rows(wrap));
+    dim3 grid((g->ny + 255) / 256, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
                        make_axisv(ay), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_2d");
@@ -494,7 +509,7 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bf
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay,
                                                               CpmlAxisV az, int wrap) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y, i = (int)blockIdx.z - fdtd_ext_lo(wrap);
+    int j = blockIdx.y, i = fdtd_b_row((int)blockIdx.z, wrap, g.nx);
     if (k >= g.nz) return;
     long sy = g.NZ, sx = (long)g.NY * g.NZ;
     long c = (long)(i + g.ng) * sx + (long)(j + g.ng) * sy + (k + g.ng);
@@ -547,7 +562,7 @@ static int fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axi
                     g->ny <= 65535 && g->nx <= 65535,
                 "lpa_fdtd_b_cpml_fused_3d: bad args");
     GridV v = make_gridv(g, 3);
-    dim3 grid((g->nz + 255) / 256, g->ny, g->nx + fdtd_ext_rows(wrap));
+    dim3 grid((g->nz + 255) / 256, g->ny, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
                        make_axisv(ay), make_axisv(az), wrap);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_3d");
@@ -561,13 +576,17 @@ extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_
 // one half step of E or B over the slab with the guard wrap of the axes in `wrap` fused in (lpa_step); ax[]: the fused
 // CPML descriptors, all NULL = the plain Yee update
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, int ext_lo, int ext_hi, void *stream) {
+              int twice, int ext_lo, int ext_hi, int b_part, void *stream) {
     LPA_REQUIRE(g && g->nx >= g->ng && g->ny >= g->ng && (dim == 2 || g->nz >= g->ng), "lpai_fdtd: slab thinner than the guard");
     LPA_REQUIRE(!twice || efield, "lpai_fdtd: only the E sweep does two half steps at once");
     LPA_REQUIRE(ext_lo >= 0 && ext_hi >= 0 && ext_lo <= g->ng && ext_hi < g->ng && ext_lo <= 3 && ext_hi <= 3 &&
                     (!(ext_lo | ext_hi) || (!efield && !(wrap & 1))),
                 "lpai_fdtd: only the B sweep of a slab split along x advances x guard planes (ng low, ng - 1 high at most)");
-    wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0) | (ext_lo << FDTD_EXT_LO_SHIFT) | (ext_hi << FDTD_EXT_HI_SHIFT);
+    LPA_REQUIRE(b_part >= 0 && b_part <= 2 && (!b_part || (!efield && !(wrap & 1) && g->nx >= 2)),
+                "lpai_fdtd: only the B sweep of a slab split along x runs in two parts");
+    if (b_part == 1) ext_lo = ext_hi = 0;       // (the guard planes belong to the edge part)
+    wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0) | (ext_lo << FDTD_EXT_LO_SHIFT) | (ext_hi << FDTD_EXT_HI_SHIFT) |
+           (b_part == 1 ? FDTD_B_INTERIOR : (b_part == 2 ? FDTD_B_EDGE : 0));
     const bool cpml = ax && ax[0];
     if (dim == 2) {
         if (efield) return cpml ? fdtd_e_cpml_fused_2d(g, dt, eps0, ax[0], ax[1], wrap, stream) : fdtd_e_2d(g, dt, eps0, wrap, stream);

@@ -47,10 +47,20 @@ static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx,
 // (B sweeps of a slab with LPA_STEP_B_EXT_*: the x guard planes at a face with a neighbour are advanced in place)
 static bool local_b(const lpa_step_desc *d) { return (d->flags & (LPA_STEP_B_EXT_LO | LPA_STEP_B_EXT_HI)) != 0; }
 
-static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false) {
+// (`b_part`: see lpai_fdtd -- 1 / 2 = the part of a B sweep that reads no E guard plane / the part that does)
+static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false, int b_part = 0) {
     const int ng = d->grid.ng > 3 ? 3 : d->grid.ng;
     const int lo = (!efield && (d->flags & LPA_STEP_B_EXT_LO)) ? ng : 0, hi = (!efield && (d->flags & LPA_STEP_B_EXT_HI)) ? ng - 1 : 0;
-    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, lo, hi, st);
+    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, lo, hi, b_part, st);
+}
+
+static int stream_fork(void *from, void *to, void *ev) {
+    if (hipEventRecord((hipEvent_t)ev, (hipStream_t)from) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)to, (hipEvent_t)ev, 0) != hipSuccess) {
+        lpa_set_error("lpa_step: cannot order the side stream");
+        return LPA_ERR_HIP;
+    }
+    return LPA_OK;
 }
 
 static lpa_push_params species_params(const lpa_step_desc *d, const lpa_step_species *sp) {
@@ -346,6 +356,16 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
         const lpa_step_species *sp = &d->species[s_];
         overlap = sp->t && sp->mig.overflow_edge && sp->mig.overflow_edge_count && sp->overflow && sp->overflow_count;
     }
+    // Overlapped steps that start at LPA_STAGE_E1 also hide the E round: the E guard planes travel on the communicator's
+    // second stream, followed there by the part of the B half step that reads them (node nx - 1 and the guard planes), while
+    // the caller's stream runs the rest of the B sweep, the reset and the interior tiles -- none of which touches an E guard
+    // plane, B at node nx - 1 or a B guard plane (the interior tiles stage at most LPA_TILE_MARGIN + 3 nodes beyond
+    // themselves and lie overlap_cols >= 1 tile columns inside).  The streams join before the fold, as for the J round.
+    const bool e_side = overlap && first_stage <= LPA_STAGE_E1 && local_b(d) && !(d->flags & LPA_STEP_E_ROUND_IN_LINE) &&
+                        g->nx >= 2 * g->ng + 2;
+    void *side = nullptr, *ev_ready = nullptr, *ev_done = nullptr, *ev_early = nullptr;
+    if (e_side)
+        if (int e = lpai_comm_side(d->slab->comm, &side, &ev_ready, &ev_done, &ev_early)) return e;
     for (int stage = first_stage; stage <= last_stage; stage++) {
         int e = LPA_OK;
         switch (stage) {
@@ -355,10 +375,22 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             const bool defer = stage == LPA_STAGE_E2 && (d->flags & LPA_STEP_DEFER_E2_GUARDS);
             const bool twice = stage == LPA_STAGE_E1 && (d->flags & LPA_STEP_E1_DOUBLE);
             e = step_fields(d, true, defer ? 0 : d->local_axes, stream, twice);      // (the periodic guard wrap rides in the sweep)
-            if (!e && slab && !defer) e = slab_exchange_guards(d, 1, false, stream);
+            if (!e && slab && !defer) {
+                if (stage == LPA_STAGE_E1 && e_side) {
+                    e = stream_fork(stream, side, ev_early);
+                    if (!e) e = slab_exchange_guards(d, 1, false, side);
+                } else {
+                    e = slab_exchange_guards(d, 1, false, stream);
+                }
+            }
             break;
         }
         case LPA_STAGE_B1:      // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
+            if (e_side) {       // (behind the E planes on the second stream: what reads them; here: everything else)
+                e = step_fields(d, false, d->local_axes, side, false, 2);
+                if (!e) e = step_fields(d, false, d->local_axes, stream, false, 1);
+                break;
+            }
             e = step_fields(d, false, d->local_axes, stream);
             if (!e && slab && !local_b(d)) e = slab_exchange_guards(d, 2, false, stream);
             break;

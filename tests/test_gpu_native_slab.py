@@ -189,10 +189,14 @@ def test_per_stage_path_over_the_native_transport_2d(doubled2d, overlap):
         assert _close(f[a][lo:hi], f2[a][lo:hi]), a
 
 
+@pytest.mark.parametrize("e_round", [True, False])
 @pytest.mark.parametrize("transport", ["loopback", "rccl"])
-def test_overlapped_mirrored_slab_2d(doubled2d, transport):
+def test_overlapped_mirrored_slab_2d(doubled2d, transport, e_round, monkeypatch):
     """lpa_step_slab.overlap_cols: edge tile columns, leaver pack and the whole exchange on the communicator's second stream
-    beside the interior tiles (north_star: halo exchange overlapped with interior work on a second HIP stream)"""
+    beside the interior tiles (north_star: halo exchange overlapped with interior work on a second HIP stream); ``e_round``:
+    the E guard planes and the rows of the B half step that read them travel there as well (both rounds hidden)"""
+    from lambdapic_amd.engine import PicEngine2D
+    monkeypatch.setattr(PicEngine2D, "overlap_e_round", e_round)
     tr2, f2 = doubled2d
     comm = _comm(transport, NX * _problem2d()[0], 4096)
     tr, f, eng = _engine2d(NX, comm, 1, overlap=True)
@@ -285,9 +289,13 @@ def doubled3d():
 @pytest.mark.parametrize("transport,overlap,local_b", [("loopback", False, True), ("rccl", False, True), ("python", False, True),
                                                        ("loopback", True, True), ("rccl", True, True),
                                                        ("loopback", False, False), ("python", False, False),
-                                                       ("loopback", True, False)])
-def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overlap, local_b):
+                                                       ("loopback", True, False), ("loopback", True, None)])
+def test_mirrored_slab_is_half_of_the_doubled_box_3d(doubled3d, transport, overlap, local_b, monkeypatch):
     tr2, f2 = doubled3d
+    if local_b is None:         # (B at home, but the E round in line: LPA_STEP_E_ROUND_IN_LINE)
+        from lambdapic_amd.engine3d import PicEngine3D
+        monkeypatch.setattr(PicEngine3D, "overlap_e_round", False)
+        local_b = True
     lam = 0.8e-6
     comm = _comm(transport, N3[0] * lam / 20, 8192)
     tr, f, eng, d = _engine3d(N3[0], comm, 1, overlap=overlap, local_b=local_b)
@@ -435,12 +443,13 @@ def test_an_overflowing_window_is_not_an_error(doubled2d, monkeypatch):
 
 
 # ---- CPML layers on the local axis of a slab ring: the y layers' B psi runs on the x guard planes too -------------------------
-@pytest.mark.parametrize("transport,local_b", [("loopback", True), ("rccl", True), ("python", True), ("loopback", False)])
-def test_mirrored_slab_with_y_layers(transport, local_b):
+@pytest.mark.parametrize("transport,local_b,overlap", [("loopback", True, False), ("rccl", True, False), ("python", True, False),
+                                                       ("loopback", False, False), ("loopback", True, True), ("rccl", True, True)])
+def test_mirrored_slab_with_y_layers(transport, local_b, overlap):
     from lambdapic_amd.engine import psi_rows
     tr2, f2, eng2 = _engine2d(2 * NX, None, 2, ypml=True)
     comm = _comm(transport, NX * _problem2d()[0], 4096)
-    tr, f, eng = _engine2d(NX, comm, 1, local_b=local_b, ypml=True)
+    tr, f, eng = _engine2d(NX, comm, 1, local_b=local_b, ypml=True, overlap=overlap)
     assert eng.local_b() == local_b and eng.pml is not None and len(eng.pml.layers) == 4
     assert np.array_equal(tr[:, 3] * 2, tr2[:, 3]) and tr[-1, 3] < tr[0, 3]       # (the y layers absorb: some are gone)
     for k in range(3):
