@@ -797,6 +797,8 @@ def main():
                          "included, in one lpa_step call); 'torch' = torch.distributed's nccl group, faces moved from Python "
                          "between lpa_step sub-ranges; 'auto' = native when its pre-flight (a child process, bounded wait) "
                          "succeeds on every rank, else torch, else host-staged gloo")
+    ap.add_argument("--no-overlap-pass", action="store_true", help="N > 1: skip the second, overlapped pass of the headline")
+    ap.add_argument("--force-overlap-pass", action="store_true", help="rehearsals: run that pass without the native transport too")
     ap.add_argument("--stall-rank", type=int, default=-1, help="rehearsal of the watchdog: this rank stops inside the C4 leg")
     ap.add_argument("--leg-timeout", type=float, default=420.0, help="time budget of one N > 1 leg in seconds")
     ap.add_argument("--no-defer", action="store_true", help="A/B: deposit cell-crossers' tail cells inline")
@@ -910,6 +912,12 @@ def main():
     eng.reseat = args.reseat
     eng.rho_continuity = args.rho == "continuity"
     eng.lazy_inv_gamma = args.inv_gamma == "recomputed"
+    if comm.size > 1:
+        # the headline is measured with every exchange IN LINE on the step's stream first -- the path with the fewest moving
+        # parts -- and printed at once; the overlapped form (both message rounds on the communicator's second stream beside
+        # the interior tiles) is measured right after it as a second pass of exactly --steps steps and replaces the headline
+        # only if it ran and was faster.  A first contact with RCCL from two streams cannot take the headline along.
+        eng.overlap = False
     dog.arm("headline (weak-scaled C2)", 600)
     for _ in range(args.warmup):
         eng.step(dt)
@@ -985,12 +993,58 @@ def main():
         # the headline, at once: a leg that hangs below cannot take it along (the full line follows at the end)
         print(json.dumps(out), flush=True)
         dog.partial = out
+    want_overlap_pass = comm.size > 1 and not args.no_overlap_pass and (comm.native is not None or args.force_overlap_pass)
+
+    def overlapped_pass():
+        """the headline's second pass: the same K steps with both message rounds behind the interior tiles (engine.overlap).
+        Runs LAST: whatever a first contact with RCCL from two streams does, the in-line headline and the legs are out"""
+        in_line_ms = out["ms_per_step"]
+        passes = {"in_line_ms_per_step": in_line_ms, "overlapped_ms_per_step": None}
+        out["config"]["passes"] = passes
+        if comm.rank == 0:
+            dog.partial = out
+        dog.arm("headline, overlapped pass", 300)
+        try:
+            eng.overlap = True
+            eng.kernel_events = None
+            for _ in range(max(2, args.warmup // 2)):
+                eng.step(dt)
+            torch.cuda.synchronize(device)
+            comm.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            if run_steps:
+                eng.run_steps(args.steps, dt)
+            else:
+                for _ in range(args.steps):
+                    eng.step(dt)
+            torch.cuda.synchronize(device)
+            comm.barrier()
+            torch.cuda.synchronize(device)
+            el2 = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el2], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el2 = float(t.item())
+            passes["overlapped_ms_per_step"] = 1e3 * el2 / args.steps
+            if el2 < elapsed:
+                out["value"], out["ms_per_step"] = n_total * args.steps / el2, 1e3 * el2 / args.steps
+                out["config"]["overlap"] = True
+                out["roofline"]["note"] = "kernel time, achieved and frac are those of the in-line pass (one K1 launch per step)"
+        except Exception as e:   # noqa: BLE001 -- the in-line headline stands
+            passes["overlapped_error"] = repr(e)
+        dog.disarm()
+        if comm.rank == 0:
+            print(json.dumps(out), flush=True)
+            dog.partial = out
     if comm.size > 1 and not args.no_extra:
         # the configs BASELINE.json defines on several GPUs are FIXED-size problems: C2's 1024^2 box (north_star quotes
         # ">= 6x at 8 GPUs" on it), C4 (4096 x 512 LWFA with window) and C5 (512 x 256 x 256 laser-target) cut into N
         # slabs -- strong scaling, reported next to the weak-scaled headline.  Every rank runs them; each leg asserts
         # its bookkeeping (live counts against the ledger, total charge of the padded arrays) before it reports.
-        del eng
+        keep_engine = want_overlap_pass
+        if not keep_engine:
+            del eng
         torch.cuda.empty_cache()
         legs = []
         want = set(args.legs.split(","))
@@ -1012,6 +1066,8 @@ def main():
                 dog.partial = dict(out, extra=list(legs))
             torch.cuda.empty_cache()
         out["extra"] = legs
+    if want_overlap_pass:
+        overlapped_pass()
     if comm.rank == 0 and comm.size == 1 and not args.no_extra:
         # north_star: "uniform-plasma and laser-target configs": the other single-GPU configs, bounded legs
         del eng
