@@ -745,11 +745,74 @@ def preflight_native():
     ok = t[2][0].item() == comm.left and t[3][0].item() == comm.right
     dist.barrier()
     comm.close()
+    if ok:
+        try:
+            preflight_engines(lambda width: SlabComm(None, periodic=True).attach_rccl(), device)
+        except Exception as e:      # noqa: BLE001 -- whatever it is, the run falls back
+            print(f"pre-flight engines: {e!r}", file=sys.stderr, flush=True)
+            ok = False
+    dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 5)
 
 
-def native_preflight_ok(timeout=150):
+def preflight_engines(make_ring, device):
+    """the second half of the pre-flight: a few steps of a small 2-D and a small 3-D slab ring through the native transport
+    in every form the run will use -- two message rounds per step with B at home, the particle-message window, in line and
+    overlapped (both rounds on the communicator's second stream) -- with the bookkeeping checked over the ranks.  Whatever a
+    first contact with RCCL does to one of them, it does it here, in a child with a bounded wait."""
+    import types
+    from lambdapic_amd import constants
+    from lambdapic_amd.engine3d import PicEngine3D
+    import torch.distributed as dist
+    ranks = lambda c: c.size if dist.is_initialized() else 1      # (the self test plays a ring of two with one process)
+    comm = make_ring(64 * LAMBDA0 / 20)      # (slab width: what a loopback ring needs to know)
+    args = types.SimpleNamespace(nx=64, ny=64, ppc=8, sort_interval=5, block_particles=1024, uth=0.2)
+    eng, dt, n = build_engine(args, comm, device)
+    eng.MIGRATE_WINDOW_MIN = 256
+    for overlap in (False, True, False):
+        eng.overlap = overlap
+        eng.run_steps(7, dt)
+        for _ in range(3):
+            eng.step(dt)
+    d = eng.diagnostics(reduce=True)
+    if d["nalive"][0] != n * ranks(comm) or not np.isfinite(d["field_energy"]) or not eng.one_call_step():
+        raise RuntimeError(f"2-D ring: {d['nalive'][0]} of {n * ranks(comm)} particles, field energy {d['field_energy']}")
+    if not 256 <= eng.migrate_window < eng.migrate_capacity:
+        raise RuntimeError(f"2-D ring: message window {eng.migrate_window}")
+    torch.cuda.synchronize(device)
+    comm.close()
+    del eng
+    comm = make_ring(32 * LAMBDA0 / 20)
+    n3, d3 = (32, 16, 32), (LAMBDA0 / 20, LAMBDA0 / 10, LAMBDA0 / 10)
+    dt = 0.95 / (C_LIGHT * np.sqrt(sum(v ** -2 for v in d3)))
+    eng = PicEngine3D(*n3, *d3, 3, sort_interval=4, comm=comm, migrate_capacity=16384)
+    gen = torch.Generator(device=device).manual_seed(77 + comm.rank)
+    n = n3[0] * n3[1] * n3[2] * 4
+    cell = torch.arange(n, device=device) // 4
+    r = lambda: torch.rand(n, device=device, dtype=torch.float64, generator=gen)
+    data = torch.full((8, 2 * n + eng.arrival_area() + 1024), float("nan"), dtype=torch.float64, device=device)
+    data[0, :n] = eng.x0 + ((cell // (n3[1] * n3[2])).double() + r() - 0.5) * d3[0]
+    data[1, :n] = (((cell // n3[2]) % n3[1]).double() + r() - 0.5) * d3[1]
+    data[2, :n] = ((cell % n3[2]).double() + r() - 0.5) * d3[2]
+    for k in range(3):
+        data[3 + k, :n] = torch.randn(n, device=device, dtype=torch.float64, generator=gen) * 0.2
+    data[6, :n] = 1.0 / torch.sqrt(1 + (data[3:6, :n] ** 2).sum(0))
+    data[7, :n] = 1e27 * d3[0] * d3[1] * d3[2] / 4
+    eng.add_species_device(-constants.E_CHARGE, constants.M_E, data, n)
+    for overlap in (True, False):
+        eng.overlap = overlap
+        eng.run_steps(5, dt)
+        for _ in range(3):
+            eng.step(dt)
+    d = eng.diagnostics(reduce=True)
+    if d["nalive"][0] != n * ranks(comm) or not np.isfinite(d["field_energy"]) or not eng.one_call_step():
+        raise RuntimeError(f"3-D ring: {d['nalive'][0]} of {n * ranks(comm)} particles, field energy {d['field_energy']}")
+    torch.cuda.synchronize(device)
+    comm.close()
+
+
+def native_preflight_ok(timeout=200):
     """run ``preflight_native`` in a child of THIS rank, on a rendezvous of its own (MASTER_PORT + 1); True when it exited 0
     in time.  Called before this process touches the GPU."""
     import subprocess
@@ -771,6 +834,14 @@ def native_preflight_ok(timeout=150):
 def main():
     if "--preflight" in sys.argv:
         preflight_native()
+    if "--preflight-selftest" in sys.argv:
+        # the engine half of the pre-flight on ONE GPU: a ring of two identical slabs over a one-rank RCCL communicator
+        from lambdapic_amd.dist import LoopbackComm
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        preflight_engines(lambda width: LoopbackComm(width, 2, rccl=True), dev)
+        print("pre-flight engines ok")
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)

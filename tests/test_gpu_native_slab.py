@@ -466,3 +466,14 @@ def test_mirrored_slab_with_y_layers(transport, local_b, overlap):
             assert _close(a[3:3 + NX], b[3:3 + NX], 1e-9), (ly["key"], k)
             if local_b and not ly["e"]:
                 assert _close(a[3 + NX:3 + NX + 2], b[3 + NX:3 + NX + 2], 1e-9) and _close(a[0:3], b[2 * NX:2 * NX + 3], 1e-9)
+
+
+def test_bench_preflight_engines_on_one_gpu():
+    """``bench.py --gpus N`` tries the native transport in a child process first: a ring exchange, then a few steps of a small
+    2-D and a small 3-D slab ring in every form the run uses (in line, overlapped, window retunes).  The engine half of that
+    child, on a ring of two identical slabs over a one-rank RCCL communicator"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preflight-selftest"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "pre-flight engines ok" in r.stdout, r.stderr[-2000:]
