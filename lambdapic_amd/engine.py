@@ -295,7 +295,7 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`: the reference pickles the whole Simulation) ----
     _TRANSIENT = ("L", "_ws", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed", "_jx_plane",
-                  "_one", "_step_keep")
+                  "_one", "_step_keep", "_event_pool")
 
     def __getstate__(self):
         """everything but handles and scratch: the library handle, sort workspaces (and with them the tilings),

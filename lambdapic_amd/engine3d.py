@@ -267,7 +267,7 @@ class PicEngine3D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
 
     # ---- restart (RestartDump, `callback/restart.py:88-107`) ------------------------------------------------
     _TRANSIENT = ("L", "c", "buf", "species", "_halo", "_side", "_axes", "_diag", "_keep", "kernel_events", "_absorbed",
-                  "_jx_plane", "_one", "_step_keep")
+                  "_jx_plane", "_one", "_step_keep", "_event_pool")
 
     def __getstate__(self):
         """see PicEngine2D.__getstate__: fields and the slots in use of every store as host arrays, handles,

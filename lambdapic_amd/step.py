@@ -67,6 +67,26 @@ class FusedStepMixin:
         # high face by more than the guard)
         return self.n_x_local() >= getattr(self, "cpml_thickness", 0) + 2 + 2 * self.ng + 2
 
+    _event_pool = None
+
+    def reserve_kernel_events(self, pairs):
+        """create ``pairs`` timer event pairs now (a torch event gets its HIP event at its first record: two records on the
+        stream, ~10 us of stream time): a bench that times K steps reserves them before its timed region, so that a timed
+        step carries only the two records around its kernel.  Reserve what the run needs and no more: recorded timing
+        events that stay alive slow the kernels down (C2's K1: 1.64 ms with 64 pairs alive, 1.67 with 512, 1.70 with 4096)"""
+        import os
+        if os.environ.get("LPA_NO_EVENT_POOL"):       # (A/B)
+            return
+        pairs = int(os.environ.get("LPA_EVENT_POOL_N", pairs))
+        stream = torch.cuda.current_stream(self.device)
+        pool = []
+        for _ in range(int(pairs)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            b.record(stream)
+            pool.append((a, b))
+        self._event_pool = pool
+
     def can_fuse(self):
         return self.fused_step and (self.pml is None or self.fused_cpml)
 
@@ -155,6 +175,8 @@ class FusedStepMixin:
                     e.mig.overflow_edge, e.mig.overflow_edge_count = mig["overflow_edge"].data_ptr(), mig["edge_count"].data_ptr()
             if timed and tiling is not None and n_sorted > 0 and not (d.fuse_species and self.kernel_events_step):
                 def pair():
+                    if self._event_pool:       # (made ahead of the timed region: reserve_kernel_events)
+                        return self._event_pool.pop()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)           # (creates the HIP events; lpa_step records them again around the launch)
                     b.record(stream)

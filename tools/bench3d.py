@@ -63,6 +63,7 @@ else:          # the same particles dealt to several species (cell by cell), eac
 for _ in range(a.warmup):
     eng.step(dt)
 eng.kernel_events = []
+eng.reserve_kernel_events(2 * a.steps + 8)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     eng.step(dt)

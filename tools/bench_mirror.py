@@ -41,6 +41,7 @@ eng.local_b_guards = not a.b_messages
 for _ in range(a.warmup):
     eng.step(dt)
 eng.kernel_events = []
+eng.reserve_kernel_events(2 * a.steps + 8)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 if a.run_steps:
     eng.run_steps(a.steps, dt)
