@@ -742,6 +742,9 @@ typedef struct {
  * step that read them, beside the rest of that sweep, the reset and the interior tiles on the caller's stream: BOTH message
  * rounds of the step are hidden behind the interior push.  This flag keeps the E round on the caller's stream (A/B). */
 #define LPA_STEP_E_ROUND_IN_LINE 32
+/* LPA_STEP_SEPARATE_UNPACK: slab ranks fold the received J / rho planes and seat every species' arrivals in ONE launch (up to
+ * four species); this flag keeps the launches apart (A/B). */
+#define LPA_STEP_SEPARATE_UNPACK 64
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

@@ -24,6 +24,7 @@
 //                   (slot = tile_off + total[r] + popcount(mask[r] below the cell)).
 // Dead / NaN particles are dropped (compaction) -- they are the reference's recycled "dead slots".
 #include "lpa_common.hpp"
+#include "lpa_fold.hpp"
 
 constexpr int TX = LPA_TILE_X, TY = LPA_TILE_Y;
 constexpr int TCELLS = TX * TY;  // 256
@@ -1238,16 +1239,14 @@ int lpai_migrate_pack(const lpa_particles *p, const lpa_tiling *t, int32_t edge_
     return LPA_OK;
 }
 
-__global__ void __launch_bounds__(256) k_migrate_unpack2(PartV p, KeyGeom kg, int ntiles, FreeSlots fs, long first_slot,
-                                                         long area_cap, int32_t *cursor, const double *buf_lo,
-                                                         const double *buf_hi, long cap, double shift_lo,
-                                                         double shift_hi) {
-    const double *buf = blockIdx.y == 0 ? buf_lo : buf_hi;
-    const double shift_x = blockIdx.y == 0 ? shift_lo : shift_hi;
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// arrivals of one face message seated: chunk `bx` (256 of its slots) -- every thread of the block takes part
+__device__ __forceinline__ void migrate_unpack_body(const PartV &p, const KeyGeom &kg, int ntiles, const FreeSlots &fs,
+                                                    long first_slot, long area_cap, int32_t *cursor, const double *buf,
+                                                    long cap, double shift_x, long bx) {
+    long t = bx * (long)blockDim.x + threadIdx.x;
     long n = (long)*(const unsigned long long *)buf;
     if (n > cap) n = cap;
-    if ((long)blockIdx.x * blockDim.x >= n) return;      // (block-uniform: nothing of this block's range arrived)
+    if (bx * (long)blockDim.x >= n) return;      // (block-uniform: nothing of this block's range arrived)
     const bool active = t < n;
     const double *d = buf + 1;
     const double x = active ? d[0 * cap + t] + shift_x : 0.0, y = active ? d[1 * cap + t] : 0.0,
@@ -1292,6 +1291,106 @@ __global__ void __launch_bounds__(256) k_migrate_unpack2(PartV p, KeyGeom kg, in
     if (p.dead) p.dead[o] = 0;
 }
 
+__global__ void __launch_bounds__(256) k_migrate_unpack2(PartV p, KeyGeom kg, int ntiles, FreeSlots fs, long first_slot,
+                                                         long area_cap, int32_t *cursor, const double *buf_lo,
+                                                         const double *buf_hi, long cap, double shift_lo,
+                                                         double shift_hi) {
+    migrate_unpack_body(p, kg, ntiles, fs, first_slot, area_cap, cursor, blockIdx.y == 0 ? buf_lo : buf_hi, cap,
+                        blockIdx.y == 0 ? shift_lo : shift_hi, (long)blockIdx.x);
+}
+
+// The J / rho fold of a slab step AND the arrivals of every species in one launch (lpa_step; both follow the J round and
+// touch disjoint data): the first fold_blocks blocks are k_fold_all's grid (fx x fy x fz, flattened), then per species and
+// face cap / 256 blocks of k_migrate_unpack2's.
+struct UnpackOne {
+    PartV p;
+    KeyGeom kg;
+    int ntiles;
+    FreeSlots fs;
+    long first_slot, area_cap;
+    int32_t *cursor;
+    const double *buf_lo, *buf_hi;
+};
+struct UnpackSet { UnpackOne u[LPA_FOLD_UNPACK_MAX_SPECIES]; };
+
+__global__ void __launch_bounds__(256) k_fold_unpack(GridV g, int axes, const double *__restrict__ r_lo,
+                                                     const double *__restrict__ r_hi, const double *__restrict__ left_own,
+                                                     int fx, int fy, int fz, UnpackSet us, int nspecies, long cap,
+                                                     int chunks, double shift_lo, double shift_hi) {
+    long b = blockIdx.x;
+    const long fold_blocks = (long)fx * fy * fz;
+    if (b < fold_blocks) {
+        const int bx = (int)(b % fx), by = (int)((b / fx) % fy), bz = (int)(b / ((long)fx * fy));
+        fold_all_body(g, axes, r_lo, r_hi, left_own, bx, by, bz);
+        return;
+    }
+    b -= fold_blocks;
+    const int s = (int)(b / (2L * chunks));
+    if (s >= nspecies) return;
+    const long r = b - (long)s * 2 * chunks;
+    const int face = (int)(r / chunks);
+    const UnpackOne &u = us.u[s];
+    migrate_unpack_body(u.p, u.kg, u.ntiles, u.fs, u.first_slot, u.area_cap, u.cursor, face == 0 ? u.buf_lo : u.buf_hi, cap,
+                        face == 0 ? shift_lo : shift_hi, r - (long)face * chunks);
+}
+
+// geometry of the free-slot lookup of an unpack (fs == NULL: arrival area only)
+static int unpack_geom(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs, KeyGeom *kg,
+                       int *ntiles) {
+    *kg = KeyGeom{};
+    *ntiles = 0;
+    if (fs) {
+        LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && t && t->tiles_x > 0 && t->tiles_y > 0 &&
+                        free_slots_ok(fs, t), "lpai_migrate_unpack2: bad grid / tiling / free-slot stacks");
+        const int dim = t->tiles_z > 0 ? 3 : 2;
+        LPA_REQUIRE(dim == 2 || (p->z && g->nz > 1 && g->dz > 0), "lpai_migrate_unpack2: 3-D tiling needs z");
+        kg->dim = dim; kg->nx = g->nx; kg->ny = g->ny; kg->nz = dim == 3 ? g->nz : 1;
+        kg->tiles_y = t->tiles_y; kg->tiles_z = dim == 3 ? t->tiles_z : 1;
+        kg->x0 = g->x0; kg->y0 = g->y0; kg->z0 = g->z0;
+        kg->inv_dx = 1.0 / g->dx; kg->inv_dy = 1.0 / g->dy; kg->inv_dz = dim == 3 ? 1.0 / g->dz : 0.0;
+        *ntiles = t->tiles_x * t->tiles_y * (dim == 3 ? t->tiles_z : 1);
+    } else {
+        kg->dim = p->z ? 3 : 2;
+    }
+    return LPA_OK;
+}
+
+int lpai_fold_unpack(const lpa_grid *g, int axes, const double *r_lo, const double *r_hi, const double *left_own,
+                     const lpa_unpack_args *u, int nspecies, int64_t capacity, double shift_lo, double shift_hi, void *stream) {
+    LPA_REQUIRE(g && g->jx && g->jy && g->jz && g->rho && g->nx > 0 && g->ny > 0 && g->ng > 0, "lpai_fold_unpack: bad grid");
+    const int dim = g->nz > 1 ? 3 : 2;
+    LPA_REQUIRE(g->nx >= 2 * g->ng && g->ny >= 2 * g->ng && (dim == 2 || g->nz >= 2 * g->ng), "lpai_fold_unpack: slab thinner than 2*ng");
+    LPA_REQUIRE(!((r_lo || r_hi) && (axes & 1)) && (!left_own || r_lo), "lpai_fold_unpack: bad face planes");
+    LPA_REQUIRE(u && nspecies >= 1 && nspecies <= LPA_FOLD_UNPACK_MAX_SPECIES && capacity > 0, "lpai_fold_unpack: bad species");
+    GridV v;
+    memset(&v, 0, sizeof v);
+    v.nx = g->nx; v.ny = g->ny; v.nz = dim == 3 ? g->nz : 1; v.ng = g->ng;
+    v.NX = g->nx + 2 * g->ng; v.NY = g->ny + 2 * g->ng; v.NZ = dim == 3 ? g->nz + 2 * g->ng : 1;
+    v.jx = g->jx; v.jy = g->jy; v.jz = g->jz; v.rho = g->rho;
+    const int fx = dim == 3 ? (v.NZ + 255) / 256 : (v.NY + 255) / 256, fy = dim == 3 ? v.NY : v.NX, fz = dim == 3 ? v.NX : 1;
+    UnpackSet us;
+    memset(&us, 0, sizeof us);
+    for (int s = 0; s < nspecies; s++) {
+        const lpa_unpack_args &a = u[s];
+        const lpa_particles *p = a.p;
+        LPA_REQUIRE(p && p->x && p->y && p->ux && p->uy && p->uz && p->inv_gamma && p->w && a.buf_lo && a.buf_hi && a.cursor &&
+                        a.first_slot >= 0 && a.area_capacity >= 0, "lpai_fold_unpack: bad species arguments");
+        UnpackOne &o = us.u[s];
+        if (int e = unpack_geom(p, g, a.t, a.fs, &o.kg, &o.ntiles)) return e;
+        o.p = make_partv(p);
+        o.fs = make_free_slots(a.fs, a.t);
+        o.first_slot = (long)a.first_slot; o.area_cap = (long)a.area_capacity; o.cursor = a.cursor;
+        o.buf_lo = a.buf_lo; o.buf_hi = a.buf_hi;
+    }
+    const int chunks = (int)((capacity + 255) / 256);
+    const long blocks = (long)fx * fy * fz + 2L * chunks * nspecies;
+    LPA_REQUIRE(blocks < (1L << 31), "lpai_fold_unpack: grid too large");
+    hipLaunchKernelGGL(k_fold_unpack, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, v, axes, r_lo, r_hi, left_own,
+                       fx, fy, fz, us, nspecies, (long)capacity, chunks, shift_lo, shift_hi);
+    LPA_CHECK_LAUNCH("lpai_fold_unpack");
+    return LPA_OK;
+}
+
 int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_tiling *t, const lpa_free_slots *fs,
                          int64_t first_slot, int64_t area_capacity, int32_t *cursor, const double *buf_lo,
                          const double *buf_hi, int64_t capacity, double shift_lo, double shift_hi, void *stream) {
@@ -1301,19 +1400,7 @@ int lpai_migrate_unpack2(const lpa_particles *p, const lpa_grid *g, const lpa_ti
     if (area_capacity == 0 && !fs) return LPA_OK;
     KeyGeom kg{};
     int ntiles = 0;
-    if (fs) {
-        LPA_REQUIRE(g && g->nx > 0 && g->ny > 0 && g->dx > 0 && g->dy > 0 && t && t->tiles_x > 0 && t->tiles_y > 0 &&
-                        free_slots_ok(fs, t), "lpai_migrate_unpack2: bad grid / tiling / free-slot stacks");
-        const int dim = t->tiles_z > 0 ? 3 : 2;
-        LPA_REQUIRE(dim == 2 || (p->z && g->nz > 1 && g->dz > 0), "lpai_migrate_unpack2: 3-D tiling needs z");
-        kg.dim = dim; kg.nx = g->nx; kg.ny = g->ny; kg.nz = dim == 3 ? g->nz : 1;
-        kg.tiles_y = t->tiles_y; kg.tiles_z = dim == 3 ? t->tiles_z : 1;
-        kg.x0 = g->x0; kg.y0 = g->y0; kg.z0 = g->z0;
-        kg.inv_dx = 1.0 / g->dx; kg.inv_dy = 1.0 / g->dy; kg.inv_dz = dim == 3 ? 1.0 / g->dz : 0.0;
-        ntiles = t->tiles_x * t->tiles_y * (dim == 3 ? t->tiles_z : 1);
-    } else {
-        kg.dim = p->z ? 3 : 2;
-    }
+    if (int e = unpack_geom(p, g, t, fs, &kg, &ntiles)) return e;
     hipLaunchKernelGGL(k_migrate_unpack2, dim3((unsigned)((capacity + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream,
                        make_partv(p), kg, ntiles, make_free_slots(fs, t), (long)first_slot, (long)area_capacity, cursor,
                        buf_lo, buf_hi, (long)capacity, shift_lo, shift_hi);

@@ -15,6 +15,7 @@
 // LPA_STEP_B_EXT_*: the B sweeps advance the x guard planes themselves (exact: they read only E, whose guard planes are
 // current) and the jx plane of the continuity update is formed from what travels with J.
 #include "lpa_common.hpp"
+#include "lpa_fold.hpp"
 
 static long plane_of(const lpa_grid *g) { return (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1); }
 
@@ -283,8 +284,24 @@ static int slab_fold_unpack(const lpa_step_desc *d, void *st) {
     int32_t info[6];
     if (int e = lpa_comm_info(sl->comm, info)) return e;
     const bool has_left = info[3] >= 0, has_right = info[4] >= 0;
-    if (int e = lpai_fold_all(g, d->local_axes, has_left ? sl->cur_r_lo : nullptr, has_right ? sl->cur_r_hi : nullptr,
-                              has_left && sl->rho_exchange == 2 ? sl->jx_left_plane : nullptr, st)) return e;
+    const double *r_lo = has_left ? sl->cur_r_lo : nullptr, *r_hi = has_right ? sl->cur_r_hi : nullptr;
+    const double *left_own = has_left && sl->rho_exchange == 2 ? sl->jx_left_plane : nullptr;
+    if (d->nspecies >= 1 && d->nspecies <= LPA_FOLD_UNPACK_MAX_SPECIES && !(d->flags & LPA_STEP_SEPARATE_UNPACK)) {
+        // the fold and every species' arrivals in one launch (they touch disjoint data)
+        lpa_unpack_args u[LPA_FOLD_UNPACK_MAX_SPECIES];
+        bool fused = true;
+        for (int s = 0; s < d->nspecies; s++) {
+            const lpa_step_species *sp = &d->species[s];
+            const lpa_step_migrate *mg = &sp->mig;
+            const lpa_free_slots *fs = (mg->edge_cols > 0 || sp->pp.leavers) ? mg->fs : nullptr;
+            if (mg->area_capacity == 0 && !fs) fused = false;      // (nothing to seat: lpai_migrate_unpack2 returns at once)
+            u[s] = lpa_unpack_args{&sp->p, sp->t, fs, sp->n_sorted, mg->area_capacity, mg->cursor, mg->r_lo, mg->r_hi};
+        }
+        if (fused)
+            return lpai_fold_unpack(g, d->local_axes, r_lo, r_hi, left_own, u, d->nspecies, sl->migrate_capacity, sl->shift_lo,
+                                    sl->shift_hi, st);
+    }
+    if (int e = lpai_fold_all(g, d->local_axes, r_lo, r_hi, left_own, st)) return e;
     for (int s = 0; s < d->nspecies; s++) {
         const lpa_step_species *sp = &d->species[s];
         const lpa_step_migrate *mg = &sp->mig;

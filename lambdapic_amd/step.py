@@ -59,6 +59,7 @@ class FusedStepMixin:
     # overlapped native slab steps: the E guard planes (and the rows of the B half step that read them) travel on the second
     # stream as well -- both message rounds of a step behind the interior push (LPA_STEP_E_ROUND_IN_LINE turns it off)
     overlap_e_round = True
+    fused_fold_unpack = True   # native slab steps: the J / rho fold and every species' arrivals in one launch
 
     def local_b(self):
         if not (self.local_b_guards and self.comm.size > 1 and self.can_fuse()):
@@ -129,6 +130,8 @@ class FusedStepMixin:
             d.flags |= (_lib.LPA_STEP_B_EXT_LO if self.comm.has_left else 0) | (_lib.LPA_STEP_B_EXT_HI if self.comm.has_right else 0)
         if not self.overlap_e_round:
             d.flags |= _lib.LPA_STEP_E_ROUND_IN_LINE
+        if not self.fused_fold_unpack:
+            d.flags |= _lib.LPA_STEP_SEPARATE_UNPACK
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):
