@@ -745,6 +745,10 @@ typedef struct {
 /* LPA_STEP_SEPARATE_UNPACK: slab ranks fold the received J / rho planes and seat every species' arrivals in ONE launch (up to
  * four species); this flag keeps the launches apart (A/B). */
 #define LPA_STEP_SEPARATE_UNPACK 64
+/* LPA_STEP_SEPARATE_PACK: on slab ranks with leaver lists the launch that pushes what the tiled kernel left to global memory
+ * (overflow list + arrival area) also packs the step's leavers -- the tiled kernel's list and, on the spot, those of the
+ * particles it pushes itself; this flag keeps the pack a launch of its own (A/B). */
+#define LPA_STEP_SEPARATE_PACK 128
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

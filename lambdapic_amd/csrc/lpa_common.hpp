@@ -45,12 +45,14 @@ int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, co
               int twice, int ext_lo, int ext_hi, int b_part, void *stream);
 // the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
 // [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
+// (`pack`, may be NULL: the step's leaver pack rides in the launch -- lpa_migrate.hpp)
+struct lpa_pack_args;
 int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
                               const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
-                              const int32_t *loose_limit, void *stream);
+                              const int32_t *loose_limit, const lpa_pack_args *pack, void *stream);
 int lpai_push_deposit_rest_3d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
                               const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
-                              const int32_t *loose_limit, void *stream);
+                              const int32_t *loose_limit, const lpa_pack_args *pack, void *stream);
 // jx jy jz (and rho) including guards = 0 and up to 32 device words = 0, one launch (lpa_step: reset + per-step counters)
 // (`also`: one more array shaped like rho to zero, or NULL)
 int lpai_reset_step(const lpa_grid *g, int with_rho, double *also, uint32_t *const *words, int nwords, void *stream);

@@ -16,6 +16,7 @@
 //
 // Restates unified_boris_pusher_cpu_2d (core/pusher/unified/unified_pusher_2d.c:157-365).
 #include "lpa_common.hpp"
+#include "lpa_migrate.hpp"
 #ifndef LPA_NT_PARTICLES_2D
 #define LPA_NT_PARTICLES_2D 0
 #endif
@@ -163,9 +164,10 @@ __device__ __forceinline__ void deposit_global_2d(const GridV &g, double x, doub
 }
 
 // the whole per-particle update on global memory
-__device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p, const PushK &k, long ip) {
+// (returns the particle's new x; NaN: a dead slot)
+__device__ __forceinline__ double update_global_2d(const GridV &g, const PartV &p, const PushK &k, long ip) {
     double x = p.x[ip], y = p.y[ip];
-    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return;
+    if ((p.dead && p.dead[ip]) || isnan(x) || isnan(y)) return __longlong_as_double(0x7ff8000000000000ll);
     double ux = p.ux[ip], uy = p.uy[ip], uz = p.uz[ip], w = p.w[ip];
     const bool noig = k.flags & LPA_PUSH_NO_IG;      // the store's inv_gamma is neither read nor written
     double ig = noig ? inv_gamma_of(ux, uy, uz) : p.ig[ip];
@@ -189,6 +191,7 @@ __device__ __forceinline__ void update_global_2d(const GridV &g, const PartV &p,
     p.x[ip] = x; p.y[ip] = y;
     p.ux[ip] = ux; p.uy[ip] = uy; p.uz[ip] = uz;
     if (!noig) p.ig[ip] = ig;
+    return x;
 }
 
 __global__ void __launch_bounds__(256) k_push_deposit_global_2d(GridV g, PartV p, PushK k, long first,
@@ -221,6 +224,18 @@ __global__ void __launch_bounds__(256) k_push_deposit_rest_2d(GridV g, PartV p, 
     long m = loose_count;
     if (loose_limit && (long)*loose_limit < m) m = *loose_limit;
     for (long t = t0; t < m; t += stride) update_global_2d(g, p, k, loose_first + t);
+}
+
+// the same launch with the step's leaver pack in it (lpa_migrate.hpp: rest_pack_body)
+__global__ void __launch_bounds__(256) k_push_deposit_rest_pack_2d(GridV g, PartV p, PushK k,
+                                                                   const uint32_t *__restrict__ list,
+                                                                   const uint32_t *__restrict__ list_count, long loose_first,
+                                                                   long loose_count, const int32_t *__restrict__ loose_limit,
+                                                                   PackArgsV pk) {
+    PushK kk = k;
+    kk.leavers = nullptr;       // (what these particles do is seen right here: no list entry)
+    rest_pack_body(p, list, list_count, loose_first, loose_count, loose_limit, pk,
+                   [&](long ip) { return update_global_2d(g, p, kk, ip); });
 }
 
 // =====================================================================================================
@@ -974,14 +989,23 @@ extern "C" int lpa_push_deposit_list_2d(const lpa_grid *g, const lpa_particles *
 
 int lpai_push_deposit_rest_2d(const lpa_grid *g, const lpa_particles *p, const lpa_push_params *pp, const uint32_t *list,
                               const uint32_t *list_count, int64_t max_count, int64_t loose_first, int64_t loose_count,
-                              const int32_t *loose_limit, void *stream) {
+                              const int32_t *loose_limit, const lpa_pack_args *pack, void *stream) {
     if (int e = check_push(g, p, pp, "lpai_push_deposit_rest_2d")) return e;
     LPA_REQUIRE((!list || list_count) && max_count >= 0 && loose_first >= 0 && loose_count >= 0 &&
                     loose_first + loose_count <= p->n, "lpai_push_deposit_rest_2d: bad list / range");
+    LPA_REQUIRE(!pack || pack_args_ok(pack, p), "lpai_push_deposit_rest_2d: bad pack arguments");
     const long work = (list ? max_count : 0) > loose_count ? (long)max_count : (long)loose_count;
-    if (work == 0 || p->n == 0) return LPA_OK;
+    if ((work == 0 && !(pack && pack->with_list)) || p->n == 0) return LPA_OK;
     long nb = (work + 255) / 256;
     if (nb > 2048) nb = 2048;
+    if (pack) {     // the step's leaver pack rides in this launch
+        const PackArgsV pk = make_pack_args_v(pack);
+        hipLaunchKernelGGL(k_push_deposit_rest_pack_2d, dim3((unsigned)(nb + pk.pack_blocks)), dim3(256), 0, (hipStream_t)stream,
+                           make_gridv(g, 2), make_partv(p), make_pushk(pp, g), list, list_count, (long)loose_first,
+                           (long)loose_count, loose_limit, pk);
+        LPA_CHECK_LAUNCH("lpai_push_deposit_rest_2d (with the leaver pack)");
+        return LPA_OK;
+    }
     hipLaunchKernelGGL(k_push_deposit_rest_2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, make_gridv(g, 2),
                        make_partv(p), make_pushk(pp, g), list, list_count, (long)loose_first, (long)loose_count, loose_limit);
     LPA_CHECK_LAUNCH("lpai_push_deposit_rest_2d");

@@ -829,93 +829,8 @@ extern "C" int lpa_sort_tiles_ahead_3d(const lpa_grid *g, const lpa_particles *s
 // its own count.  Buffer layout (doubles): [0] = count (int64 bit pattern), then
 // [LPA_MIG_NATTR][capacity] SoA, attribute order x y z ux uy uz inv_gamma w id.
 // =====================================================================================================
-// Free-slot stacks: a particle that leaves a tile-ordered store through an x face frees a slot of an edge
-// tile, and about as many particles ARRIVE in that tile through the same face.  The pack kernel records the
-// freed slots per edge tile, the unpack kernel hands them to the arrivals of that tile: those sit inside their
-// tile's range again and take the LDS-tiled push, instead of waiting in the arrival area -- pushed one by one
-// through global memory -- for the next sort (0.34 ms per step on the 3-D slab).
-struct FreeSlots {
-    int32_t *count;   // [2 * edge_tiles]
-    int32_t *slot;    // [2 * edge_tiles][depth]
-    int edge_tiles;   // tiles in the edge columns of ONE face
-    int depth;
-};
+#include "lpa_migrate.hpp"   // FreeSlots, migrate_pack_one (shared with the push kernels' rest launch)
 
-// edge index of a tile: low-face columns first, then the high-face columns; -1 for interior tiles
-__device__ __forceinline__ int edge_index(int tile, int ntiles, int edge_tiles) {
-    if (tile < edge_tiles) return tile;
-    if (tile >= ntiles - edge_tiles) return tile - (ntiles - 2 * edge_tiles);
-    return -1;
-}
-
-__device__ __forceinline__ void migrate_pack_one(const PartV &p, long ip, double xlo, double xhi,
-                                                 double *buf_lo, double *buf_hi, long cap,
-                                                 const FreeSlots &fs = FreeSlots{nullptr, nullptr, 0, 0},
-                                                 const int32_t *tile_off = nullptr, int ntiles = 0,
-                                                 long n_sorted = 0, bool active = true,
-                                                 int32_t *surplus = nullptr, bool have_x = false, double x_in = 0.0,
-                                                 int known_tile = -1) {
-    // called by every lane of the wave (`active` = this lane has a particle): the message slots are taken
-    // with ONE atomic per wave and face -- tens of thousands of leavers bumping a single counter one by one
-    // took 0.14 ms of the 3-D scan
-    double x = have_x ? x_in : (active ? p.x[ip] : 0.0);      // (have_x: the caller loaded a batch of positions up front)
-    const bool live = active && !((p.dead && p.dead[ip]) || isnan(x));
-    const int side = !live ? -1 : (x < xlo ? 0 : (x > xhi ? 1 : -1));
-    const int lane = (int)(threadIdx.x & 63u);
-    long slot = -1;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const unsigned long long m = __ballot(side == s);
-        if (!m) continue;   // wave-uniform
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) {
-            const unsigned long long k = (unsigned long long)__popcll(m);
-            base = atomicAdd((unsigned long long *)(s == 0 ? buf_lo : buf_hi), k);
-            // leavers that do not fit into the message: counted for the host (checked at the next sort)
-            if (surplus && base + k > (unsigned long long)cap)
-                atomicAdd(surplus, (int32_t)(base >= (unsigned long long)cap ? k : base + k - (unsigned long long)cap));
-        }
-        base = __shfl(base, leader);
-        if (side == s) slot = (long)base + __popcll(m & ((1ull << lane) - 1ull));
-    }
-    if (side < 0) return;
-    double *b = side == 0 ? buf_lo : buf_hi;
-    if (slot < cap) {
-        double *d = b + 1;
-        d[0 * cap + slot] = x;
-        d[1 * cap + slot] = p.y[ip];
-        d[2 * cap + slot] = p.z ? p.z[ip] : 0.0;
-        d[3 * cap + slot] = p.ux[ip];
-        d[4 * cap + slot] = p.uy[ip];
-        d[5 * cap + slot] = p.uz[ip];
-        d[6 * cap + slot] = p.ig[ip];
-        d[7 * cap + slot] = p.w[ip];
-        d[8 * cap + slot] = p.id ? __longlong_as_double((long long)p.id[ip]) : 0.0;
-        // the particle now belongs to the neighbour (sync_particles_2d.c:185-202)
-        p.x[ip] = __longlong_as_double(0x7ff8000000000000ll);
-        p.y[ip] = __longlong_as_double(0x7ff8000000000000ll);
-        if (p.dead) p.dead[ip] = 1;
-        if (fs.count && ip < n_sorted) {   // the freed slot belongs to the tile whose range holds it
-            int lo = 0, hi = ntiles;       // last tile with tile_off[tile] <= ip
-            if (known_tile >= 0) lo = known_tile, hi = known_tile + 1;      // (the tiled push kernels say which)
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if ((long)tile_off[mid] <= ip) lo = mid; else hi = mid;
-            }
-            int e = edge_index(lo, ntiles, fs.edge_tiles);
-            if (e >= 0) {
-                int k = atomicAdd(&fs.count[e], 1);
-                if (k < fs.depth) fs.slot[(long)e * fs.depth + k] = (int32_t)ip;
-                else atomicSub(&fs.count[e], 1);
-            }
-        }
-    }
-    // slot >= cap: the particle is NOT lost -- it stays where it is (outside the slab, handled by the
-    // torus path) and leaves at the next step; the event is counted in *surplus, which the engines read
-    // at their next sort and turn into an error (the torus path deposits such a particle on the wrong side
-    // of the slab).
-}
 
 __global__ void __launch_bounds__(256) k_migrate_pack_x(PartV p, double xlo, double xhi, double *buf_lo,
                                                         double *buf_hi, long cap, int32_t *surplus) {
@@ -1064,20 +979,6 @@ __global__ void __launch_bounds__(256) k_migrate_unpack_tiled(PartV p, KeyGeom k
     p.w[o] = d[7 * cap + t];
     if (p.id) p.id[o] = (unsigned long long)__double_as_longlong(d[8 * cap + t]);
     if (p.dead) p.dead[o] = 0;
-}
-
-static int free_slots_ok(const lpa_free_slots *fs, const lpa_tiling *t) {
-    return fs && fs->count && fs->slot && fs->depth > 0 && fs->edge_cols >= 1 && t &&
-           2 * fs->edge_cols <= t->tiles_x;
-}
-
-static FreeSlots make_free_slots(const lpa_free_slots *fs, const lpa_tiling *t) {
-    FreeSlots f{nullptr, nullptr, 0, 0};
-    if (fs) {
-        f.count = fs->count; f.slot = fs->slot; f.depth = fs->depth;
-        f.edge_tiles = fs->edge_cols * t->tiles_y * (t->tiles_z > 0 ? t->tiles_z : 1);
-    }
-    return f;
 }
 
 extern "C" int lpa_migrate_pack_x(const lpa_particles *p, double xlo, double xhi, double *buf_lo,

@@ -16,6 +16,7 @@
 // current) and the jx plane of the continuity update is formed from what travels with J.
 #include "lpa_common.hpp"
 #include "lpa_fold.hpp"
+#include "lpa_migrate.hpp"
 
 static long plane_of(const lpa_grid *g) { return (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1); }
 
@@ -118,7 +119,22 @@ static int record(void *ev, void *st) {
 // 3-D, fuse_species: the tile-ordered part of every species in one launch (one E / B staging per tile).
 enum { LOOSE_WITH_PART = 0, LOOSE_SKIP = 1, LOOSE_ONLY = 2 };
 
-static int push_part(const lpa_step_desc *d, int part, int cols, void *st, int loose_mode = LOOSE_WITH_PART) {
+// which species' leavers were packed by their rest launch already (lpa_migrate.hpp; one lpa_step call)
+struct StepCtx { bool packed[64] = {false}; };
+
+// the pack arguments of a species' rest launch on a slab rank with leaver lists; `with_list`: this launch also walks the list
+// the tiled kernel wrote (false: it only packs what it pushes itself)
+static bool pack_args_of(const lpa_step_desc *d, const lpa_step_species *sp, bool with_list, lpa_pack_args *a) {
+    const lpa_step_slab *sl = d->slab;
+    if (!(sl && sl->comm) || !sp->pp.leavers || !sp->t || (d->flags & LPA_STEP_SEPARATE_PACK)) return false;
+    const lpa_step_migrate *mg = &sp->mig;
+    if (!(mg->s_lo && mg->s_hi) || sl->migrate_capacity <= 0 || !(sl->xlo < sl->xhi)) return false;
+    *a = lpa_pack_args{sp->pp.leavers, sp->pp.leaver_count, sp->pp.leaver_capacity, sp->t, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi,
+                       sl->migrate_capacity, mg->fs, mg->surplus, with_list ? 1 : 0};
+    return true;
+}
+
+static int push_part(const lpa_step_desc *d, StepCtx *ctx, int part, int cols, void *st, int loose_mode = LOOSE_WITH_PART) {
     const lpa_grid *g = &d->grid;
     const bool edge = part == LPA_PART_EDGE, loose = part != LPA_PART_INTERIOR && loose_mode != LOOSE_SKIP;
     if (loose_mode == LOOSE_ONLY) {     // the arrival areas alone (they depend on nothing the tiled kernels produce)
@@ -126,10 +142,12 @@ static int push_part(const lpa_step_desc *d, int part, int cols, void *st, int l
             const lpa_step_species *sp = &d->species[s];
             if (sp->p.n == 0 || !sp->t || !sp->mig.cursor || sp->p.n <= sp->n_sorted) continue;
             lpa_push_params pp = species_params(d, sp);
+            lpa_pack_args pa;       // (their own leavers are packed on the spot; the tiled kernel's list is another launch's)
+            const lpa_pack_args *pk = pack_args_of(d, sp, false, &pa) ? &pa : nullptr;
             const int e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, &pp, nullptr, nullptr, 0, sp->n_sorted, sp->p.n - sp->n_sorted,
-                                                                  (const int32_t *)sp->mig.cursor, st)
+                                                                  (const int32_t *)sp->mig.cursor, pk, st)
                                       : lpai_push_deposit_rest_3d(g, &sp->p, &pp, nullptr, nullptr, 0, sp->n_sorted, sp->p.n - sp->n_sorted,
-                                                                  (const int32_t *)sp->mig.cursor, st);
+                                                                  (const int32_t *)sp->mig.cursor, pk, st);
             if (e) return e;
         }
         return LPA_OK;
@@ -140,11 +158,18 @@ static int push_part(const lpa_step_desc *d, int part, int cols, void *st, int l
     auto rest = [&](const lpa_step_species *sp, const lpa_push_params *pp, bool with_list) -> int {
         const uint32_t *list = with_list ? ovf_of(sp) : nullptr;
         const int64_t nloose = loose ? sp->p.n - sp->n_sorted : 0;
-        if (!list && nloose <= 0) return LPA_OK;
-        return d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
-                                                       (const int32_t *)sp->mig.cursor, st)
-                           : lpai_push_deposit_rest_3d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
-                                                       (const int32_t *)sp->mig.cursor, st);
+        // slab ranks: the launch also packs the step's leavers -- those it pushes itself and (the ALL / EDGE part, whose
+        // tiled kernel is the one that can list any) the tiled kernel's list
+        lpa_pack_args pa;
+        const bool lists = part != LPA_PART_INTERIOR;
+        const lpa_pack_args *pk = pack_args_of(d, sp, lists, &pa) ? &pa : nullptr;
+        if (!list && nloose <= 0 && !(pk && lists)) return LPA_OK;
+        const int e = d->dim == 2 ? lpai_push_deposit_rest_2d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
+                                                              (const int32_t *)sp->mig.cursor, pk, st)
+                                  : lpai_push_deposit_rest_3d(g, &sp->p, pp, list, cnt_of(sp), sp->n_sorted, sp->n_sorted, nloose,
+                                                              (const int32_t *)sp->mig.cursor, pk, st);
+        if (!e && pk && lists) ctx->packed[sp - d->species] = true;
+        return e;
     };
     if (d->dim == 3 && d->fuse_species) {
         constexpr int MAXS = 4;
@@ -199,7 +224,7 @@ static int push_part(const lpa_step_desc *d, int part, int cols, void *st, int l
     return LPA_OK;
 }
 
-static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
+static int step_push(const lpa_step_desc *d, StepCtx *ctx, bool counters_zeroed, void *st) {
     LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
     if (!counters_zeroed)
         if (int e = step_zero_counters(d, st)) return e;
@@ -212,7 +237,7 @@ static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
         const lpa_step_species *sp = &d->species[s];
         loose_any = loose_any || (sp->p.n > sp->n_sorted && sp->t && sp->mig.cursor && sp->n_sorted > 0);
     }
-    if (!loose_any) return push_part(d, LPA_PART_ALL, 0, st);
+    if (!loose_any) return push_part(d, ctx, LPA_PART_ALL, 0, st);
     void *side, *ev_ready, *ev_done;
     if (int e = lpai_comm_side(d->slab->comm, &side, &ev_ready, &ev_done)) return e;
     if (hipEventRecord((hipEvent_t)ev_ready, (hipStream_t)st) != hipSuccess ||
@@ -220,12 +245,12 @@ static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
         lpa_set_error("lpa_step: cannot fork the side stream");
         return LPA_ERR_HIP;
     }
-    if (int e = push_part(d, LPA_PART_ALL, 0, side, LOOSE_ONLY)) return e;
+    if (int e = push_part(d, ctx, LPA_PART_ALL, 0, side, LOOSE_ONLY)) return e;
     if (hipEventRecord((hipEvent_t)ev_done, (hipStream_t)side) != hipSuccess) {
         lpa_set_error("lpa_step: hipEventRecord failed");
         return LPA_ERR_HIP;
     }
-    if (int e = push_part(d, LPA_PART_ALL, 0, st, LOOSE_SKIP)) return e;
+    if (int e = push_part(d, ctx, LPA_PART_ALL, 0, st, LOOSE_SKIP)) return e;
     if (hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev_done, 0) != hipSuccess) {
         lpa_set_error("lpa_step: cannot join the side stream");
         return LPA_ERR_HIP;
@@ -235,7 +260,7 @@ static int step_push(const lpa_step_desc *d, bool counters_zeroed, void *st) {
 
 // slab ranks, first half of the fold: leavers of every species into their face messages, then ONE exchange for the J / rho
 // guard planes and all particle messages (sync_currents + sync_particles back to back, simulation.py:1043-1080)
-static int slab_pack_exchange(const lpa_step_desc *d, bool headers_zeroed, void *st) {
+static int slab_pack_exchange(const lpa_step_desc *d, const StepCtx *ctx, bool headers_zeroed, void *st) {
     const lpa_step_slab *sl = d->slab;
     if (!headers_zeroed)      // (LPA_STAGE_PUSH / RESET of this call did it otherwise)
         if (int e = step_zero_counters(d, st, false)) return e;
@@ -265,7 +290,9 @@ static int slab_pack_exchange(const lpa_step_desc *d, bool headers_zeroed, void 
         const lpa_step_migrate *mg = &sp->mig;
         LPA_REQUIRE(mg->s_lo && mg->s_hi && mg->r_lo && mg->r_hi && mg->cursor, "lpa_step: species without migration buffers");
         LPA_REQUIRE(sp->t && sp->n_sorted >= 0, "lpa_step: a slab rank needs tile-ordered stores (arrival area)");
-        if (sp->pp.leavers) {       // this step's pushes listed the leavers: no scan
+        if (ctx->packed[s]) {
+            // (the species' rest launch packed its leavers: lpa_migrate.hpp)
+        } else if (sp->pp.leavers) {       // this step's pushes listed the leavers: no scan
             if (int e = lpai_migrate_pack_list(&sp->p, sp->t, sp->pp.leavers, sp->pp.leaver_count, sp->pp.leaver_capacity, sl->xlo,
                                                sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity, mg->fs, mg->surplus, st)) return e;
         } else if (int e = lpai_migrate_pack(&sp->p, sp->t, mg->edge_cols, sl->xlo, sl->xhi, mg->s_lo, mg->s_hi, sl->migrate_capacity,
@@ -314,7 +341,7 @@ static int slab_fold_unpack(const lpa_step_desc *d, void *st) {
 
 // Overlapped slab step (lpa_step_slab.overlap_cols): the edge part, the leaver pack and the whole exchange on the
 // communicator's second stream, the interior part on the caller's; joined before the fold.
-static int slab_push_overlapped(const lpa_step_desc *d, bool counters_zeroed, void *st) {
+static int slab_push_overlapped(const lpa_step_desc *d, StepCtx *ctx, bool counters_zeroed, void *st) {
     const lpa_step_slab *sl = d->slab;
     LPA_REQUIRE(d->nspecies <= 64, "lpa_step: more than 64 species");
     if (!counters_zeroed)
@@ -326,13 +353,13 @@ static int slab_push_overlapped(const lpa_step_desc *d, bool counters_zeroed, vo
         lpa_set_error("lpa_step: cannot fork the side stream");
         return LPA_ERR_HIP;
     }
-    if (int e = push_part(d, LPA_PART_EDGE, sl->overlap_cols, side)) return e;
-    if (int e = slab_pack_exchange(d, true, side)) return e;
+    if (int e = push_part(d, ctx, LPA_PART_EDGE, sl->overlap_cols, side)) return e;
+    if (int e = slab_pack_exchange(d, ctx, true, side)) return e;
     if (hipEventRecord((hipEvent_t)ev_done, (hipStream_t)side) != hipSuccess) {
         lpa_set_error("lpa_step: hipEventRecord failed");
         return LPA_ERR_HIP;
     }
-    if (int e = push_part(d, LPA_PART_INTERIOR, sl->overlap_cols, st)) return e;
+    if (int e = push_part(d, ctx, LPA_PART_INTERIOR, sl->overlap_cols, st)) return e;
     if (hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev_done, 0) != hipSuccess) {
         lpa_set_error("lpa_step: cannot join the side stream");
         return LPA_ERR_HIP;
@@ -367,6 +394,7 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     // the B guard stages of such a slab wrap the y / z guards of the x guard planes it advanced, too
     const int b_wrap = d->local_axes | (local_b(d) ? 8 : 0);
     bool headers_zeroed = false, counters_zeroed = false, exchanged = false;
+    StepCtx ctx;
     // overlapped push + exchange: only when this call runs on through the fold and every store is tile ordered
     bool overlap = slab && d->slab->overlap_cols > 0 && first_stage <= LPA_STAGE_PUSH && last_stage >= LPA_STAGE_FOLD;
     for (int s_ = 0; overlap && s_ < d->nspecies; s_++) {
@@ -434,16 +462,16 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
         }
         case LPA_STAGE_PUSH:    // pusher[ispec](dt, unified=True) for every species: :983-990
             if (overlap) {      // edge part + leaver pack + exchange on the second stream beside the interior part
-                e = slab_push_overlapped(d, counters_zeroed, stream);
+                e = slab_push_overlapped(d, &ctx, counters_zeroed, stream);
                 exchanged = !e;
             } else {
-                e = step_push(d, counters_zeroed, stream);
+                e = step_push(d, &ctx, counters_zeroed, stream);
             }
             headers_zeroed = true;
             break;
         case LPA_STAGE_FOLD:    // sync_currents (+ sync_particles between slabs): :1043-1080, 1155-1176
             if (slab) {
-                if (!exchanged) e = slab_pack_exchange(d, headers_zeroed, stream);
+                if (!exchanged) e = slab_pack_exchange(d, &ctx, headers_zeroed, stream);
                 if (!e) e = slab_fold_unpack(d, stream);
                 // (rho: with rho_exchange the jx plane rides with the B planes of LPA_STAGE_B2_GUARD and rho follows there)
                 if (!e && d->continuity && d->slab->rho_exchange != 1) e = slab_rho(d, stream);

@@ -60,6 +60,7 @@ class FusedStepMixin:
     # stream as well -- both message rounds of a step behind the interior push (LPA_STEP_E_ROUND_IN_LINE turns it off)
     overlap_e_round = True
     fused_fold_unpack = True   # native slab steps: the J / rho fold and every species' arrivals in one launch
+    fused_rest_pack = True     # ... and the leaver pack inside the launch that pushes the overflow list + arrival area
 
     def local_b(self):
         if not (self.local_b_guards and self.comm.size > 1 and self.can_fuse()):
@@ -132,6 +133,8 @@ class FusedStepMixin:
             d.flags |= _lib.LPA_STEP_E_ROUND_IN_LINE
         if not self.fused_fold_unpack:
             d.flags |= _lib.LPA_STEP_SEPARATE_UNPACK
+        if not self.fused_rest_pack:
+            d.flags |= _lib.LPA_STEP_SEPARATE_PACK
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):
