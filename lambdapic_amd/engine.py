@@ -189,11 +189,8 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
         self._ws = {}
         self._halo = None
         self._side = None       # second stream: J / rho guard planes travel while the interior is pushed
-        # hide the J / rho + particle exchange behind the interior tiles?  None = decide per step (``overlap``): the split
-        # costs ~20 us (an edge launch of few tiles) and hides one message round of 25-50 us of RCCL time plus the
-        # pack: it pays on big slabs over a real wire (a C2-sized slab, one-rank RCCL communicator: 2.049 -> 2.014-2.025 ms
-        # per step) and loses on small ones (C4 / 8: 0.297 -> 0.303-0.305; without a wire 0.234 -> 0.255); the 3-D engine
-        # (6.6 MB per face) keeps it on
+        # hide both message rounds behind the interior tiles?  None = decide per step (the ``overlap`` property); the 3-D
+        # engine keeps it on
         self._overlap = None
         self.reuse_slots = True   # arrivals take the slots freed by leavers of their tile (lpa_free_slots)
         self.defer_crossers = True
@@ -865,14 +862,21 @@ class PicEngine2D(RhoContinuityMixin, FusedStepMixin, MigrateWindowMixin):
     def n_x_local(self):
         return self.nx
 
-    OVERLAP_MIN_PARTICLES = 1 << 25
+    OVERLAP_MAX_EDGE_FRACTION = 0.10
 
     @property
     def overlap(self):
+        """None (the default) = behind a real RCCL communicator, when the edge tile columns are a small part of the slab:
+        one-rank RCCL communicator, ``run_steps`` -- 512 x 512 cells (edge 2 x 2 of 64 tile columns) 0.263 ms overlapped
+        against 0.278 in line, 1024 x 1024 1.937 against 1.980, 128 x 1024 (4 of 16 columns) 0.400 against 0.402; without a
+        wire the split only costs (0.221 against 0.215)"""
         if self._overlap is not None:
             return self._overlap
-        return (self.comm.size > 1 and self.comm.native is not None and self.comm.native_kind == _lib.LPA_COMM_RCCL and
-                sum(sp.n for sp in self.species) >= self.OVERLAP_MIN_PARTICLES)
+        if not (self.comm.size > 1 and self.comm.native is not None and self.comm.native_kind == _lib.LPA_COMM_RCCL):
+            return False
+        dt = getattr(self, "_dt_hint", 0.0)
+        cols = self.edge_columns(dt) if dt > 0 else 0
+        return cols > 0 and 2 * cols <= self.OVERLAP_MAX_EDGE_FRACTION * (self.nx // _lib.LPA_TILE_X)
 
     @overlap.setter
     def overlap(self, v):

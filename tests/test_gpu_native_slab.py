@@ -477,3 +477,23 @@ def test_bench_preflight_engines_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preflight-selftest"], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "pre-flight engines ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_2d_engine_chooses_the_overlap_by_the_edge_fraction():
+    """``PicEngine2D.overlap`` left at None: on behind a real RCCL communicator when the edge tile columns are at most a tenth
+    of the slab, off on narrow slabs and without a wire"""
+    from lambdapic_amd.dist import LoopbackComm
+    from lambdapic_amd.engine import PicEngine2D
+    dx, dy, dt = _problem2d()[:3]
+    seen = {}
+    for nx, rccl in ((512, True), (128, True), (512, False)):
+        eng = PicEngine2D(nx, 64, dx, dy, device="cuda:0", comm=LoopbackComm(nx * dx, 2, rccl=rccl), sort_interval=5)
+        eng.add_species(-1.602176634e-19, 9.1093837139e-31, capacity=4096)
+        assert eng.overlap is False             # (no step yet: no dt to size the edge columns from)
+        eng._dt_hint = dt
+        seen[(nx, rccl)] = (eng.overlap, eng.edge_columns(dt))
+        eng.overlap = True
+        assert eng.overlap is True
+        eng.overlap = None
+        eng.comm.close()
+    assert seen[(512, True)][0] is True and seen[(128, True)][0] is False and seen[(512, False)][0] is False, seen
