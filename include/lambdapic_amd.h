@@ -749,6 +749,10 @@ typedef struct {
  * (overflow list + arrival area) also packs the step's leavers -- the tiled kernel's list and, on the spot, those of the
  * particles it pushes itself; this flag keeps the pack a launch of its own (A/B). */
 #define LPA_STEP_SEPARATE_PACK 128
+/* LPA_STEP_SEPARATE_TAILS: the current reset of LPA_STAGE_RESET rides in the launch of LPA_STAGE_B1's sweep and the rho
+ * continuity update of LPA_STAGE_FOLD in that of LPA_STAGE_B2's when the stages run in one call (each is a ~5 us launch that
+ * touches nothing the sweep reads or writes); this flag keeps them launches of their own (A/B). */
+#define LPA_STEP_SEPARATE_TAILS 256
 #define LPA_STAGE_E1 0
 #define LPA_STAGE_B1 1
 #define LPA_STAGE_RESET 2

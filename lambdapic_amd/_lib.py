@@ -115,7 +115,7 @@ class lpa_step_desc(C.Structure):
 
 LPA_COMM_RCCL, LPA_COMM_LOOPBACK = 1, 2
 LPA_STEP_DEFER_E2_GUARDS, LPA_STEP_DEFER_E2, LPA_STEP_E1_DOUBLE = 1, 2, 4
-LPA_STEP_B_EXT_LO, LPA_STEP_B_EXT_HI, LPA_STEP_E_ROUND_IN_LINE, LPA_STEP_SEPARATE_UNPACK, LPA_STEP_SEPARATE_PACK = 8, 16, 32, 64, 128
+LPA_STEP_B_EXT_LO, LPA_STEP_B_EXT_HI, LPA_STEP_E_ROUND_IN_LINE, LPA_STEP_SEPARATE_UNPACK, LPA_STEP_SEPARATE_PACK, LPA_STEP_SEPARATE_TAILS = 8, 16, 32, 64, 128, 256
 LPA_STAGE_E1, LPA_STAGE_B1, LPA_STAGE_RESET, LPA_STAGE_PUSH, LPA_STAGE_FOLD, LPA_STAGE_B2, LPA_STAGE_B2_GUARD, \
     LPA_STAGE_E2 = range(8)
 

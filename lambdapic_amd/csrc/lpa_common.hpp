@@ -41,8 +41,11 @@ static inline int lpa_grid_ok(const lpa_grid *g, int dim, int need_j) {
 // B sweep of a slab split along x also advances that many x guard planes at the low / high face -- FDTD_EXT_* there)
 // (`b_part`: 0 the whole sweep; 1 / 2: the B sweep in two launches -- nodes [0, nx - 1) / node nx - 1 + the guard planes:
 // the part that reads no E guard plane and the part that does, FDTD_B_* there)
+// (`tail`, may be NULL: a small grid-wide job the B sweep's launch carries -- lpa_tail.hpp; lpai_tail_rides says whether it can)
+struct lpai_tail;
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, int ext_lo, int ext_hi, int b_part, void *stream);
+              int twice, int ext_lo, int ext_hi, int b_part, const lpai_tail *tail, void *stream);
+int lpai_tail_rides(const lpa_grid *g, int dim, const lpai_tail *t);
 // the global-memory remainder of a tiled push in one launch: overflow list (NULL = none) + the loose range
 // [loose_first, loose_first + min(loose_count, *loose_limit)) (loose_limit: device cursor of the arrival area, may be NULL)
 // (`pack`, may be NULL: the step's leaver pack rides in the launch -- lpa_migrate.hpp)

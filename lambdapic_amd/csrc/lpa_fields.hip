@@ -6,6 +6,7 @@
 
 #include "lpa_common.hpp"
 #include "lpa_fold.hpp"
+#include "lpa_tail.hpp"
 
 // ---- error string ----------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -97,7 +98,8 @@ __global__ void __launch_bounds__(256) k_fdtd_e_2d(GridV g, double bfac, double 
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt, int wrap) {
+__global__ void __launch_bounds__(256) k_fdtd_b_2d(GridV g, double dt, int wrap, BTail tail) {
+    b_tail(g, tail);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = fdtd_b_row((int)blockIdx.y, wrap, g.nx);
     if (j >= g.ny) return;
@@ -127,7 +129,8 @@ __global__ void __launch_bounds__(256) k_fdtd_e_3d(GridV g, double bfac, double 
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, k, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt, int wrap) {
+__global__ void __launch_bounds__(256) k_fdtd_b_3d(GridV g, double dt, int wrap, BTail tail) {
+    b_tail(g, tail);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = fdtd_b_row((int)blockIdx.z, wrap, g.nx);
     if (k >= g.nz) return;
@@ -153,11 +156,11 @@ static int fdtd_e_2d(const lpa_grid *g, double dt, double eps0, int wrap, void *
 }
 extern "C" int lpa_fdtd_e_2d(const lpa_grid *g, double dt, double eps0, void *stream) { return fdtd_e_2d(g, dt, eps0, 0, stream); }
 
-static int fdtd_b_2d(const lpa_grid *g, double dt, int wrap, void *stream) {
+static int fdtd_b_2d(const lpa_grid *g, double dt, int wrap, void *stream, const BTail &tail = BTail{}) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0), "lpa_fdtd_b_2d: bad grid");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, fdtd_b_rows(wrap, g->nx));
-    hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
+    hipLaunchKernelGGL(k_fdtd_b_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap, tail);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_2d");
     return LPA_OK;
 }
@@ -176,12 +179,12 @@ static int fdtd_e_3d(const lpa_grid *g, double dt, double eps0, int wrap, void *
 }
 extern "C" int lpa_fdtd_e_3d(const lpa_grid *g, double dt, double eps0, void *stream) { return fdtd_e_3d(g, dt, eps0, 0, stream); }
 
-static int fdtd_b_3d(const lpa_grid *g, double dt, int wrap, void *stream) {
+static int fdtd_b_3d(const lpa_grid *g, double dt, int wrap, void *stream, const BTail &tail = BTail{}) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0), "lpa_fdtd_b_3d: bad grid");
     LPA_REQUIRE(g->ny <= 65535 && g->nx <= 65535, "lpa_fdtd_b_3d: nx, ny must be <= 65535");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, fdtd_b_rows(wrap, g->nx));
-    hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap);
+    hipLaunchKernelGGL(k_fdtd_b_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, wrap, tail);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_3d");
     return LPA_OK;
 }
@@ -385,7 +388,9 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_2d(GridV g, double bf
     store3_wrapped(g, g.ex, g.ey, g.ez, c, i, j, 0, wrap, ex, ey, ez);
 }
 
-__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay, int wrap) {
+__global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_2d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay, int wrap,
+                                                              BTail tail) {
+    b_tail(g, tail);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = fdtd_b_row((int)blockIdx.y, wrap, g.nx);
     if (j >= g.ny) return;
@@ -439,13 +444,13 @@ extern "C" int lpa_fdtd_e_cpml_fused_2d(const lpa_grid *g, double dt, double eps
 }
 
 static int fdtd_b_cpml_fused_2d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay, int wrap,
-                                void *stream) {
+                                void *stream, const BTail &tail = BTail{}) {
     LPA_REQUIRE(lpa_grid_ok(g, 2, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny),
                 "lpa_fdtd_b_cpml_fused_2d: bad args");
     GridV v = make_gridv(g, 2);
     dim3 grid((g->ny + 255) / 256, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_2d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
-                       make_axisv(ay), wrap);
+                       make_axisv(ay), wrap, tail);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_2d");
     return LPA_OK;
 }
@@ -508,7 +513,8 @@ __global__ void __launch_bounds__(256) k_fdtd_e_cpml_fused_3d(GridV g, double bf
 }
 
 __global__ void __launch_bounds__(256) k_fdtd_b_cpml_fused_3d(GridV g, double dt, CpmlAxisV ax, CpmlAxisV ay,
-                                                              CpmlAxisV az, int wrap) {
+                                                              CpmlAxisV az, int wrap, BTail tail) {
+    b_tail(g, tail);
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y, i = fdtd_b_row((int)blockIdx.z, wrap, g.nx);
     if (k >= g.nz) return;
@@ -558,14 +564,14 @@ extern "C" int lpa_fdtd_e_cpml_fused_3d(const lpa_grid *g, double dt, double eps
 }
 
 static int fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_cpml_axis *ax, const lpa_cpml_axis *ay,
-                                const lpa_cpml_axis *az, int wrap, void *stream) {
+                                const lpa_cpml_axis *az, int wrap, void *stream, const BTail &tail = BTail{}) {
     LPA_REQUIRE(lpa_grid_ok(g, 3, 0) && cpml_axis_ok(ax, g->nx) && cpml_axis_ok(ay, g->ny) && cpml_axis_ok(az, g->nz) &&
                     g->ny <= 65535 && g->nx <= 65535,
                 "lpa_fdtd_b_cpml_fused_3d: bad args");
     GridV v = make_gridv(g, 3);
     dim3 grid((g->nz + 255) / 256, g->ny, fdtd_b_rows(wrap, g->nx));
     hipLaunchKernelGGL(k_fdtd_b_cpml_fused_3d, grid, dim3(256), 0, (hipStream_t)stream, v, dt, make_axisv(ax),
-                       make_axisv(ay), make_axisv(az), wrap);
+                       make_axisv(ay), make_axisv(az), wrap, tail);
     LPA_CHECK_LAUNCH("lpa_fdtd_b_cpml_fused_3d");
     return LPA_OK;
 }
@@ -576,8 +582,42 @@ extern "C" int lpa_fdtd_b_cpml_fused_3d(const lpa_grid *g, double dt, const lpa_
 
 // one half step of E or B over the slab with the guard wrap of the axes in `wrap` fused in (lpa_step); ax[]: the fused
 // CPML descriptors, all NULL = the plain Yee update
+// can the B sweep of this grid carry `t` (lpa_tail.hpp)?  Fills the device form.  The reset needs jx jy jz [rho] in one
+// allocation (it is one memset-like range), like lpai_reset_step's single launch
+static bool make_btail(const lpa_grid *g, int dim, const lpai_tail *t, BTail *out) {
+    *out = BTail{};
+    if (!t || t->mode == B_TAIL_NONE || !g->jx || !g->jy || !g->jz || !g->rho) return false;
+    const long cnt = (long)(g->nx + 2 * g->ng) * (g->ny + 2 * g->ng) * (dim == 3 ? (long)(g->nz + 2 * g->ng) : 1);
+    if (t->mode == B_TAIL_RESET) {
+        const bool contiguous = g->jy == g->jx + cnt && g->jz == g->jy + cnt && (!t->with_rho || g->rho == g->jz + cnt);
+        if (!contiguous || t->nwords < 0 || t->nwords > 32) return false;
+        out->mode = B_TAIL_RESET;
+        out->a = g->jx; out->n = (t->with_rho ? 4 : 3) * cnt;
+        out->b = t->also; out->nb = t->also ? cnt : 0;
+        out->nw = t->nwords;
+        for (int i = 0; i < t->nwords; i++) out->w.w[i] = t->words[i];
+        return true;
+    }
+    if (t->mode == B_TAIL_RHO) {
+        if (!(t->dt > 0) || (t->split_x && (t->periodic_axes & 1)) || t->split_x < 0 || t->split_x > 3 || ((t->split_x & 1) && !t->left))
+            return false;
+        out->mode = B_TAIL_RHO;
+        out->dtdx = t->dt / g->dx; out->dtdy = t->dt / g->dy; out->dtdz = dim == 3 ? t->dt / g->dz : 0.0;
+        out->mx = t->split_x ? ((t->split_x & 1 ? RHO_NB_LO : 0) | (t->split_x & 2 ? RHO_NB_HI : 0)) : (t->periodic_axes & 1);
+        out->my = (t->periodic_axes >> 1) & 1; out->mz = (t->periodic_axes >> 2) & 1;
+        out->left = t->left;
+        return true;
+    }
+    return false;
+}
+
+int lpai_tail_rides(const lpa_grid *g, int dim, const lpai_tail *t) {
+    BTail b;
+    return g && make_btail(g, dim, t, &b) ? 1 : 0;
+}
+
 int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, const lpa_cpml_axis *const *ax, int wrap,
-              int twice, int ext_lo, int ext_hi, int b_part, void *stream) {
+              int twice, int ext_lo, int ext_hi, int b_part, const lpai_tail *tail, void *stream) {
     LPA_REQUIRE(g && g->nx >= g->ng && g->ny >= g->ng && (dim == 2 || g->nz >= g->ng), "lpai_fdtd: slab thinner than the guard");
     LPA_REQUIRE(!twice || efield, "lpai_fdtd: only the E sweep does two half steps at once");
     LPA_REQUIRE(ext_lo >= 0 && ext_hi >= 0 && ext_lo <= g->ng && ext_hi < g->ng && ext_lo <= 3 && ext_hi <= 3 &&
@@ -589,13 +629,16 @@ int lpai_fdtd(const lpa_grid *g, int dim, int efield, double dt, double eps0, co
     wrap = (wrap & 7) | (twice ? FDTD_TWICE : 0) | (ext_lo << FDTD_EXT_LO_SHIFT) | (ext_hi << FDTD_EXT_HI_SHIFT) |
            (b_part == 1 ? FDTD_B_INTERIOR : (b_part == 2 ? FDTD_B_EDGE : 0));
     const bool cpml = ax && ax[0];
+    BTail bt{};
+    LPA_REQUIRE(!tail || (!efield && b_part != 2 && make_btail(g, dim, tail, &bt)),
+                "lpai_fdtd: this sweep cannot carry the tail (ask lpai_tail_rides first)");
     if (dim == 2) {
         if (efield) return cpml ? fdtd_e_cpml_fused_2d(g, dt, eps0, ax[0], ax[1], wrap, stream) : fdtd_e_2d(g, dt, eps0, wrap, stream);
-        return cpml ? fdtd_b_cpml_fused_2d(g, dt, ax[0], ax[1], wrap, stream) : fdtd_b_2d(g, dt, wrap, stream);
+        return cpml ? fdtd_b_cpml_fused_2d(g, dt, ax[0], ax[1], wrap, stream, bt) : fdtd_b_2d(g, dt, wrap, stream, bt);
     }
     if (efield)
         return cpml ? fdtd_e_cpml_fused_3d(g, dt, eps0, ax[0], ax[1], ax[2], wrap, stream) : fdtd_e_3d(g, dt, eps0, wrap, stream);
-    return cpml ? fdtd_b_cpml_fused_3d(g, dt, ax[0], ax[1], ax[2], wrap, stream) : fdtd_b_3d(g, dt, wrap, stream);
+    return cpml ? fdtd_b_cpml_fused_3d(g, dt, ax[0], ax[1], ax[2], wrap, stream, bt) : fdtd_b_3d(g, dt, wrap, stream, bt);
 }
 
 // ---- 3-D CPML (cpml.py:431-475 kappa-scaled update, :609-729 psi recursions) ---------------------------
@@ -1144,8 +1187,6 @@ extern "C" int lpa_halo_faces(const lpa_grid *g, int op, int which, double *buf_
 // =====================================================================================================
 // helpers of lpa_step (internal): per-step counter reset, and the slab form of the J / rho face fold
 // =====================================================================================================
-struct Words32 { uint32_t *w[32]; };
-
 __global__ void k_zero_words(Words32 a, int n) {
     if ((int)threadIdx.x < n) *a.w[threadIdx.x] = 0u;
 }

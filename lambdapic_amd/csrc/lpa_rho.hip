@@ -9,6 +9,7 @@
 // two real deposits rho is advanced from the folded currents here -- streaming kernels over the grid, 5-6 doubles per
 // node, against 27 LDS atomics per particle.
 #include "lpa_common.hpp"
+#include "lpa_tail.hpp"
 
 // ---- jx jy jz = 0 (rho persists) ---------------------------------------------------------------------------------
 extern "C" int lpa_reset_j(const lpa_grid *g, void *stream) {
@@ -31,40 +32,15 @@ extern "C" int lpa_reset_j(const lpa_grid *g, void *stream) {
     return LPA_OK;
 }
 
-// ---- rho -= dt div J -------------------------------------------------------------------------------------------------
-// mode per axis: bit 0 = folded inside the slab (periodic: interior nodes, node 0 -> node n - 1); else bit 1 / bit 2 =
-// the low / high face has a neighbour slab (its guard planes were sent away: interior nodes on that side, node 0 ->
-// the left neighbour's plane); a face with neither is open: its guard nodes are updated too, on the padded torus --
-// where the deposit itself lands
-constexpr int RHO_PERIODIC = 1, RHO_NB_LO = 2, RHO_NB_HI = 4;
-__device__ __forceinline__ bool rho_axis(int c, int n, int ng, int N, int mode, int &prev) {
-    if (mode & RHO_PERIODIC) {
-        if (c < ng || c >= ng + n) return false;
-        prev = c == ng ? ng + n - 1 : c - 1;
-        return true;
-    }
-    if (((mode & RHO_NB_LO) && c < ng) || ((mode & RHO_NB_HI) && c >= ng + n)) return false;
-    prev = c == 0 ? N - 1 : c - 1;
-    return true;
-}
-
+// ---- rho -= dt div J (the per-cell body: lpa_tail.hpp -- a B sweep's launch can carry it too) --------------------------------
 __global__ void __launch_bounds__(256) k_rho_continuity(GridV g, double dtdx, double dtdy, double dtdz, int mx, int my,
                                                         int mz, const double *__restrict__ left) {
-    const bool d3 = g.NZ > 1;
     // one x plane per blockIdx.y, its (y, z) nodes flattened over blockIdx.x (a 262-node z row per block would leave
     // the second of its two 256-thread blocks with six lanes)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= g.NY * g.NZ) return;
     const int cx = blockIdx.y, cy = f / g.NZ, cz = f - cy * g.NZ;
-    int px, py, pz = 0;
-    if (!rho_axis(cx, g.nx, g.ng, g.NX, mx, px) || !rho_axis(cy, g.ny, g.ng, g.NY, my, py)) return;
-    if (d3 && !rho_axis(cz, g.nz, g.ng, g.NZ, mz, pz)) return;
-    const long sX = (long)g.NY * g.NZ, sY = g.NZ;
-    const long c = cx * sX + cy * sY + cz;
-    const double jxp = ((mx & RHO_NB_LO) && cx == g.ng) ? left[cy * sY + cz] : g.jx[px * sX + cy * sY + cz];
-    double div = (g.jx[c] - jxp) * dtdx + (g.jy[c] - g.jy[cx * sX + py * sY + cz]) * dtdy;
-    if (d3) div += (g.jz[c] - g.jz[cx * sX + cy * sY + pz]) * dtdz;
-    g.rho[c] -= div;
+    rho_continuity_cell(g, cx, cy, cz, dtdx, dtdy, dtdz, mx, my, mz, left);
 }
 
 extern "C" int lpa_rho_continuity(const lpa_grid *g, double dt, int periodic_axes, int split_x,

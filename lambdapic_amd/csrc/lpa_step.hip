@@ -17,6 +17,7 @@
 #include "lpa_common.hpp"
 #include "lpa_fold.hpp"
 #include "lpa_migrate.hpp"
+#include "lpa_tail.hpp"
 
 static long plane_of(const lpa_grid *g) { return (long)(g->ny + 2 * g->ng) * (g->nz > 1 ? g->nz + 2 * g->ng : 1); }
 
@@ -50,10 +51,12 @@ static int slab_exchange_guards(const lpa_step_desc *d, int which, bool with_jx,
 static bool local_b(const lpa_step_desc *d) { return (d->flags & (LPA_STEP_B_EXT_LO | LPA_STEP_B_EXT_HI)) != 0; }
 
 // (`b_part`: see lpai_fdtd -- 1 / 2 = the part of a B sweep that reads no E guard plane / the part that does)
-static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false, int b_part = 0) {
+static int step_fields(const lpa_step_desc *d, bool efield, int wrap, void *st, bool twice = false, int b_part = 0,
+                       const lpai_tail *tail = nullptr) {
     const int ng = d->grid.ng > 3 ? 3 : d->grid.ng;
     const int lo = (!efield && (d->flags & LPA_STEP_B_EXT_LO)) ? ng : 0, hi = (!efield && (d->flags & LPA_STEP_B_EXT_HI)) ? ng - 1 : 0;
-    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, lo, hi, b_part, st);
+    return lpai_fdtd(&d->grid, d->dim, efield, 0.5 * d->dt, d->eps0, efield ? d->e_axes : d->b_axes, wrap, twice, lo, hi, b_part,
+                     tail, st);
 }
 
 static int stream_fork(void *from, void *to, void *ev) {
@@ -367,14 +370,23 @@ static int slab_push_overlapped(const lpa_step_desc *d, StepCtx *ctx, bool count
     return LPA_OK;
 }
 
-static int slab_rho(const lpa_step_desc *d, void *st) {
+// the arguments of the slab's rho continuity update (lpa_rho_continuity)
+static int slab_rho_args(const lpa_step_desc *d, int *split, const double **left) {
     const lpa_step_slab *sl = d->slab;
     int32_t info[6];
     if (int e = lpa_comm_info(sl->comm, info)) return e;
-    const int split = (info[3] >= 0 ? 1 : 0) | (info[4] >= 0 ? 2 : 0);
+    *split = (info[3] >= 0 ? 1 : 0) | (info[4] >= 0 ? 2 : 0);
     // (rho_exchange 2: the fold left the neighbour's folded plane in my jx guard plane at node -1)
-    const double *left = sl->rho_exchange == 2 ? d->grid.jx + (long)(d->grid.ng - 1) * plane_of(&d->grid) : sl->jx_left_plane;
-    return lpa_rho_continuity(&d->grid, d->dt, d->local_axes, split, info[3] >= 0 ? left : nullptr, st);
+    const double *l = sl->rho_exchange == 2 ? d->grid.jx + (long)(d->grid.ng - 1) * plane_of(&d->grid) : sl->jx_left_plane;
+    *left = info[3] >= 0 ? l : nullptr;
+    return LPA_OK;
+}
+
+static int slab_rho(const lpa_step_desc *d, void *st) {
+    int split;
+    const double *left;
+    if (int e = slab_rho_args(d, &split, &left)) return e;
+    return lpa_rho_continuity(&d->grid, d->dt, d->local_axes, split, left, st);
 }
 
 extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage, void *stream) {
@@ -395,6 +407,12 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
     const int b_wrap = d->local_axes | (local_b(d) ? 8 : 0);
     bool headers_zeroed = false, counters_zeroed = false, exchanged = false;
     StepCtx ctx;
+    // two ~5 us launches ride in the B sweeps' (lpa_tail.hpp): the reset that follows the first B half step and the rho
+    // continuity update that precedes the second
+    const bool tails = !(d->flags & LPA_STEP_SEPARATE_TAILS);
+    bool reset_rode = false, rho_pending = false;
+    uint32_t *rw[11 * 64 + 1];     // (the reset's counter words: alive until the B1 launch that carries them was issued)
+    lpai_tail rho_tail{};
     // overlapped push + exchange: only when this call runs on through the fold and every store is tile ordered
     bool overlap = slab && d->slab->overlap_cols > 0 && first_stage <= LPA_STAGE_PUSH && last_stage >= LPA_STAGE_FOLD;
     for (int s_ = 0; overlap && s_ < d->nspecies; s_++) {
@@ -430,16 +448,44 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
             }
             break;
         }
-        case LPA_STAGE_B1:      // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
+        case LPA_STAGE_B1: {    // update_bfield(dt / 2) + sync_guard_fields(B): :954-960
+            // the reset of LPA_STAGE_RESET rides in this sweep's launch when it follows in the same call
+            lpai_tail rt{};
+            const lpai_tail *tail = nullptr;
+            if (tails && last_stage >= LPA_STAGE_RESET) {
+                int ns = 0;
+                if (last_stage >= LPA_STAGE_PUSH) {
+                    ns = step_counters(d, rw, true);
+                    if (ns < 0) return LPA_ERR_ARG;
+                    if (ns > 31) ns = 0;
+                }
+                int nw = ns;
+                rt.mode = B_TAIL_RESET;
+                rt.with_rho = d->continuity ? 0 : 1;
+                rt.also = (!d->continuity && d->absorbed) ? d->absorbed_spill : nullptr;
+                if (!d->continuity && d->absorbed_count) rw[nw++] = d->absorbed_count;
+                rt.words = rw; rt.nwords = nw;
+                if (lpai_tail_rides(g, d->dim, &rt)) {
+                    tail = &rt;
+                    reset_rode = true;
+                    counters_zeroed = ns > 0;
+                }
+            }
             if (e_side) {       // (behind the E planes on the second stream: what reads them; here: everything else)
                 e = step_fields(d, false, d->local_axes, side, false, 2);
-                if (!e) e = step_fields(d, false, d->local_axes, stream, false, 1);
+                if (!e) e = step_fields(d, false, d->local_axes, stream, false, 1, tail);
                 break;
             }
-            e = step_fields(d, false, d->local_axes, stream);
+            e = step_fields(d, false, d->local_axes, stream, false, 0, tail);
             if (!e && slab && !local_b(d)) e = slab_exchange_guards(d, 2, false, stream);
             break;
+        }
         case LPA_STAGE_RESET: { // current_depositor.reset(): :980-981
+            if (reset_rode) {   // (LPA_STAGE_B1's launch zeroed J [, rho] and the counters; what is left: the absorbed charge)
+                if (d->continuity && d->absorbed)
+                    e = lpa_rho_absorbed_spill(g, d->absorbed, d->absorbed_count, d->absorbed_capacity, d->absorbed_spill, stream);
+                break;
+            }
             // (+ the per-step counters of the push that follows in the same call: one launch for both)
             uint32_t *w[11 * 64 + 1];
             int ns = 0;
@@ -474,15 +520,29 @@ extern "C" int lpa_step(const lpa_step_desc *d, int first_stage, int last_stage,
                 if (!exchanged) e = slab_pack_exchange(d, &ctx, headers_zeroed, stream);
                 if (!e) e = slab_fold_unpack(d, stream);
                 // (rho: with rho_exchange the jx plane rides with the B planes of LPA_STAGE_B2_GUARD and rho follows there)
-                if (!e && d->continuity && d->slab->rho_exchange != 1) e = slab_rho(d, stream);
+                if (!e && d->continuity && d->slab->rho_exchange != 1) {
+                    int split;
+                    const double *left;
+                    e = slab_rho_args(d, &split, &left);
+                    rho_tail = lpai_tail{B_TAIL_RHO, 0, nullptr, nullptr, 0, d->dt, d->local_axes, split, left};
+                    // (rides in the B sweep of LPA_STAGE_B2 when that follows in this call)
+                    if (!e && tails && last_stage >= LPA_STAGE_B2 && lpai_tail_rides(g, d->dim, &rho_tail)) rho_pending = true;
+                    else if (!e) e = slab_rho(d, stream);
+                }
                 break;
             }
             e = lpai_fold_all(g, d->local_axes, nullptr, nullptr, nullptr, stream);
-            if (!e && d->continuity) e = lpa_rho_continuity(g, d->dt, d->local_axes, 0, nullptr, stream);
+            if (!e && d->continuity) {
+                rho_tail = lpai_tail{B_TAIL_RHO, 0, nullptr, nullptr, 0, d->dt, d->local_axes, 0, nullptr};
+                if (tails && last_stage >= LPA_STAGE_B2 && lpai_tail_rides(g, d->dim, &rho_tail)) rho_pending = true;
+                else e = lpa_rho_continuity(g, d->dt, d->local_axes, 0, nullptr, stream);
+            }
             break;
         case LPA_STAGE_B2:      // update_bfield(dt / 2): :1098 (the '_laser' stage follows: :1101)
             // a call that runs on through LPA_STAGE_B2_GUARD has no injection in between: the wrap rides in the sweep
-            e = step_fields(d, false, last_stage >= LPA_STAGE_B2_GUARD ? d->local_axes : 0, stream);
+            e = step_fields(d, false, last_stage >= LPA_STAGE_B2_GUARD ? d->local_axes : 0, stream, false, 0,
+                            rho_pending ? &rho_tail : nullptr);
+            rho_pending = false;
             break;
         case LPA_STAGE_B2_GUARD:    // sync_guard_fields(B): :1103-1108
             if (first_stage > LPA_STAGE_B2) e = lpa_guard_wrap(g, 2, b_wrap, stream);

@@ -61,6 +61,7 @@ class FusedStepMixin:
     overlap_e_round = True
     fused_fold_unpack = True   # native slab steps: the J / rho fold and every species' arrivals in one launch
     fused_rest_pack = True     # ... and the leaver pack inside the launch that pushes the overflow list + arrival area
+    fused_sweep_tails = True   # the current reset rides in the first B sweep's launch, the rho continuity update in the second's
 
     def local_b(self):
         if not (self.local_b_guards and self.comm.size > 1 and self.can_fuse()):
@@ -135,6 +136,8 @@ class FusedStepMixin:
             d.flags |= _lib.LPA_STEP_SEPARATE_UNPACK
         if not self.fused_rest_pack:
             d.flags |= _lib.LPA_STEP_SEPARATE_PACK
+        if not self.fused_sweep_tails:
+            d.flags |= _lib.LPA_STEP_SEPARATE_TAILS
         keep = []
         if self.pml is not None:
             for fld, arr in ((True, d.e_axes), (False, d.b_axes)):
